@@ -1,0 +1,74 @@
+"""Oracle vs the REFERENCE-PINNED extraction fixtures (tests/golden/extract_*.npz, produced by
+running the reference's own utils.k_hop_subgraph / utils.neighbors — see make_golden.py) and
+vs its own committed fp64 diffusion vectors (regression pin)."""
+import numpy as np
+import pytest
+import scipy.sparse as ssp
+
+import oracle
+from conftest import DIFFUSION_NAMES, EXTRACT_NAMES, csr_from_undirected, load_diffusion, load_extract
+
+
+def _ragged(blob, key, i):
+    off = blob[key + "_off"]
+    return blob[key][off[i]:off[i + 1]]
+
+
+@pytest.mark.parametrize("name", EXTRACT_NAMES)
+def test_extraction_matches_reference(name):
+    g = load_extract(name)
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    for h in g["hops"]:
+        for li, (s, d) in enumerate(g["links"]):
+            nodes, sub, dists, _, _ = oracle.k_hop_subgraph(int(s), int(d), int(h), A)
+            assert nodes[0] == s and nodes[1] == d
+            order = np.lexsort((np.asarray(nodes), np.asarray(dists)))
+            # node-index sets per hop: bit-exact
+            np.testing.assert_array_equal(np.asarray(nodes)[order], _ragged(g, f"h{h}_nodes", li))
+            np.testing.assert_array_equal(np.asarray(dists)[order], _ragged(g, f"h{h}_dists", li))
+            # masked induced matrix incl. explicit zeros (K1, K2)
+            sub = ssp.csr_matrix(sub)
+            r = np.repeat(np.arange(sub.shape[0]), np.diff(sub.indptr))
+            trip = np.stack([np.asarray(nodes)[r], np.asarray(nodes)[sub.indices],
+                             sub.data.astype(np.int64)], axis=1)
+            trip = trip[np.lexsort((trip[:, 1], trip[:, 0]))]
+            np.testing.assert_array_equal(trip, _ragged(g, f"h{h}_sub", li))
+            # PoS Plus row selection (K4)
+            cn = oracle.neighbors({0}, sub) & oracle.neighbors({1}, sub)
+            np.testing.assert_array_equal(sorted(nodes[a] for a in cn), _ragged(g, f"h{h}_cn", li))
+
+
+def test_set_order_variant_same_sets():
+    g = load_extract("rand300")
+    A = csr_from_undirected(int(g["num_nodes"]), g["edges"])
+    s, d = (int(v) for v in g["links"][0])
+    a = oracle.k_hop_subgraph(s, d, 2, A, order="canonical")
+    b = oracle.k_hop_subgraph(s, d, 2, A, order="set")
+    assert sorted(zip(a[2], a[0])) == sorted(zip(b[2], b[0]))
+
+
+@pytest.mark.parametrize("name", DIFFUSION_NAMES)
+def test_diffusion_regression(name):
+    g = load_diffusion(name)
+    n, K, h = int(g["num_nodes"]), int(g["K"]), int(g["num_hops"])
+    A = csr_from_undirected(n, g["edges"])
+    li = g["links"].T
+    kw = {"sign_k": K, "k_node_set_strategy": "intersection"}
+    X = g["X"]
+    for tag, lst in [
+        ("pos", oracle.get_PoS_prepped_ds(li, h, A, X, 1, kw, dtype=np.float64)),
+        ("plus", oracle.get_PoS_Plus_prepped_ds(li, h, A, X, 1, kw, dtype=np.float64)),
+        ("sop", oracle.get_SoP_prepped_ds(oracle.global_normalized_powers(A, K, np.float64), li, A,
+                                          X, 1, dtype=np.float64)),
+    ]:
+        rows, row_ptr, _ = oracle.collate_rows(lst, K)
+        np.testing.assert_array_equal(row_ptr, g[f"{tag}_row_ptr"])
+        np.testing.assert_allclose(rows, g[f"{tag}_rows"], rtol=1e-12, atol=1e-14)
+        # fp32 mode of the oracle (the reference's precision) stays inside the 1e-5 band
+        if tag == "pos":
+            lst32 = oracle.get_PoS_prepped_ds(li, h, A, X.astype(np.float32), 1, kw,
+                                              dtype=np.float32)
+            r32, _, _ = oracle.collate_rows(lst32, K)
+            scale = np.abs(rows).max(axis=-1, keepdims=True) + 1e-30
+            assert np.max(np.abs(r32 - rows) / scale) < 1e-5

@@ -1,0 +1,103 @@
+"""Hand-derived known answers — these anchor the *diffusion* half of the oracle,
+which the reference itself cannot pin (its arithmetic is in torch_sparse, not installed)."""
+import numpy as np
+import scipy.sparse as ssp
+
+import oracle
+from conftest import csr_from_undirected
+
+KW = {"sign_k": 3, "k_node_set_strategy": "intersection"}
+
+
+def test_pair_graph_everything_masked():
+    # (i) single edge 0-1, link (0,1): masked subgraph empty -> deg 0 -> inf->0 -> x_i = 0
+    A = csr_from_undirected(2, [[0, 1]])
+    X = np.array([[2.0, 3.0], [5.0, 7.0]])
+    (d,) = oracle.get_PoS_prepped_ds(np.array([[0], [1]]), 2, A, X, 1, KW, dtype=np.float64)
+    np.testing.assert_array_equal(d["x"], [[1, 2, 3], [1, 5, 7]])
+    for i in (1, 2, 3):
+        np.testing.assert_array_equal(d[f"x{i}"], np.zeros((2, 3)))
+
+
+def test_triangle_pos_and_plus():
+    # (ii) triangle, link (0,1): after masking edges 0-2, 1-2; d=(1,1,2); Â[0,2]=Â[1,2]=1/√2
+    A = csr_from_undirected(3, [[0, 1], [0, 2], [1, 2]])
+    X = np.array([[1.0, 10.0], [2.0, 20.0], [3.0, 30.0]])
+    li = np.array([[0], [1]])
+    (d,) = oracle.get_PoS_prepped_ds(li, 1, A, X, 1, KW, dtype=np.float64)
+    s = 1 / np.sqrt(2)
+    np.testing.assert_allclose(d["x1"], [[0, 3 * s, 30 * s], [0, 3 * s, 30 * s]])
+    # Â²[0,0] = Â²[0,1] = 1/2 -> x2[0] = ½[1|X0] + ½[1|X1]
+    np.testing.assert_allclose(d["x2"][0], [1.0, 1.5, 15.0])
+    np.testing.assert_allclose(d["x2"][1], [1.0, 1.5, 15.0])
+    # Â³ = Â (eigen-structure of the path 0-2-1): x3 == x1
+    np.testing.assert_allclose(d["x3"], d["x1"])
+    (p,) = oracle.get_PoS_Plus_prepped_ds(li, 1, A, X, 1, KW, dtype=np.float64)
+    np.testing.assert_array_equal(p["rows_global"], [0, 1, 2])          # CN = {2}, R = 3
+    np.testing.assert_allclose(p["x"], [[1, 1, 10], [1, 2, 20], [0, 3, 30]])
+    # row of node 2: Â[2,0]=Â[2,1]=1/√2 -> x1[2] = s[1|X0] + s[1|X1]
+    np.testing.assert_allclose(p["x1"][2], [2 * s, 3 * s, 30 * s])
+
+
+def test_isolated_node_inf_to_zero():
+    # (iii) star 0-{1,2,3,4}, 4-5, node 6 isolated; link (0,6): row of node 6 has deg 0
+    A = csr_from_undirected(7, [[0, 1], [0, 2], [0, 3], [0, 4], [4, 5]])
+    X = np.arange(14, dtype=np.float64).reshape(7, 2) + 1
+    (d,) = oracle.get_PoS_prepped_ds(np.array([[0], [6]]), 2, A, X, 0, KW, dtype=np.float64)
+    assert np.all(np.isfinite(d["x1"]))
+    np.testing.assert_array_equal(d["x1"][1], 0)
+    np.testing.assert_array_equal(d["x3"][1], 0)
+    # x1[0] = Σ_{j=1..4} Â[0,j] X_j ; deg(0)=4, deg(1..3)=1, deg(4)=2
+    w = np.array([0.5, 0.5, 0.5, 1 / np.sqrt(8)])
+    np.testing.assert_allclose(d["x1"][0, 1:], w @ X[1:5])
+    assert d["x1"][0, 0] == 0                                          # label column: Â[0,0]+Â[0,6]
+
+
+def test_sop_triangle():
+    # (iv) global (unmasked) triangle: all deg 2, Â = ½(J−I), Â² = ¼(J+I)
+    A = csr_from_undirected(3, [[0, 1], [0, 2], [1, 2]])
+    X = np.array([[1.0, 10.0], [2.0, 20.0], [3.0, 30.0]])
+    P = oracle.global_normalized_powers(A, 2, np.float64)
+    np.testing.assert_allclose(P[0].toarray(), 0.5 * (np.ones((3, 3)) - np.eye(3)))
+    np.testing.assert_allclose(P[1].toarray(), 0.25 * (np.ones((3, 3)) + np.eye(3)))
+    (d,) = oracle.get_SoP_prepped_ds(P, np.array([[0], [1]]), A, X, 1, dtype=np.float64)
+    np.testing.assert_allclose(d["x"], [[1, 1, 10], [1, 2, 20]])
+    # x1[0] = [Â[0,0]=0 | ½·X2]  (the dst term ½·X1 is masked)
+    np.testing.assert_allclose(d["x1"][0], [0, 1.5, 15])
+    np.testing.assert_allclose(d["x1"][1], [0, 1.5, 15])
+    # x2[0] = [Â²[0,0]=½ | ½·X0 + ¼·X2]
+    np.testing.assert_allclose(d["x2"][0], [0.5, 0.5 * 1 + 0.75, 0.5 * 10 + 7.5])
+
+
+def test_probe5_cn_and_explicit_zero_semantics():
+    # (v) edges 0-2,1-2,0-3,1-3,3-4; link (0,1) absent -> K2: two explicit zeros inserted
+    A = csr_from_undirected(5, [[0, 2], [1, 2], [0, 3], [1, 3], [3, 4]])
+    nodes, sub, dists, _, _ = oracle.k_hop_subgraph(0, 1, 1, A)
+    assert nodes == [0, 1, 2, 3] and dists == [0, 0, 1, 1]
+    assert sub.nnz == 10 and len(ssp.find(sub)[0]) == 8                # K2 / K3
+    assert oracle.neighbors({0}, sub) == {1, 2, 3}                      # K4
+    (p,) = oracle.get_PoS_Plus_prepped_ds(np.array([[0], [1]]), 1, A, np.eye(5), 1, KW,
+                                          dtype=np.float64)
+    np.testing.assert_array_equal(p["rows_global"], [0, 1, 2, 3])
+
+
+def test_hybrid_and_pool_contract():
+    A = csr_from_undirected(5, [[0, 2], [1, 2], [0, 3], [1, 3], [3, 4]])
+    X = np.random.default_rng(0).standard_normal((5, 3))
+    li = np.array([[0, 3], [1, 4]])
+    pos = oracle.get_PoS_prepped_ds(li, 2, A, X, 1, KW, dtype=np.float64)
+    sop = oracle.get_SoP_prepped_ds(oracle.global_normalized_powers(A, 3, np.float64), li, A, X, 1,
+                                    dtype=np.float64)
+    hyb = oracle.hybrid_combine(pos, sop, 3)
+    assert sorted(k for k in hyb[0] if k.startswith("x")) == ["x", "x1", "x2", "x3", "x4", "x5"]
+    np.testing.assert_array_equal(hyb[1]["x4"], sop[1]["x2"])
+    np.testing.assert_array_equal(hyb[1]["x5"], sop[1]["x3"])
+    plus = oracle.get_PoS_Plus_prepped_ds(li, 2, A, X, 1, KW, dtype=np.float64)
+    rows, row_ptr, y = oracle.collate_rows(plus, 3)
+    assert rows.shape == (row_ptr[-1], 4, 4) and list(y) == [1, 1]
+    h = rows.reshape(rows.shape[0], -1)
+    out = oracle.centre_pool(h, row_ptr, k_heuristic=1, k_pool_strategy="mean")
+    assert out.shape == (2, 2 * h.shape[1])
+    np.testing.assert_allclose(out[0, :h.shape[1]], h[0] * h[1])
+    np.testing.assert_allclose(out[0, h.shape[1]:], h[2:row_ptr[1]].mean(0))
+    np.testing.assert_array_equal(out[1, h.shape[1]:], 0)               # link (3,4): no CN -> zeros
