@@ -1,0 +1,157 @@
+/*
+ * s3grl.h — C ABI of libs3grl_hip.so, the MI355X (gfx950) S3GRL operator-precompute engine.
+ *
+ * This is the drop-in boundary for ONE path of venomouscyanide/S3GRL: the per-link PoS /
+ * PoS Plus / SoP operator precompute that `utils.extract_enclosing_subgraphs`
+ * (reference utils.py:446-554) dispatches to
+ *     OptimizedSignOperations.get_PoS_prepped_ds       (reference tuned_SIGN.py:137-189)
+ *     OptimizedSignOperations.get_PoS_Plus_prepped_ds  (reference tuned_SIGN.py:192-262)
+ *     OptimizedSignOperations.get_SoP_prepped_ds       (reference tuned_SIGN.py:49-134)
+ * including the k-hop extraction they call (reference utils.py:33-85) and, for SoP, the global
+ * operator setup of `SEALDataset.process` (reference sgrl_link_pred.py:161-178).
+ *
+ * The reference is pure Python and has no FFI of its own; a maintainer binds these entry
+ * points with ctypes from `tuned_SIGN.py` (stub in INTEGRATION.md).  All pointers are plain
+ * DEVICE pointers unless a parameter says "host"; no torch / PyG types cross this boundary.
+ * Every function returns an s3grl_status; nothing is printed, nothing throws.
+ *
+ * Output contract (what reference models.py:372 `torch.cat(xs, dim=-1)` feeds the MLP):
+ *     rows     fp32 [total_rows, sign_k+1, 1+F]   operator 0 is x itself, column 0 the label
+ *                                                  column z (1 for src/dst rows, else 0)
+ *     row_ptr  int64 [L+1]                         rows of link l are row_ptr[l]..row_ptr[l+1];
+ *                                                  first two are src, dst; PoS Plus appends the
+ *                                                  common-neighbour rows in ascending node id
+ * Thread-compatibility: one context per host thread / stream; contexts share nothing.
+ */
+#ifndef S3GRL_H_
+#define S3GRL_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S3GRL_ABI_VERSION 1
+
+typedef enum s3grl_status {
+  S3GRL_OK = 0,
+  S3GRL_ERR_INVALID_ARGUMENT = 1, /* null pointer, negative size, sign_k < 1, link id out of range */
+  S3GRL_ERR_NOT_IMPLEMENTED = 2,  /* maps to the reference's NotImplementedError:
+                                     k_node_set_strategy other than "intersection"
+                                     (tuned_SIGN.py:235; "union" is unusable as shipped),
+                                     directed graphs, per-hop sampling, random-walk subgraphs */
+  S3GRL_ERR_NO_FEATURES = 3,      /* X == NULL: the reference's `assert subgraph_features is not
+                                     None` (tuned_SIGN.py:166,221) */
+  S3GRL_ERR_OUT_OF_MEMORY = 4,
+  S3GRL_ERR_HIP = 5,              /* a HIP runtime call failed; see s3grl_last_error() */
+  S3GRL_ERR_NO_DEVICE = 6,        /* no gfx950 device visible */
+  S3GRL_ERR_GRAPH_TOO_LARGE = 7,  /* num_nodes above the LDS-bitmap limit of this build */
+  S3GRL_ERR_SELF_LINK = 8         /* src == dst: the reference duplicates the node; unsupported */
+} s3grl_status;
+
+typedef enum s3grl_mode {
+  S3GRL_MODE_POS = 0,      /* get_PoS_prepped_ds       : rows {src,dst} */
+  S3GRL_MODE_POS_PLUS = 1, /* get_PoS_Plus_prepped_ds  : rows {src,dst} + N(src) ∩ N(dst) */
+  S3GRL_MODE_SOP = 2       /* get_SoP_prepped_ds       : global operators, rows {src,dst} */
+} s3grl_mode;
+
+typedef enum s3grl_strategy {
+  S3GRL_STRATEGY_INTERSECTION = 0, /* sign_kwargs['k_node_set_strategy'] == 'intersection' */
+  S3GRL_STRATEGY_UNION = 1         /* accepted by the reference's parser, broken in its code */
+} s3grl_strategy;
+
+/* sign_kwargs / call arguments of the reference operators (tuned_SIGN.py:137-138,145,200,229) */
+typedef struct s3grl_cfg {
+  int32_t mode;      /* s3grl_mode */
+  int32_t num_hops;  /* k of the k-hop enclosing subgraph (ignored for SoP, like the reference) */
+  int32_t sign_k;    /* number of operators K >= 1 */
+  int32_t strategy;  /* s3grl_strategy, PoS Plus only */
+  int32_t directed;  /* must be 0 (A_csc == None in every non-ogbl-citation2 run) */
+  int32_t reserved[3];
+} s3grl_cfg;
+
+/* sizes a plan measured while extracting; the benchmark's algorithmic-bytes figure
+ * (B_link = 8n + 4 vol(S) + 4 n F + 4 R (K+1)(1+F)) is computed from these. */
+typedef struct s3grl_plan_stats {
+  int64_t num_links;
+  int64_t total_rows;       /* ΣR */
+  int64_t total_nodes;      /* Σ n        subgraph nodes over all links */
+  int64_t total_volume;     /* Σ vol(S)   global degrees of those nodes */
+  int64_t total_sub_edges;  /* Σ e        directed entries of the masked induced sub-CSRs */
+  int64_t total_support;    /* Σ over row pairs of nodes with a non-zero operator coefficient */
+  int64_t num_row_pairs;    /* gather jobs */
+  int64_t max_nodes;        /* max n */
+  int64_t workspace_bytes;  /* device bytes held by the plan + context arena */
+  int64_t reserved[3];
+} s3grl_plan_stats;
+
+typedef struct s3grl_context s3grl_context; /* device, stream, workspace arena */
+typedef struct s3grl_graph s3grl_graph;     /* structure of the train graph A (values ignored,
+                                               exactly as ssp.find -> SparseTensor(row, col)
+                                               ignores them, tuned_SIGN.py:153-156) */
+typedef struct s3grl_plan s3grl_plan;       /* extraction + operator coefficients of one call */
+typedef struct s3grl_sop s3grl_sop;         /* SoP global state: Â, Y_i = Â^i X */
+
+int32_t s3grl_abi_version(void);
+const char* s3grl_status_string(s3grl_status s);
+/* message of the last failing call on this host thread (HIP error text), never NULL */
+const char* s3grl_last_error(void);
+
+/* `stream` is a hipStream_t passed as void* (NULL = the legacy default stream). */
+s3grl_status s3grl_context_create(int32_t device, void* stream, s3grl_context** out);
+s3grl_status s3grl_context_destroy(s3grl_context* ctx);
+
+/* CSR of A as scipy holds it (reference sgrl_link_pred.py:111-114): indptr [N+1], indices
+ * [nnz] sorted within a row; the matrix must be structurally symmetric (undirected train
+ * graph).  The arrays are copied; the caller may free them afterwards. */
+s3grl_status s3grl_graph_create(s3grl_context* ctx, int64_t num_nodes, const int64_t* indptr,
+                                const int32_t* indices, int64_t nnz, s3grl_graph** out);
+s3grl_status s3grl_graph_destroy(s3grl_graph* g);
+
+/* PoS / PoS Plus, feature-independent half: BFS to num_hops from {src,dst} on the unmasked
+ * graph, induced sub-CSR with the target link removed, D^-1/2 A D^-1/2, and rows {src,dst}
+ * (+ common neighbours) of Â^1..Â^K by row propagation.  `links` is int64 [L,2] (the
+ * reference iterates link_index.t().tolist(), tuned_SIGN.py:147). */
+s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links,
+                               int64_t num_links, const s3grl_cfg* cfg, s3grl_plan** out);
+s3grl_status s3grl_plan_destroy(s3grl_plan* p);
+/* host struct out */
+s3grl_status s3grl_plan_get_stats(const s3grl_plan* p, s3grl_plan_stats* out);
+/* device int64 [L+1] out */
+s3grl_status s3grl_plan_row_ptr(const s3grl_plan* p, int64_t* row_ptr);
+/* device int64 [total_rows] out: global node id of every output row */
+s3grl_status s3grl_plan_row_nodes(const s3grl_plan* p, int64_t* row_nodes);
+/* parity hook: node_ptr int64 [L+1] (always), then, when non-NULL, nodes int32 [Σn] in
+ * ascending id per link and dists int8 [Σn] (hop distance from {src,dst}) — the quantities
+ * reference utils.k_hop_subgraph returns as `nodes`, `dists` (utils.py:53-54,73-74). */
+s3grl_status s3grl_plan_export_subgraphs(const s3grl_plan* p, int64_t* node_ptr, int32_t* nodes,
+                                         int8_t* dists);
+
+/* PoS / PoS Plus, feature half: rows[r, i, :] = [z | Σ_w Â^i[row r, w] X[w, :]].
+ * X fp32 [N, F] row-major with leading dimension ldx (elements); rows fp32
+ * [total_rows, K+1, 1+F] dense.  Asynchronous on the context's stream. */
+s3grl_status s3grl_run(s3grl_context* ctx, const s3grl_plan* p, const float* X, int64_t ldx,
+                       int64_t num_features, float* rows);
+
+/* SoP: one-off global setup (reference sgrl_link_pred.py:161-178 recomputes it per split):
+ * Â = D^-1/2 A D^-1/2 of the whole graph and Y_i = Â^i X, i = 1..K. */
+s3grl_status s3grl_sop_create(s3grl_context* ctx, const s3grl_graph* g, const float* X,
+                              int64_t ldx, int64_t num_features, int32_t sign_k, s3grl_sop** out);
+s3grl_status s3grl_sop_destroy(s3grl_sop* s);
+/* rows fp32 [2L, K+1, 1+F]: x_i[src] = [Â^i[s,s] | Σ_{w != d} Â^i[s,w] X[w]] and the mirror
+ * image for dst (reference tuned_SIGN.py:71-78,92-113,119-132). */
+s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t* links,
+                           int64_t num_links, float* rows);
+
+/* last kernel timings of this context in milliseconds (HIP events on the context's stream):
+ * what[0]=structure (count+build), [1]=propagate, [2]=gather, [3]=sop setup, [4]=sop run;
+ * plus launches of the dominant kernel in what[5]. Host array of 8 doubles. */
+s3grl_status s3grl_context_timings(s3grl_context* ctx, double* what);
+/* enable/disable the per-phase HIP-event timing above (off by default: events serialise) */
+s3grl_status s3grl_context_set_profiling(s3grl_context* ctx, int32_t enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S3GRL_H_ */

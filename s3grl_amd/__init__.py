@@ -1,0 +1,8 @@
+"""s3grl_amd — MI355X (gfx950) engine for the S3GRL PoS / PoS Plus / SoP operator precompute.
+
+Only the hot path of venomouscyanide/S3GRL lives here: the HIP kernels and
+C ABI in csrc/ + include/s3grl.h, and the host-side mirror of the reference's operator
+interface (`s3grl_amd.tuned_SIGN`).  Importing the package does not touch the GPU; the first
+call into the engine loads libs3grl_hip.so and fails loudly if it is not built.
+"""
+__version__ = "0.1.0"

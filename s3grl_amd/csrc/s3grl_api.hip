@@ -1,0 +1,468 @@
+// extern "C" entry points of libs3grl_hip.so (see include/s3grl.h) and host orchestration.
+#include <algorithm>
+#include <cstring>
+#include <memory>
+
+#include "s3grl_internal.hpp"
+
+namespace s3grl {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+
+Arena::~Arena() {
+  for (auto& kv : free_) (void)hipFree(kv.second);
+  for (auto& kv : live_) (void)hipFree(kv.first);
+}
+
+s3grl_status Arena::alloc(size_t bytes, void** out) {
+  if (bytes == 0) bytes = 256;
+  // 2 MiB granularity for big blocks so that sizes that wobble between steps hit the cache
+  const size_t gran = bytes >= (1u << 20) ? (2u << 20) : 256;
+  bytes = (bytes + gran - 1) / gran * gran;
+  auto it = free_.lower_bound(bytes);
+  if (it != free_.end() && it->first <= bytes * 2 + (4u << 20)) {
+    *out = it->second;
+    live_[it->second] = it->first;
+    free_.erase(it);
+    return S3GRL_OK;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {
+    // give cached blocks back and retry once
+    for (auto& kv : free_) {
+      (void)hipFree(kv.second);
+      held_ -= kv.first;
+    }
+    free_.clear();
+    e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+      set_last_error("hipMalloc(" + std::to_string(bytes) + "): " + hipGetErrorString(e));
+      return S3GRL_ERR_OUT_OF_MEMORY;
+    }
+  }
+  held_ += bytes;
+  live_[p] = bytes;
+  *out = p;
+  return S3GRL_OK;
+}
+
+void Arena::release(void* p) {
+  if (!p) return;
+  auto it = live_.find(p);
+  if (it == live_.end()) return;
+  free_.emplace(it->second, p);
+  live_.erase(it);
+}
+
+namespace {
+
+__global__ void indptr_to_i32_kernel(const int64_t* __restrict__ in, int64_t n,
+                                     int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (int32_t)in[i];
+}
+
+__global__ void max_i32_kernel(const int32_t* __restrict__ in, int64_t n, int64_t* out) {
+  int m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    m = max(m, in[i]);
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<long long*>(out), (long long)m);
+}
+
+template <typename T>
+s3grl_status arena_alloc(s3grl_context* ctx, size_t count, T** out, std::vector<void*>* owned) {
+  void* p = nullptr;
+  S3GRL_TRY(ctx->arena.alloc(count * sizeof(T), &p));
+  *out = static_cast<T*>(p);
+  if (owned) owned->push_back(p);
+  return S3GRL_OK;
+}
+
+struct Transient {  // released on scope exit (stream-ordered reuse is safe: one stream per context)
+  s3grl_context* ctx;
+  std::vector<void*> ptrs;
+  ~Transient() {
+    for (void* p : ptrs) ctx->arena.release(p);
+  }
+};
+
+s3grl_status record(s3grl_context* ctx, int idx) {
+  if (!ctx->profiling) return S3GRL_OK;
+  S3GRL_HIP_TRY(hipEventRecord(ctx->ev[idx], ctx->stream));
+  return S3GRL_OK;
+}
+
+}  // namespace
+}  // namespace s3grl
+
+using namespace s3grl;
+
+extern "C" {
+
+int32_t s3grl_abi_version(void) { return S3GRL_ABI_VERSION; }
+
+const char* s3grl_status_string(s3grl_status s) {
+  switch (s) {
+    case S3GRL_OK: return "ok";
+    case S3GRL_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case S3GRL_ERR_NOT_IMPLEMENTED: return "not implemented";
+    case S3GRL_ERR_NO_FEATURES: return "node features are required";
+    case S3GRL_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case S3GRL_ERR_HIP: return "HIP runtime error";
+    case S3GRL_ERR_NO_DEVICE: return "no gfx950 device";
+    case S3GRL_ERR_GRAPH_TOO_LARGE: return "graph or subgraph too large for this build";
+    case S3GRL_ERR_SELF_LINK: return "src == dst";
+  }
+  return "unknown status";
+}
+
+const char* s3grl_last_error(void) { return g_last_error.c_str(); }
+
+s3grl_status s3grl_context_create(int32_t device, void* stream, s3grl_context** out) {
+  if (!out) return S3GRL_ERR_INVALID_ARGUMENT;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) {
+    set_last_error("no HIP device " + std::to_string(device));
+    return S3GRL_ERR_NO_DEVICE;
+  }
+  S3GRL_HIP_TRY(hipSetDevice(device));
+  auto* ctx = new s3grl_context();
+  ctx->device = device;
+  ctx->stream = static_cast<hipStream_t>(stream);
+  for (auto& e : ctx->ev) S3GRL_HIP_TRY(hipEventCreate(&e));
+  S3GRL_HIP_TRY(hipMalloc(&ctx->d_scalars, 16 * sizeof(int64_t)));
+  S3GRL_HIP_TRY(hipHostMalloc(&ctx->h_scalars, 16 * sizeof(int64_t)));
+  *out = ctx;
+  return S3GRL_OK;
+}
+
+s3grl_status s3grl_context_destroy(s3grl_context* ctx) {
+  if (!ctx) return S3GRL_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& e : ctx->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
+  if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
+  if (ctx->x_padded) ctx->arena.release(ctx->x_padded);
+  delete ctx;
+  return S3GRL_OK;
+}
+
+s3grl_status s3grl_context_set_profiling(s3grl_context* ctx, int32_t enabled) {
+  if (!ctx) return S3GRL_ERR_INVALID_ARGUMENT;
+  ctx->profiling = enabled != 0;
+  return S3GRL_OK;
+}
+
+s3grl_status s3grl_context_timings(s3grl_context* ctx, double* what) {
+  if (!ctx || !what) return S3GRL_ERR_INVALID_ARGUMENT;
+  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  std::memcpy(what, ctx->timings, sizeof(ctx->timings));
+  return S3GRL_OK;
+}
+
+s3grl_status s3grl_graph_create(s3grl_context* ctx, int64_t num_nodes, const int64_t* indptr,
+                                const int32_t* indices, int64_t nnz, s3grl_graph** out) {
+  if (!ctx || !out || !indptr || num_nodes <= 0 || nnz < 0 || (nnz > 0 && !indices))
+    return S3GRL_ERR_INVALID_ARGUMENT;
+  if (nnz >= (int64_t)INT32_MAX || num_nodes >= (int64_t)INT32_MAX) {
+    set_last_error("graph needs 64-bit edge offsets, not supported");
+    return S3GRL_ERR_GRAPH_TOO_LARGE;
+  }
+  S3GRL_HIP_TRY(hipSetDevice(ctx->device));
+  auto* g = new s3grl_graph();
+  g->ctx = ctx;
+  g->num_nodes = num_nodes;
+  g->nnz = nnz;
+  void* p = nullptr;
+  S3GRL_TRY(ctx->arena.alloc((size_t)(num_nodes + 1) * 4, &p));
+  g->indptr = static_cast<int32_t*>(p);
+  S3GRL_TRY(ctx->arena.alloc((size_t)std::max<int64_t>(nnz, 1) * 4, &p));
+  g->indices = static_cast<int32_t*>(p);
+  const int64_t n1 = num_nodes + 1;
+  hipLaunchKernelGGL(indptr_to_i32_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0,
+                     ctx->stream, indptr, n1, g->indptr);
+  S3GRL_HIP_TRY(hipGetLastError());
+  if (nnz)
+    S3GRL_HIP_TRY(hipMemcpyAsync(g->indices, indices, (size_t)nnz * 4, hipMemcpyDeviceToDevice,
+                                 ctx->stream));
+  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *out = g;
+  return S3GRL_OK;
+}
+
+s3grl_status s3grl_graph_destroy(s3grl_graph* g) {
+  if (!g) return S3GRL_OK;
+  g->ctx->arena.release(g->indptr);
+  g->ctx->arena.release(g->indices);
+  delete g;
+  return S3GRL_OK;
+}
+
+s3grl_status s3grl_plan_destroy(s3grl_plan* p) {
+  if (!p) return S3GRL_OK;
+  for (void* q : p->owned) p->ctx->arena.release(q);
+  delete p;
+  return S3GRL_OK;
+}
+
+s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links,
+                               int64_t L, const s3grl_cfg* cfg, s3grl_plan** out) {
+  if (!ctx || !g || !cfg || !out || L < 0 || (L > 0 && !links)) return S3GRL_ERR_INVALID_ARGUMENT;
+  if (cfg->sign_k < 1 || cfg->sign_k > kMaxSignK || cfg->num_hops < 0) {
+    set_last_error("sign_k must be in 1..8 and num_hops >= 0");
+    return S3GRL_ERR_INVALID_ARGUMENT;
+  }
+  if (cfg->mode != S3GRL_MODE_POS && cfg->mode != S3GRL_MODE_POS_PLUS) {
+    set_last_error("s3grl_plan_create handles PoS / PoS Plus; use s3grl_sop_* for SoP");
+    return S3GRL_ERR_INVALID_ARGUMENT;
+  }
+  if (cfg->directed) {
+    set_last_error("directed graphs (A_csc) are not implemented");
+    return S3GRL_ERR_NOT_IMPLEMENTED;
+  }
+  const bool plus = cfg->mode == S3GRL_MODE_POS_PLUS;
+  if (plus && cfg->strategy != S3GRL_STRATEGY_INTERSECTION) {
+    set_last_error("check strat: only k_node_set_strategy='intersection' is usable");
+    return S3GRL_ERR_NOT_IMPLEMENTED;
+  }
+  if (g->num_nodes > kMaxNodesLds) {
+    set_last_error("num_nodes " + std::to_string(g->num_nodes) + " exceeds the LDS bitmap limit " +
+                   std::to_string(kMaxNodesLds));
+    return S3GRL_ERR_GRAPH_TOO_LARGE;
+  }
+  if (L >= (int64_t)INT32_MAX) return S3GRL_ERR_INVALID_ARGUMENT;
+  S3GRL_HIP_TRY(hipSetDevice(ctx->device));
+  const int K = cfg->sign_k;
+  const bool keep = (cfg->reserved[0] & 1) != 0;
+
+  std::unique_ptr<s3grl_plan, s3grl_status (*)(s3grl_plan*)> plan(new s3grl_plan(),
+                                                                  s3grl_plan_destroy);
+  plan->ctx = ctx;
+  plan->graph = g;
+  plan->cfg = *cfg;
+  plan->L = L;
+  plan->stats = s3grl_plan_stats{};
+  plan->stats.num_links = L;
+  Transient tmp{ctx, {}};
+  auto* own = &plan->owned;
+  auto* tr = &tmp.ptrs;
+
+  S3GRL_TRY(arena_alloc(ctx, (size_t)(L + 1), &plan->row_ptr, own));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)(L + 1), &plan->node_off, own));
+  if (L == 0) {
+    S3GRL_HIP_TRY(hipMemsetAsync(plan->row_ptr, 0, 8, ctx->stream));
+    S3GRL_HIP_TRY(hipMemsetAsync(plan->node_off, 0, 8, ctx->stream));
+    *out = plan.release();
+    return S3GRL_OK;
+  }
+  S3GRL_TRY(record(ctx, 0));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)L * 2, &plan->links, own));
+  S3GRL_HIP_TRY(hipMemcpyAsync(plan->links, links, (size_t)L * 16, hipMemcpyDeviceToDevice,
+                               ctx->stream));
+  int32_t *vol, *cn_cap;
+  int64_t *edge_off, *cn_off = nullptr;
+  S3GRL_TRY(arena_alloc(ctx, (size_t)L, &plan->n_nodes, own));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)L, &vol, tr));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)L, &cn_cap, tr));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)(L + 1), &edge_off, tr));
+  if (plus) S3GRL_TRY(arena_alloc(ctx, (size_t)(L + 1), &cn_off, tr));
+
+  // d_scalars: [0] err flag (int32), [1] max n, [2] Σ edges, [3] Σ support
+  int64_t* ds = ctx->d_scalars;
+  int64_t* hs = ctx->h_scalars;
+  S3GRL_HIP_TRY(hipMemsetAsync(ds, 0, 16 * sizeof(int64_t), ctx->stream));
+  S3GRL_TRY(launch_count(ctx, g, plan->links, L, cfg->num_hops, plus ? 1 : 0, plan->n_nodes, vol,
+                         cn_cap, reinterpret_cast<int32_t*>(ds)));
+  S3GRL_TRY(launch_scan_i32_to_i64(ctx, plan->n_nodes, L, plan->node_off));
+  S3GRL_TRY(launch_scan_i32_to_i64(ctx, vol, L, edge_off));
+  if (plus) S3GRL_TRY(launch_scan_i32_to_i64(ctx, cn_cap, L, cn_off));
+  hipLaunchKernelGGL(max_i32_kernel, dim3(256), dim3(256), 0, ctx->stream, plan->n_nodes, L, ds + 1);
+  S3GRL_HIP_TRY(hipGetLastError());
+  S3GRL_HIP_TRY(hipMemcpyAsync(hs, ds, 2 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipMemcpyAsync(hs + 4, plan->node_off + L, 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipMemcpyAsync(hs + 5, edge_off + L, 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (plus) S3GRL_HIP_TRY(hipMemcpyAsync(hs + 6, cn_off + L, 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const int err = (int)(hs[0] & 0xffffffff);
+  if (err == 2) {
+    set_last_error("a link has src == dst");
+    return S3GRL_ERR_SELF_LINK;
+  }
+  if (err == 1) {
+    set_last_error("a link endpoint is outside [0, num_nodes)");
+    return S3GRL_ERR_INVALID_ARGUMENT;
+  }
+  const int64_t max_n = hs[1], tot_n = hs[4], tot_vol = hs[5], tot_cn = plus ? hs[6] : 0;
+  plan->stats.total_nodes = tot_n;
+  plan->stats.total_volume = tot_vol;
+  plan->stats.max_nodes = max_n;
+
+  int32_t *rowstart, *cnt, *lcsr, *cn_tmp = nullptr, *cn_count, *n_rows, *n_jobs;
+  float* dinv;
+  std::vector<void*>* nodes_owner = keep ? own : tr;
+  S3GRL_TRY(arena_alloc(ctx, (size_t)tot_n, &plan->nodes, nodes_owner));
+  if (keep) S3GRL_TRY(arena_alloc(ctx, (size_t)tot_n, &plan->dists, own));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)tot_n, &rowstart, tr));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)tot_n, &cnt, tr));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)tot_n, &dinv, tr));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)std::max<int64_t>(tot_vol, 1), &lcsr, tr));
+  if (plus) S3GRL_TRY(arena_alloc(ctx, (size_t)std::max<int64_t>(tot_cn, 1), &cn_tmp, tr));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)L, &cn_count, tr));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)L, &n_rows, tr));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)L, &n_jobs, tr));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)(L + 1), &plan->job_off, own));
+
+  S3GRL_TRY(launch_build(ctx, g, plan->links, L, cfg->num_hops, plus ? 1 : 0, plan->node_off,
+                         edge_off, cn_off, plan->nodes, keep ? plan->dists : nullptr, rowstart, cnt,
+                         dinv, lcsr, cn_tmp, cn_count, n_rows, n_jobs, ds + 2));
+  S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_rows, L, plan->row_ptr));
+  S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_jobs, L, plan->job_off));
+  int64_t tot_rows = 2 * L, njobs = L;
+  if (plus) {
+    S3GRL_HIP_TRY(hipMemcpyAsync(hs + 8, plan->row_ptr + L, 8, hipMemcpyDeviceToHost, ctx->stream));
+    S3GRL_HIP_TRY(hipMemcpyAsync(hs + 9, plan->job_off + L, 8, hipMemcpyDeviceToHost, ctx->stream));
+    S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    tot_rows = hs[8];
+    njobs = hs[9];
+  }
+  plan->stats.total_rows = tot_rows;
+  plan->stats.num_row_pairs = njobs;
+  plan->njobs = njobs;
+
+  int32_t* job_n;
+  int64_t* coef_off;
+  S3GRL_TRY(arena_alloc(ctx, (size_t)njobs, &plan->jobs, own));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)njobs, &job_n, tr));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)(njobs + 1), &coef_off, tr));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)tot_rows, &plan->row_nodes, own));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)njobs * K * 2, &plan->job_z, own));
+  S3GRL_TRY(launch_make_jobs(ctx, plan->links, L, plan->node_off, plan->row_ptr, plan->job_off,
+                             cn_off, cn_tmp, plan->nodes, plan->n_nodes, K, plan->jobs,
+                             plan->row_nodes, job_n));
+  S3GRL_TRY(launch_scan_i32_to_i64(ctx, job_n, njobs, coef_off));
+  int64_t tot_coef = tot_n;  // PoS: one job per link
+  if (plus) {
+    S3GRL_HIP_TRY(hipMemcpyAsync(hs + 10, coef_off + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
+    S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    tot_coef = hs[10];
+  }
+  S3GRL_TRY(arena_alloc(ctx, (size_t)std::max<int64_t>(tot_coef, 1), &plan->c_ids, own));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)std::max<int64_t>(tot_coef, 1) * 2 * K, &plan->c_coef, own));
+  S3GRL_TRY(record(ctx, 1));
+  S3GRL_TRY(launch_propagate(ctx, plan->jobs, njobs, coef_off, plan->links, plan->node_off, edge_off,
+                             plan->nodes, rowstart, cnt, dinv, lcsr, K, max_n, plan->c_ids,
+                             plan->c_coef, plan->job_z, ds + 3));
+  S3GRL_TRY(record(ctx, 2));
+  S3GRL_HIP_TRY(hipMemcpyAsync(hs + 2, ds + 2, 2 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  plan->stats.total_sub_edges = hs[2];
+  plan->stats.total_support = hs[3];
+  plan->stats.workspace_bytes = (int64_t)ctx->arena.bytes_held();
+  if (ctx->profiling) {
+    float ms = 0;
+    S3GRL_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->timings[0] = ms;
+    S3GRL_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
+    ctx->timings[1] = ms;
+  }
+  if (!keep) plan->nodes = nullptr;
+  *out = plan.release();
+  return S3GRL_OK;
+}
+
+s3grl_status s3grl_plan_get_stats(const s3grl_plan* p, s3grl_plan_stats* out) {
+  if (!p || !out) return S3GRL_ERR_INVALID_ARGUMENT;
+  *out = p->stats;
+  return S3GRL_OK;
+}
+
+s3grl_status s3grl_plan_row_ptr(const s3grl_plan* p, int64_t* row_ptr) {
+  if (!p || !row_ptr) return S3GRL_ERR_INVALID_ARGUMENT;
+  S3GRL_HIP_TRY(hipMemcpyAsync(row_ptr, p->row_ptr, (size_t)(p->L + 1) * 8, hipMemcpyDeviceToDevice,
+                               p->ctx->stream));
+  return S3GRL_OK;
+}
+
+s3grl_status s3grl_plan_row_nodes(const s3grl_plan* p, int64_t* row_nodes) {
+  if (!p || !row_nodes) return S3GRL_ERR_INVALID_ARGUMENT;
+  if (p->stats.total_rows)
+    S3GRL_HIP_TRY(hipMemcpyAsync(row_nodes, p->row_nodes, (size_t)p->stats.total_rows * 8,
+                                 hipMemcpyDeviceToDevice, p->ctx->stream));
+  return S3GRL_OK;
+}
+
+s3grl_status s3grl_plan_export_subgraphs(const s3grl_plan* p, int64_t* node_ptr, int32_t* nodes,
+                                         int8_t* dists) {
+  if (!p || !node_ptr) return S3GRL_ERR_INVALID_ARGUMENT;
+  hipStream_t st = p->ctx->stream;
+  S3GRL_HIP_TRY(hipMemcpyAsync(node_ptr, p->node_off, (size_t)(p->L + 1) * 8,
+                               hipMemcpyDeviceToDevice, st));
+  if (nodes || dists) {
+    if (!p->nodes || !p->dists) {
+      set_last_error("plan was created without cfg.reserved[0] bit 0 (keep subgraphs)");
+      return S3GRL_ERR_INVALID_ARGUMENT;
+    }
+    const size_t n = (size_t)p->stats.total_nodes;
+    if (nodes && n) S3GRL_HIP_TRY(hipMemcpyAsync(nodes, p->nodes, n * 4, hipMemcpyDeviceToDevice, st));
+    if (dists && n) S3GRL_HIP_TRY(hipMemcpyAsync(dists, p->dists, n, hipMemcpyDeviceToDevice, st));
+  }
+  return S3GRL_OK;
+}
+
+// X as the gather kernel wants it: 16-byte aligned rows, ld a multiple of 4 floats >= F.
+static s3grl_status aligned_features(s3grl_context* ctx, int64_t N, const float* X, int64_t ldx,
+                                     int64_t F, const float** Xa, int64_t* lda) {
+  const int64_t need = (F + 3) / 4 * 4;
+  if ((reinterpret_cast<uintptr_t>(X) & 15) == 0 && ldx % 4 == 0 && ldx >= need) {
+    *Xa = X;
+    *lda = ldx;
+    return S3GRL_OK;
+  }
+  const size_t bytes = (size_t)N * need * 4;
+  if (ctx->x_padded_bytes < bytes) {
+    if (ctx->x_padded) ctx->arena.release(ctx->x_padded);
+    void* p = nullptr;
+    S3GRL_TRY(ctx->arena.alloc(bytes, &p));
+    ctx->x_padded = static_cast<float*>(p);
+    ctx->x_padded_bytes = bytes;
+  }
+  S3GRL_TRY(launch_copy_pad(ctx, X, ldx, N, F, ctx->x_padded, need));
+  *Xa = ctx->x_padded;
+  *lda = need;
+  return S3GRL_OK;
+}
+
+s3grl_status s3grl_run(s3grl_context* ctx, const s3grl_plan* p, const float* X, int64_t ldx,
+                       int64_t F, float* rows) {
+  if (!ctx || !p) return S3GRL_ERR_INVALID_ARGUMENT;
+  if (!X) {
+    set_last_error("node features are None");
+    return S3GRL_ERR_NO_FEATURES;
+  }
+  if (F <= 0 || ldx < F || (p->stats.total_rows && !rows)) return S3GRL_ERR_INVALID_ARGUMENT;
+  if (p->njobs == 0) return S3GRL_OK;
+  S3GRL_HIP_TRY(hipSetDevice(ctx->device));
+  const float* Xa;
+  int64_t lda;
+  S3GRL_TRY(aligned_features(ctx, p->graph->num_nodes, X, ldx, F, &Xa, &lda));
+  S3GRL_TRY(record(ctx, 3));
+  S3GRL_TRY(launch_gather(ctx, p->jobs, p->njobs, p->c_ids, p->c_coef, p->job_z, p->cfg.sign_k, Xa,
+                          lda, F, rows));
+  S3GRL_TRY(record(ctx, 4));
+  if (ctx->profiling) {
+    S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    S3GRL_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
+    ctx->timings[2] = ms;
+    ctx->timings[5] = 1.0;
+  }
+  return S3GRL_OK;
+}
+
+}  // extern "C"

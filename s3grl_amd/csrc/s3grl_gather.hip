@@ -1,0 +1,167 @@
+// Feature half of PoS / PoS Plus on gfx950: the dominant, HBM/Infinity-Cache-bound kernel.
+//
+//   rows[r, i, 1 + f] = Σ_w  Â^i[row r, w] · X[w, f]        i = 1..K, both rows of a pair
+//   rows[r, 0, :]     = [z_r | X[node_r, :]]
+//   rows[r, i, 0]     = Σ_w Â^i[row r, w] z_w                (label column)
+//
+// replaces the reference's `power_of_a[selected_rows] @ subg_x` (tuned_SIGN.py:175,185 and
+// :240,258) and its two dense copies of X_S (utils.py:83, tuned_SIGN.py:179).
+//
+// One wavefront owns one row pair.  The (node id, 2K coefficients) list is wave-uniform, so it
+// is read through the scalar cache into SGPRs; each lane owns 4·CH feature columns and keeps
+// 2K·4·CH fp32 accumulators in VGPRs; every X row of the support is fetched ONCE per pair with
+// 16-byte loads (64 lanes × 16 B = one 1 KiB wave-instruction per 256 columns), UNROLL rows
+// in flight per wave.  No LDS, no MFMA: 2·2K flop per 4 B of X.
+#include "s3grl_internal.hpp"
+
+namespace s3grl {
+namespace {
+
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kUnroll = 4;
+
+template <int K, int CH>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void gather_kernel(
+    const Job* __restrict__ jobs, int njobs, const int32_t* __restrict__ c_ids,
+    const float* __restrict__ c_coef, const float* __restrict__ job_z, const float* __restrict__ X,
+    int64_t ldx, int F, float* __restrict__ rows) {
+  const int lane = threadIdx.x & 63;
+  const int jid = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+  if (jid >= njobs) return;
+  const int col0 = blockIdx.y * (CH * 256);  // first feature column of this wave's tile
+  const Job job = jobs[jid];
+  const int cnt = __builtin_amdgcn_readfirstlane(job.support);
+  const int32_t* __restrict__ ids = c_ids + job.coef_off;
+  const float* __restrict__ cf = c_coef + job.coef_off * (2 * K);
+
+  // this lane's columns: col0 + (lane + 64 c) * 4 .. +3
+  int coff[CH];
+  bool cok[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    coff[c] = col0 + (lane + 64 * c) * 4;
+    cok[c] = coff[c] < F;  // rows of X are padded to a multiple of 4 floats by the caller
+  }
+
+  float4_t acc[K][2][CH];
+#pragma unroll
+  for (int i = 0; i < K; ++i)
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < CH; ++c) acc[i][r][c] = (float4_t)(0.f);
+
+  int j = 0;
+  for (; j + kUnroll <= cnt; j += kUnroll) {
+    float4_t v[kUnroll][CH];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const float* __restrict__ xr = X + (int64_t)ids[j + u] * ldx;
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+        v[u][c] = cok[c] ? *reinterpret_cast<const float4_t*>(xr + coff[c]) : (float4_t)(0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const float* __restrict__ q = cf + (int64_t)(j + u) * (2 * K);
+#pragma unroll
+      for (int i = 0; i < K; ++i) {
+        const float ca = q[2 * i], cb = q[2 * i + 1];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          acc[i][0][c] += ca * v[u][c];
+          acc[i][1][c] += cb * v[u][c];
+        }
+      }
+    }
+  }
+  for (; j < cnt; ++j) {
+    const float* __restrict__ xr = X + (int64_t)ids[j] * ldx;
+    const float* __restrict__ q = cf + (int64_t)j * (2 * K);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const float4_t v = cok[c] ? *reinterpret_cast<const float4_t*>(xr + coff[c]) : (float4_t)(0.f);
+#pragma unroll
+      for (int i = 0; i < K; ++i) {
+        acc[i][0][c] += q[2 * i] * v;
+        acc[i][1][c] += q[2 * i + 1] * v;
+      }
+    }
+  }
+
+  // epilogue: rows are [K+1][1+F] fp32; the +1 label column makes them 4-byte aligned only
+  const int Fp = F + 1;
+  const int64_t rstride = (int64_t)(K + 1) * Fp;
+  const int nrow = job.node_b >= 0 ? 2 : 1;
+  for (int r = 0; r < nrow; ++r) {
+    float* __restrict__ out = rows + (job.out_row + r) * rstride;
+    const int node = r == 0 ? job.node_a : job.node_b;
+    const float* __restrict__ xr = X + (int64_t)node * ldx;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (cok[c]) {
+        const float4_t x0 = *reinterpret_cast<const float4_t*>(xr + coff[c]);
+        const int nv = min(4, F - coff[c]);  // F need not be a multiple of 4 (X is padded)
+        float* o = out + 1 + coff[c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (e < nv) o[e] = x0[e];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+          const float4_t a = acc[i][r][c];
+          float* oi = out + (int64_t)(i + 1) * Fp + 1 + coff[c];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (e < nv) oi[e] = a[e];
+        }
+      }
+    }
+    if (blockIdx.y == 0 && lane <= K) {
+      const float z = lane == 0 ? (float)(r == 0 ? job.z_a : job.z_b)
+                                : job_z[((int64_t)jid * K + (lane - 1)) * 2 + r];
+      out[(int64_t)lane * Fp] = z;
+    }
+  }
+}
+
+template <int K>
+s3grl_status launch_k(s3grl_context* ctx, const Job* jobs, int64_t njobs, const int32_t* c_ids,
+                      const float* c_coef, const float* job_z, const float* X, int64_t ldx,
+                      int64_t F, float* rows) {
+  const unsigned gx = (unsigned)((njobs + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (F <= 256) {
+    hipLaunchKernelGGL((gather_kernel<K, 1>), dim3(gx, 1), dim3(kWavesPerBlock * 64), 0, ctx->stream,
+                       jobs, (int)njobs, c_ids, c_coef, job_z, X, ldx, (int)F, rows);
+  } else {
+    const unsigned gy = (unsigned)((F + 511) / 512);
+    hipLaunchKernelGGL((gather_kernel<K, 2>), dim3(gx, gy), dim3(kWavesPerBlock * 64), 0,
+                       ctx->stream, jobs, (int)njobs, c_ids, c_coef, job_z, X, ldx, (int)F, rows);
+  }
+  S3GRL_HIP_TRY(hipGetLastError());
+  return S3GRL_OK;
+}
+
+}  // namespace
+
+s3grl_status launch_gather(s3grl_context* ctx, const Job* jobs, int64_t njobs, const int32_t* c_ids,
+                           const float* c_coef, const float* job_z, int K, const float* X,
+                           int64_t ldx, int64_t F, float* rows) {
+  if (njobs == 0) return S3GRL_OK;
+  switch (K) {
+    case 1: return launch_k<1>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows);
+    case 2: return launch_k<2>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows);
+    case 3: return launch_k<3>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows);
+    case 4: return launch_k<4>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows);
+    case 5: return launch_k<5>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows);
+    case 6: return launch_k<6>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows);
+    case 7: return launch_k<7>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows);
+    case 8: return launch_k<8>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows);
+    default:
+      set_last_error("sign_k must be in 1..8");
+      return S3GRL_ERR_INVALID_ARGUMENT;
+  }
+}
+
+}  // namespace s3grl

@@ -1,0 +1,161 @@
+// Internal declarations shared by the translation units of libs3grl_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/s3grl.h"
+
+namespace s3grl {
+
+void set_last_error(const std::string& msg);
+
+#define S3GRL_HIP_TRY(expr)                                                                   \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      ::s3grl::set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" +      \
+                              __FILE__ + ":" + std::to_string(__LINE__) + ")");               \
+      return _e == hipErrorOutOfMemory ? S3GRL_ERR_OUT_OF_MEMORY : S3GRL_ERR_HIP;             \
+    }                                                                                         \
+  } while (0)
+
+#define S3GRL_TRY(expr)                    \
+  do {                                     \
+    s3grl_status _s = (expr);              \
+    if (_s != S3GRL_OK) return _s;         \
+  } while (0)
+
+constexpr int kBlock = 256;            // threads per workgroup in the structure kernels
+constexpr int kMaxNodesLds = 327680;   // 4 bitmaps of N bits must fit 160 KiB of LDS
+constexpr int kMaxSignK = 8;
+
+// One gather job = one pair of output rows of one link (rows 2p, 2p+1 of that link).
+struct Job {
+  int64_t coef_off;   // first entry of this job's (id, coefficient) list
+  int64_t out_row;    // index of the first output row
+  int32_t link;       // link index
+  int32_t support;    // entries in the list after compaction
+  int32_t node_a;     // global id of row a
+  int32_t node_b;     // global id of row b, or -1 when the pair has a single row
+  int32_t local_a;    // local ids inside the link's subgraph
+  int32_t local_b;
+  int32_t z_a;        // label column of operator 0 (1 for src/dst)
+  int32_t z_b;
+};
+
+// Grow-only caching device allocator: plans are created and destroyed every benchmark step,
+// hipMalloc/hipFree of multi-GB blocks must not sit inside the timed region.
+class Arena {
+ public:
+  ~Arena();
+  s3grl_status alloc(size_t bytes, void** out);
+  void release(void* p);
+  size_t bytes_held() const { return held_; }
+
+ private:
+  std::multimap<size_t, void*> free_;
+  std::map<void*, size_t> live_;
+  size_t held_ = 0;
+};
+
+}  // namespace s3grl
+
+struct s3grl_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  s3grl::Arena arena;
+  bool profiling = false;
+  double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int64_t* d_scalars = nullptr;  // small device scratch for totals
+  int64_t* h_scalars = nullptr;  // pinned host mirror
+  float* x_padded = nullptr;     // 16-byte aligned copy of X when the caller's is not
+  size_t x_padded_bytes = 0;
+};
+
+struct s3grl_graph {
+  s3grl_context* ctx = nullptr;
+  int64_t num_nodes = 0;
+  int64_t nnz = 0;
+  int32_t* indptr = nullptr;   // [N+1] device, int32 (nnz < 2^31)
+  int32_t* indices = nullptr;  // [nnz] device
+};
+
+struct s3grl_plan {
+  s3grl_context* ctx = nullptr;
+  const s3grl_graph* graph = nullptr;
+  s3grl_cfg cfg{};
+  int64_t L = 0;
+  s3grl_plan_stats stats{};
+  // per link
+  int64_t* links = nullptr;      // [L,2]
+  int32_t* n_nodes = nullptr;    // [L]
+  int64_t* node_off = nullptr;   // [L+1]
+  int64_t* row_ptr = nullptr;    // [L+1]
+  int64_t* job_off = nullptr;    // [L+1]
+  int32_t* nodes = nullptr;      // [Σn] global ids, ascending per link
+  int8_t* dists = nullptr;       // [Σn] hop distance
+  // per job
+  s3grl::Job* jobs = nullptr;    // [njobs]
+  int64_t njobs = 0;
+  float* job_z = nullptr;        // [njobs, K, 2] label column of operators 1..K
+  int32_t* c_ids = nullptr;      // [Σ_jobs n] global node ids with a non-zero coefficient
+  float* c_coef = nullptr;       // [Σ_jobs n, K, 2]
+  int64_t* row_nodes = nullptr;  // [ΣR]
+  std::vector<void*> owned;      // everything above, for release
+};
+
+struct s3grl_sop {
+  s3grl_context* ctx = nullptr;
+  const s3grl_graph* graph = nullptr;
+  int32_t K = 0;
+  int64_t F = 0;
+  int64_t ldy = 0;       // leading dimension of X copy / Y_i (multiple of 4)
+  float* dinv = nullptr; // [N]
+  float* Y = nullptr;    // [K+1, N, ldy]; Y[0] = X
+  std::vector<void*> owned;
+};
+
+namespace s3grl {
+
+// structure.hip
+s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
+                          int hops, int plus, int32_t* n_nodes, int32_t* vol, int32_t* cn_cap,
+                          int32_t* err_flag);
+s3grl_status launch_scan_i32_to_i64(s3grl_context* ctx, const int32_t* in, int64_t n, int64_t* out);
+s3grl_status launch_build(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
+                          int hops, int plus, const int64_t* node_off, const int64_t* edge_off,
+                          const int64_t* cn_off, int32_t* nodes, int8_t* dists, int32_t* rowstart,
+                          int32_t* cnt, float* dinv, int32_t* lcsr, int32_t* cn_tmp,
+                          int32_t* cn_count, int32_t* n_rows, int32_t* n_jobs, int64_t* tot_edges);
+s3grl_status launch_make_jobs(s3grl_context* ctx, const int64_t* links, int64_t L,
+                              const int64_t* node_off, const int64_t* row_ptr,
+                              const int64_t* job_off, const int64_t* cn_off, const int32_t* cn_tmp,
+                              const int32_t* nodes, const int32_t* n_nodes, int K, Job* jobs,
+                              int64_t* row_nodes, int32_t* job_n);
+s3grl_status launch_propagate(s3grl_context* ctx, Job* jobs, int64_t njobs, const int64_t* coef_off,
+                              const int64_t* links, const int64_t* node_off,
+                              const int64_t* edge_off, const int32_t* nodes,
+                              const int32_t* rowstart, const int32_t* cnt, const float* dinv,
+                              const int32_t* lcsr, int K, int64_t max_nodes, int32_t* c_ids,
+                              float* c_coef, float* job_z, int64_t* tot_support);
+// gather.hip
+s3grl_status launch_gather(s3grl_context* ctx, const Job* jobs, int64_t njobs, const int32_t* c_ids,
+                           const float* c_coef, const float* job_z, int K, const float* X,
+                           int64_t ldx, int64_t F, float* rows);
+// sop.hip
+s3grl_status launch_global_dinv(s3grl_context* ctx, const s3grl_graph* g, float* dinv);
+s3grl_status launch_copy_pad(s3grl_context* ctx, const float* X, int64_t ldx, int64_t N, int64_t F,
+                             float* Y, int64_t ldy);
+s3grl_status launch_spmm_norm(s3grl_context* ctx, const s3grl_graph* g, const float* dinv,
+                              const float* Yin, float* Yout, int64_t F, int64_t ldy);
+s3grl_status launch_sop_links(s3grl_context* ctx, const s3grl_sop* s, const int64_t* links,
+                              int64_t L, float* rows);
+
+}  // namespace s3grl

@@ -1,0 +1,287 @@
+"""Host side of the engine above the C ABI: device buffers come from torch (plumbing only), every
+computation goes through libs3grl_hip.so.  Nothing here computes on the CPU.
+
+    eng = Engine()                                  # context on the current HIP device / stream
+    g = eng.graph(A)                                # scipy CSR (structure only) -> device CSR
+    res = eng.precompute(g, x, links, mode="pos", num_hops=3, sign_k=3)
+    res.rows      # fp32 [ΣR, K+1, 1+F] on the device  == torch.cat([x, x1..xK], -1) of the
+                  # reference's collated Data (sgrl_link_pred.py:204,449-459; models.py:372)
+    res.row_ptr   # int64 [L+1]
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+@dataclass
+class Precomputed:
+    rows: torch.Tensor        # [ΣR, K+1, 1+F] fp32, device
+    row_ptr: torch.Tensor     # [L+1] int64, device
+    row_nodes: torch.Tensor   # [ΣR] int64, device: global node id of every row
+    stats: dict = field(default_factory=dict)
+
+    @property
+    def num_links(self):
+        return self.row_ptr.numel() - 1
+
+
+class Graph:
+    """Device CSR of the train graph A.  Values are ignored (reference tuned_SIGN.py:153-156
+    drops them at `ssp.find` -> `SparseTensor(row, col)`)."""
+
+    def __init__(self, engine, indptr, indices, num_nodes):
+        self.engine = engine
+        self.num_nodes = int(num_nodes)
+        self.indptr = indptr      # int64 [N+1] device (kept alive for the caller's benefit)
+        self.indices = indices    # int32 [nnz] device
+        self.nnz = int(indices.numel())
+        h = C.c_void_p()
+        N.check(N.lib().s3grl_graph_create(engine._ctx, self.num_nodes, _ptr(indptr), _ptr(indices),
+                                           self.nnz, C.byref(h)), "s3grl_graph_create")
+        self._h = h
+        engine._children.add(self)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            if self.engine._ctx:          # the context owns the arena the handle points into
+                N.lib().s3grl_graph_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Plan:
+    def __init__(self, engine, graph, links, cfg):
+        self.engine, self.graph, self.cfg = engine, graph, cfg
+        self.num_links = int(links.shape[0])
+        h = C.c_void_p()
+        N.check(N.lib().s3grl_plan_create(engine._ctx, graph._h, _ptr(links), self.num_links,
+                                          C.byref(cfg), C.byref(h)), "s3grl_plan_create")
+        self._h = h
+        engine._children.add(self)
+        st = N.PlanStats()
+        N.check(N.lib().s3grl_plan_get_stats(h, C.byref(st)), "s3grl_plan_get_stats")
+        self.stats = st.as_dict()
+
+    def row_ptr(self):
+        out = torch.empty(self.num_links + 1, dtype=torch.int64, device=self.engine.device)
+        N.check(N.lib().s3grl_plan_row_ptr(self._h, _ptr(out)), "s3grl_plan_row_ptr")
+        return out
+
+    def row_nodes(self):
+        out = torch.empty(self.stats["total_rows"], dtype=torch.int64, device=self.engine.device)
+        N.check(N.lib().s3grl_plan_row_nodes(self._h, _ptr(out)), "s3grl_plan_row_nodes")
+        return out
+
+    def export_subgraphs(self):
+        """(node_ptr [L+1], nodes [Σn] ascending per link, dists [Σn]) — parity hook."""
+        dev = self.engine.device
+        node_ptr = torch.empty(self.num_links + 1, dtype=torch.int64, device=dev)
+        nodes = torch.empty(self.stats["total_nodes"], dtype=torch.int32, device=dev)
+        dists = torch.empty(self.stats["total_nodes"], dtype=torch.int8, device=dev)
+        N.check(N.lib().s3grl_plan_export_subgraphs(self._h, _ptr(node_ptr), _ptr(nodes),
+                                                    _ptr(dists)), "s3grl_plan_export_subgraphs")
+        return node_ptr, nodes, dists
+
+    def run(self, x, out=None):
+        if x is None:
+            N.check(N.ERR_NO_FEATURES, "s3grl_run")
+        eng = self.engine
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+        F = x.shape[1]
+        K = self.cfg.sign_k
+        R = self.stats["total_rows"]
+        if out is None:
+            out = torch.empty((R, K + 1, F + 1), dtype=torch.float32, device=eng.device)
+        else:
+            assert out.is_contiguous() and out.numel() == R * (K + 1) * (F + 1)
+        N.check(N.lib().s3grl_run(eng._ctx, self._h, _ptr(x), x.stride(0), F, _ptr(out)), "s3grl_run")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            if self.engine._ctx:          # the context owns the arena the handle points into
+                N.lib().s3grl_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Sop:
+    """SoP global state: Â = D^-1/2 A D^-1/2 of the whole graph and Y_i = Â^i X
+    (reference sgrl_link_pred.py:161-178 + tuned_SIGN.py:92-100 in closed form)."""
+
+    def __init__(self, engine, graph, x, sign_k):
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+        self.engine, self.graph, self.sign_k = engine, graph, int(sign_k)
+        self.F = int(x.shape[1])
+        h = C.c_void_p()
+        N.check(N.lib().s3grl_sop_create(engine._ctx, graph._h, _ptr(x), x.stride(0), self.F,
+                                         self.sign_k, C.byref(h)), "s3grl_sop_create")
+        self._h = h
+        engine._children.add(self)
+
+    def run(self, links, out=None):
+        eng = self.engine
+        L = int(links.shape[0])
+        if out is None:
+            out = torch.empty((2 * L, self.sign_k + 1, self.F + 1), dtype=torch.float32,
+                              device=eng.device)
+        N.check(N.lib().s3grl_sop_run(eng._ctx, self._h, _ptr(links), L, _ptr(out)), "s3grl_sop_run")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            if self.engine._ctx:          # the context owns the arena the handle points into
+                N.lib().s3grl_sop_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One context = one device + one stream + one workspace arena."""
+
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("s3grl_amd needs a HIP device (MI355X); there is no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
+            else torch.device(device)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream().cuda_stream
+        h = C.c_void_p()
+        N.check(N.lib().s3grl_context_create(self.device.index or 0, C.c_void_p(stream), C.byref(h)),
+                "s3grl_context_create")
+        self._ctx = h
+        self._children = weakref.WeakSet()
+
+    # ---- inputs ---------------------------------------------------------------------------
+    def graph(self, A=None, *, indptr=None, indices=None, num_nodes=None):
+        """From a scipy CSR matrix (what the reference hands its operators) or raw CSR arrays."""
+        if A is not None:
+            import scipy.sparse as ssp
+
+            A = ssp.csr_matrix(A)
+            if not A.has_canonical_format:
+                A = A.copy()
+                A.sum_duplicates()
+            if A.nnz and (A.data == 0).any():
+                raise ValueError("stored zeros in A are not supported (the reference's BFS would "
+                                 "follow them while its operator drops them)")
+            if (A != A.T).nnz:
+                raise NotImplementedError("A must be structurally symmetric (directed graphs are "
+                                          "not implemented)")
+            indptr, indices, num_nodes = A.indptr, A.indices, A.shape[0]
+        ip = torch.as_tensor(np.asarray(indptr, dtype=np.int64)).to(self.device)
+        ix = torch.as_tensor(np.asarray(indices, dtype=np.int32)).to(self.device)
+        return Graph(self, ip, ix, num_nodes)
+
+    def features(self, x):
+        x = torch.as_tensor(x)
+        return x.to(device=self.device, dtype=torch.float32).contiguous()
+
+    def links(self, link_index):
+        """[2, L] (the reference's layout) or [L, 2] -> int64 [L, 2] on the device."""
+        li = torch.as_tensor(link_index)
+        if li.dim() != 2:
+            raise ValueError("link_index must be 2-D")
+        if li.shape[0] == 2 and li.shape[1] != 2:
+            li = li.t()
+        elif li.shape[1] != 2:
+            raise ValueError("link_index must be [2, L]")
+        return li.to(device=self.device, dtype=torch.int64).contiguous()
+
+    # ---- the batched native entry ----------------------------------------------------------
+    def plan(self, graph, links, *, mode="pos", num_hops=1, sign_k=3, strategy="intersection",
+             directed=False, keep_subgraphs=False):
+        cfg = N.Cfg()
+        cfg.mode = {"pos": N.MODE_POS, "pos_plus": N.MODE_POS_PLUS}[mode]
+        cfg.num_hops = int(num_hops)
+        cfg.sign_k = int(sign_k)
+        if strategy not in N.STRATEGY:
+            raise NotImplementedError(f"check strat {strategy}")      # tuned_SIGN.py:235
+        cfg.strategy = N.STRATEGY[strategy]
+        cfg.directed = int(bool(directed))
+        cfg.reserved[0] = 1 if keep_subgraphs else 0
+        return Plan(self, graph, links, cfg)
+
+    def precompute(self, graph, x, links, *, mode="pos", num_hops=1, sign_k=3,
+                   strategy="intersection", directed=False, out=None):
+        """links: int64 [L,2] device tensor (see `links()`); x: fp32 [N,F] device tensor."""
+        if x is None:
+            N.check(N.ERR_NO_FEATURES, "precompute")
+        if mode == "sop":
+            sop = Sop(self, graph, x, sign_k)
+            try:
+                rows = sop.run(links, out)
+            finally:
+                sop.close()
+            L = links.shape[0]
+            row_ptr = torch.arange(0, 2 * L + 1, 2, dtype=torch.int64, device=self.device)
+            return Precomputed(rows, row_ptr, links.reshape(-1).clone(), {"num_links": L,
+                                                                          "total_rows": 2 * L})
+        plan = self.plan(graph, links, mode=mode, num_hops=num_hops, sign_k=sign_k,
+                         strategy=strategy, directed=directed)
+        try:
+            rows = plan.run(x, out)
+            res = Precomputed(rows, plan.row_ptr(), plan.row_nodes(), dict(plan.stats))
+        finally:
+            plan.close()
+        return res
+
+    # ---- measurement -----------------------------------------------------------------------
+    def set_profiling(self, on):
+        N.check(N.lib().s3grl_context_set_profiling(self._ctx, int(bool(on))), "set_profiling")
+
+    def timings(self):
+        buf = (C.c_double * 8)()
+        N.check(N.lib().s3grl_context_timings(self._ctx, buf), "s3grl_context_timings")
+        keys = ["structure_ms", "propagate_ms", "gather_ms", "sop_setup_ms", "sop_run_ms",
+                "gather_launches"]
+        return {k: float(buf[i]) for i, k in enumerate(keys)}
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            for child in list(self._children):
+                child.close()
+            N.lib().s3grl_context_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default = {}
+
+
+def default_engine(device=None):
+    key = str(device) if device is not None else "cur%d" % torch.cuda.current_device()
+    if key not in _default:
+        _default[key] = Engine(device)
+    return _default[key]

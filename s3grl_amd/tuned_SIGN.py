@@ -1,0 +1,189 @@
+"""Drop-in for the reference's `tuned_SIGN` module on MI355X.
+
+`from s3grl_amd.tuned_SIGN import TunedSIGN, OptimizedSignOperations` gives the same names,
+positional signatures, argument meaning and error behaviour as reference tuned_SIGN.py, so
+`utils.extract_enclosing_subgraphs` (reference utils.py:446-554) can call them unchanged.  Each
+static method uploads (and caches) A and x, runs the HIP engine once for the whole link list and
+returns a `list` of per-link `Data`-like objects that are views into one collated tensor.
+
+What is NOT mirrored (raises NotImplementedError, the reference's own convention for unsupported
+flows): random-walk / ScaLed subgraphs (`rw_kwargs`), per-hop sampling (`ratio_per_hop < 1`,
+`max_nodes_per_hop`), directed graphs (`A_csc`), and `k_node_set_strategy='union'`, which the
+reference itself cannot execute (tuned_SIGN.py:243 builds a ragged tensor).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from . import engine as _engine
+
+try:  # PyG present: hand back real Data objects
+    from torch_geometric.data import Data as _PygData  # type: ignore
+except Exception:  # PyG absent (this image): attribute/item compatible stand-in
+    _PygData = None
+
+
+class LinkData:
+    """Minimal stand-in for torch_geometric.data.Data: attribute and item access, `keys()`,
+    `to(device)`.  Holds `x`, `x1..xK` ([R, 1+F] views) and `y`."""
+
+    def __init__(self, **kw):
+        self.__dict__["_store"] = dict(kw)
+
+    def __getattr__(self, k):
+        try:
+            return self.__dict__["_store"][k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self._store[k] = v
+
+    def __getitem__(self, k):
+        return self._store[k]
+
+    def __setitem__(self, k, v):
+        self._store[k] = v
+
+    def __contains__(self, k):
+        return k in self._store
+
+    def keys(self):
+        return list(self._store.keys())
+
+    def pop(self, k, *d):
+        return self._store.pop(k, *d)
+
+    def to(self, device):
+        return LinkData(**{k: (v.to(device) if torch.is_tensor(v) else v)
+                           for k, v in self._store.items()})
+
+    @property
+    def num_features(self):
+        return self._store["x"].shape[-1]
+
+    def __repr__(self):
+        parts = [f"{k}={list(v.shape) if torch.is_tensor(v) else v}" for k, v in self._store.items()]
+        return "LinkData(" + ", ".join(parts) + ")"
+
+
+def _make_data(**kw):
+    return _PygData(**kw) if _PygData is not None else LinkData(**kw)
+
+
+# A and x are the same objects across the 6 operator calls of one run
+# (reference sgrl_link_pred.py:195-203): upload once.
+_cache = {}
+
+
+def _device_inputs(A, x):
+    eng = _engine.default_engine()
+    kA = ("A", id(A), A.shape, A.nnz)
+    if kA not in _cache:
+        for k in [k for k in _cache if k[0] == "A"]:
+            _cache.pop(k).close()
+        _cache[kA] = eng.graph(A)
+    kx = ("x", id(x), tuple(x.shape), x.data_ptr() if torch.is_tensor(x) else 0)
+    if kx not in _cache:
+        for k in [k for k in _cache if k[0] == "x"]:
+            _cache.pop(k)
+        _cache[kx] = eng.features(x)
+    return eng, _cache[kA], _cache[kx]
+
+
+def clear_cache():
+    for k in list(_cache):
+        v = _cache.pop(k)
+        if hasattr(v, "close"):
+            v.close()
+
+
+def _as_data_list(res, K, y):
+    """Zero-copy per-link views of the collated rows: x, x1..xK each [R, 1+F]."""
+    out_dev = os.environ.get("S3GRL_OUTPUT_DEVICE", "cpu")
+    rows = res.rows if out_dev != "cpu" else res.rows.cpu()
+    ptr = res.row_ptr.cpu().tolist()
+    data_list = []
+    for l in range(len(ptr) - 1):
+        blk = rows[ptr[l]:ptr[l + 1]]
+        d = _make_data(x=blk[:, 0, :], y=y)
+        for i in range(1, K + 1):
+            d[f"x{i}"] = blk[:, i, :]
+        data_list.append(d)
+    return data_list
+
+
+def _check_unsupported(ratio_per_hop, max_nodes_per_hop, directed, A_csc, rw_kwargs):
+    if rw_kwargs:
+        raise NotImplementedError("random-walk (ScaLed) subgraphs are not implemented in the "
+                                  "MI355X engine yet")
+    if ratio_per_hop is not None and ratio_per_hop < 1.0:
+        raise NotImplementedError("ratio_per_hop < 1.0 (per-hop sampling) is not implemented")
+    if max_nodes_per_hop is not None:
+        raise NotImplementedError("max_nodes_per_hop is not implemented")
+    if directed or A_csc is not None:
+        raise NotImplementedError("directed graphs are not implemented")
+
+
+class OptimizedSignOperations:
+    @staticmethod
+    def get_SoP_prepped_ds(powers_of_A, link_index, A, x, y):
+        """Reference tuned_SIGN.py:49-134.  `powers_of_A` is only consulted for its length
+        (= sign_k): the engine rebuilds Â from A's structure, which is what the reference's
+        caller derived it from (sgrl_link_pred.py:161-178)."""
+        print("SoP Optimized Flow.")
+        K = len(powers_of_A)
+        if K < 1:
+            raise ValueError("powers_of_A is empty")
+        eng, g, xd = _device_inputs(A, x)
+        res = eng.precompute(g, xd, eng.links(link_index), mode="sop", sign_k=K)
+        return _as_data_list(res, K, y)
+
+    @staticmethod
+    def get_PoS_prepped_ds(link_index, num_hops, A, ratio_per_hop, max_nodes_per_hop, directed, A_csc,
+                           x, y, sign_kwargs, rw_kwargs):
+        """Reference tuned_SIGN.py:137-189."""
+        print("PoS Optimized Flow.")
+        _check_unsupported(ratio_per_hop, max_nodes_per_hop, directed, A_csc, rw_kwargs)
+        K = sign_kwargs['sign_k']
+        assert x is not None                                  # tuned_SIGN.py:166
+        eng, g, xd = _device_inputs(A, x)
+        res = eng.precompute(g, xd, eng.links(link_index), mode="pos", num_hops=num_hops, sign_k=K)
+        return _as_data_list(res, K, y)
+
+    @staticmethod
+    def get_PoS_Plus_prepped_ds(link_index, num_hops, A, ratio_per_hop, max_nodes_per_hop, directed,
+                                A_csc, x, y, sign_kwargs, rw_kwargs):
+        """Reference tuned_SIGN.py:192-262."""
+        print("PoS Plus Optimized Flow.")
+        _check_unsupported(ratio_per_hop, max_nodes_per_hop, directed, A_csc, rw_kwargs)
+        K = sign_kwargs['sign_k']
+        strat = sign_kwargs['k_node_set_strategy']
+        if strat not in ('union', 'intersection'):
+            raise NotImplementedError(f"check strat {strat}")  # tuned_SIGN.py:235
+        if strat == 'union':
+            raise NotImplementedError("check strategy union: unusable in the reference "
+                                      "(tuned_SIGN.py:243), not implemented here")
+        assert x is not None                                  # tuned_SIGN.py:221
+        eng, g, xd = _device_inputs(A, x)
+        res = eng.precompute(g, xd, eng.links(link_index), mode="pos_plus", num_hops=num_hops,
+                             sign_k=K, strategy=strat)
+        return _as_data_list(res, K, y)
+
+
+class TunedSIGN:
+    """Name kept for import compatibility (reference tuned_SIGN.py:13-44).  The non-optimised
+    flows it serves (`optimize_sign=False`, reference utils.py:497-550) are outside the hot path
+    (no paper config uses them for SIGN) and are not implemented."""
+
+    def __init__(self, K):
+        self.K = K
+
+    def __call__(self, data, sign_k):
+        raise NotImplementedError("non-optimised SIGN flow (optimize_sign=False) is not part of the "
+                                  "MI355X engine; use OptimizedSignOperations")
+
+    def SoP_data_creation(self, sop_data_list):
+        raise NotImplementedError("non-optimised SoP flow is not part of the MI355X engine")

@@ -1,0 +1,231 @@
+"""-m gpu: the HIP engine (through the C ABI) against the reference-pinned extraction fixtures
+and the fp64 oracle.  Bars (BASELINE.json north_star): node-index sets bit-exact; float
+diffusion products within 1e-5 relative, measured as |got - ref64| <= 1e-5 * max(|ref64|,
+‖ref64 row‖∞) per output row [1+F] (the row-norm floor keeps elements that cancel to ~0 from
+dividing by nothing)."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import DIFFUSION_NAMES, EXTRACT_NAMES, csr_from_undirected, load_diffusion, load_extract
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    from s3grl_amd.engine import Engine
+
+    assert torch.cuda.is_available()
+    e = Engine("cuda:0")
+    yield e
+    e.close()
+
+
+def rel_err(got, ref):
+    ref = np.asarray(ref, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    scale = np.maximum(np.abs(ref), np.abs(ref).max(axis=-1, keepdims=True))
+    return float(np.max(np.abs(got - ref) / np.maximum(scale, 1e-300))) if ref.size else 0.0
+
+
+def _ragged(blob, key, i):
+    off = blob[key + "_off"]
+    return blob[key][off[i]:off[i + 1]]
+
+
+@pytest.mark.parametrize("name", EXTRACT_NAMES)
+def test_subgraph_node_sets_bit_exact(eng, name):
+    g = load_extract(name)
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    G = eng.graph(A)
+    links = eng.links(g["links"].T)
+    for h in g["hops"]:
+        plan = eng.plan(G, links, mode="pos_plus", num_hops=int(h), sign_k=2, keep_subgraphs=True)
+        node_ptr, nodes, dists = (t.cpu().numpy() for t in plan.export_subgraphs())
+        row_ptr = plan.row_ptr().cpu().numpy()
+        row_nodes = plan.row_nodes().cpu().numpy()
+        for li, (s, d) in enumerate(g["links"]):
+            mine = nodes[node_ptr[li]:node_ptr[li + 1]]
+            md = dists[node_ptr[li]:node_ptr[li + 1]]
+            exp_nodes = _ragged(g, f"h{h}_nodes", li)
+            exp_d = _ragged(g, f"h{h}_dists", li)
+            o = np.argsort(exp_nodes, kind="stable")
+            np.testing.assert_array_equal(mine, exp_nodes[o])           # the set, ascending
+            np.testing.assert_array_equal(md, exp_d[o])                 # per-hop membership
+            rn = row_nodes[row_ptr[li]:row_ptr[li + 1]]
+            assert rn[0] == s and rn[1] == d
+            np.testing.assert_array_equal(rn[2:], _ragged(g, f"h{h}_cn", li))   # CCN rows
+        # induced, masked edge count == non-zero triples of the reference's sub-CSR
+        exp_e = sum(int((_ragged(g, f"h{h}_sub", li)[:, 2] != 0).sum()) for li in range(len(g["links"])))
+        assert plan.stats["total_sub_edges"] == exp_e
+        assert plan.stats["total_nodes"] == int(node_ptr[-1])
+        plan.close()
+    G.close()
+
+
+@pytest.mark.parametrize("name", DIFFUSION_NAMES)
+@pytest.mark.parametrize("mode", ["pos", "pos_plus"])
+def test_diffusion_vs_golden(eng, name, mode):
+    g = load_diffusion(name)
+    n, K, h = int(g["num_nodes"]), int(g["K"]), int(g["num_hops"])
+    G = eng.graph(csr_from_undirected(n, g["edges"]))
+    x = eng.features(g["X"])
+    res = eng.precompute(G, x, eng.links(g["links"].T), mode=mode, num_hops=h, sign_k=K)
+    tag = "pos" if mode == "pos" else "plus"
+    np.testing.assert_array_equal(res.row_ptr.cpu().numpy(), g[f"{tag}_row_ptr"])
+    np.testing.assert_array_equal(res.row_nodes.cpu().numpy(), g[f"{tag}_rows_global"])
+    assert rel_err(res.rows.cpu().numpy(), g[f"{tag}_rows"]) < TOL
+    G.close()
+
+
+@pytest.mark.parametrize("F", [1, 5, 16, 130, 500, 513, 1433])
+def test_feature_widths(eng, F):
+    """column tiling / padding paths of the gather kernel (F not a multiple of 4, > 512, ...)"""
+    g = load_extract("rand300")
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    rng = np.random.default_rng(F)
+    X = rng.standard_normal((n, F))
+    links = g["links"][:12].T
+    kw = {"sign_k": 3, "k_node_set_strategy": "intersection"}
+    G = eng.graph(A)
+    res = eng.precompute(G, eng.features(X), eng.links(links), mode="pos_plus", num_hops=2, sign_k=3)
+    ref, ptr, _ = oracle.collate_rows(
+        oracle.get_PoS_Plus_prepped_ds(links, 2, A, X, 1, kw, dtype=np.float64), 3)
+    np.testing.assert_array_equal(res.row_ptr.cpu().numpy(), ptr)
+    assert rel_err(res.rows.cpu().numpy(), ref) < TOL
+    G.close()
+
+
+@pytest.mark.parametrize("K", [1, 2, 4, 5, 8])
+def test_sign_k_range(eng, K):
+    g = load_extract("usair")
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = np.random.default_rng(K).random((n, 24))
+    links = g["links"][:10].T
+    kw = {"sign_k": K, "k_node_set_strategy": "intersection"}
+    G = eng.graph(A)
+    res = eng.precompute(G, eng.features(X), eng.links(links), mode="pos", num_hops=2, sign_k=K)
+    ref, _, _ = oracle.collate_rows(oracle.get_PoS_prepped_ds(links, 2, A, X, 1, kw, dtype=np.float64), K)
+    assert rel_err(res.rows.cpu().numpy(), ref) < TOL
+    G.close()
+
+
+def test_known_answers_on_device(eng):
+    # triangle, link (0,1): x1[0] = (1/√2)[0|X2]; x2[0] = ½[1|X0] + ½[1|X1]; CN = {2}
+    A = csr_from_undirected(3, [[0, 1], [0, 2], [1, 2]])
+    X = np.array([[1.0, 10.0], [2.0, 20.0], [3.0, 30.0]])
+    G = eng.graph(A)
+    res = eng.precompute(G, eng.features(X), eng.links(np.array([[0], [1]])), mode="pos_plus",
+                         num_hops=1, sign_k=2)
+    rows = res.rows.cpu().numpy()
+    s = 1 / np.sqrt(2)
+    assert res.row_nodes.cpu().tolist() == [0, 1, 2]
+    np.testing.assert_allclose(rows[0, 0], [1, 1, 10])
+    np.testing.assert_allclose(rows[2, 0], [0, 3, 30])
+    np.testing.assert_allclose(rows[0, 1], [0, 3 * s, 30 * s], rtol=1e-6)
+    np.testing.assert_allclose(rows[0, 2], [1.0, 1.5, 15.0], rtol=1e-6)
+    np.testing.assert_allclose(rows[2, 1], [2 * s, 3 * s, 30 * s], rtol=1e-6)
+    G.close()
+    # single edge: everything masked -> inf -> 0 -> operators are all zero
+    A = csr_from_undirected(2, [[0, 1]])
+    G = eng.graph(A)
+    res = eng.precompute(G, eng.features(np.array([[2.0, 3.0], [5.0, 7.0]])),
+                         eng.links(np.array([[0], [1]])), mode="pos", num_hops=2, sign_k=3)
+    rows = res.rows.cpu().numpy()
+    np.testing.assert_array_equal(rows[:, 0], [[1, 2, 3], [1, 5, 7]])
+    np.testing.assert_array_equal(rows[:, 1:], 0)
+    G.close()
+
+
+def test_empty_and_errors(eng):
+    import torch
+
+    A = csr_from_undirected(5, [[0, 2], [1, 2], [0, 3], [1, 3], [3, 4]])
+    G = eng.graph(A)
+    x = eng.features(np.eye(5))
+    empty = torch.zeros((0, 2), dtype=torch.int64, device=eng.device)
+    res = eng.precompute(G, x, empty, mode="pos", num_hops=2, sign_k=2)
+    assert res.rows.shape == (0, 3, 6) and res.row_ptr.cpu().tolist() == [0]
+    with pytest.raises(ValueError):
+        eng.precompute(G, x, eng.links(np.array([[0], [7]])), mode="pos", num_hops=1, sign_k=2)
+    with pytest.raises(ValueError):
+        eng.precompute(G, x, eng.links(np.array([[2], [2]])), mode="pos", num_hops=1, sign_k=2)
+    with pytest.raises(NotImplementedError):
+        eng.precompute(G, x, eng.links(np.array([[0], [1]])), mode="pos_plus", num_hops=1, sign_k=2,
+                       strategy="union")
+    with pytest.raises(AssertionError):
+        eng.precompute(G, None, eng.links(np.array([[0], [1]])), mode="pos", num_hops=1, sign_k=2)
+    # the engine is still usable after errors, and deterministic run to run
+    a = eng.precompute(G, x, eng.links(np.array([[0, 3], [1, 4]])), mode="pos", num_hops=2, sign_k=3)
+    b = eng.precompute(G, x, eng.links(np.array([[0, 3], [1, 4]])), mode="pos", num_hops=2, sign_k=3)
+    assert torch.equal(a.rows, b.rows)
+    G.close()
+
+
+def test_dropin_operator_api(eng):
+    """Same positional signature and return shape as reference tuned_SIGN.py:137-138,192-193."""
+    import torch
+    from s3grl_amd.tuned_SIGN import OptimizedSignOperations, clear_cache
+
+    g = load_extract("usair")
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = torch.from_numpy(np.random.default_rng(3).random((n, 16)).astype(np.float32))
+    link_index = torch.from_numpy(g["links"][:8].T.copy())
+    kw = {"sign_k": 2, "use_feature": True, "sign_type": "PoS", "optimize_sign": True,
+          "k_heuristic": 1, "k_node_set_strategy": "intersection"}
+    lst = OptimizedSignOperations.get_PoS_Plus_prepped_ds(link_index, 1, A, 1.0, None, False, None, X,
+                                                          1, kw, None)
+    ref = oracle.get_PoS_Plus_prepped_ds(link_index.numpy(), 1, A, X.numpy().astype(np.float64), 1, kw,
+                                         dtype=np.float64)
+    assert len(lst) == 8
+    for d, r in zip(lst, ref):
+        assert d.y == 1 and d.x.shape == r["x"].shape and d["x2"].shape == r["x2"].shape
+        for k in ("x", "x1", "x2"):
+            assert rel_err(d[k].numpy(), r[k]) < TOL
+    with pytest.raises(NotImplementedError):
+        OptimizedSignOperations.get_PoS_prepped_ds(link_index, 1, A, 0.5, None, False, None, X, 1, kw,
+                                                   None)
+    with pytest.raises(AssertionError):
+        OptimizedSignOperations.get_PoS_prepped_ds(link_index, 1, A, 1.0, None, False, None, None, 1,
+                                                   kw, None)
+    clear_cache()
+
+
+def test_full_size_properties(eng):
+    """Cora-size run: properties that need no oracle — row 0/1 of operator 0 are [1|X[src/dst]],
+    outputs are linear in X, and swapping (src,dst) swaps the two rows."""
+    import torch
+
+    topo = np.load(__import__("pathlib").Path(__file__).resolve().parent.parent / "s3grl_amd" /
+                   "data" / "topo_cora.npz")
+    n, e = int(topo["num_nodes"]), topo["edges"].astype(np.int64)
+    A = csr_from_undirected(n, e)
+    rng = np.random.default_rng(5)
+    X1 = torch.from_numpy(rng.random((n, 64)).astype(np.float32))
+    X2 = torch.from_numpy(rng.random((n, 64)).astype(np.float32))
+    links = np.concatenate([e[rng.choice(len(e), 600, replace=False)],
+                            rng.integers(0, n, size=(600, 2))])
+    links = links[links[:, 0] != links[:, 1]]
+    G = eng.graph(A)
+    L = eng.links(links.T)
+    a = eng.precompute(G, eng.features(X1), L, mode="pos", num_hops=3, sign_k=3).rows
+    b = eng.precompute(G, eng.features(X2), L, mode="pos", num_hops=3, sign_k=3).rows
+    c = eng.precompute(G, eng.features(X1 + 2 * X2), L, mode="pos", num_hops=3, sign_k=3).rows
+    lin = a[:, :, 1:] + 2 * b[:, :, 1:]
+    assert torch.allclose(c[:, :, 1:], lin, rtol=1e-4, atol=1e-5)
+    assert torch.equal(c[:, :, 0], a[:, :, 0])                               # label column: X-free
+    src = torch.from_numpy(links[:, 0])
+    assert torch.equal(a[0::2, 0, 1:].cpu(), X1[src])
+    assert torch.all(a[:, 0, 0] == 1)
+    sw = eng.precompute(G, eng.features(X1), eng.links(links[:, ::-1].T.copy()), mode="pos",
+                        num_hops=3, sign_k=3).rows
+    assert torch.equal(sw[0::2], a[1::2]) and torch.equal(sw[1::2], a[0::2])
+    G.close()
