@@ -66,6 +66,11 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64.so.7; import it FIRST so that the dynamic loader binds
+    # this library to the same HIP runtime (one runtime per process: device pointers and
+    # streams are shared with torch).
+    import torch  # noqa: F401
+
     path = Path(os.environ.get("S3GRL_LIB", LIB_PATH))
     if not path.exists():
         raise ImportError(
