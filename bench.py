@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Benchmark of the S3GRL operator precompute on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload pubmed_pos_k3]
+
+One "step" = one pass of the hot path (plan: extraction + operator rows; run: feature gather)
+over the workload's whole link list (train/valid/test x pos/neg, 164 000 links for PubMed) with
+the graph and X already resident in HBM.  Prints ONE JSON line (rank 0).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): link pairs are independent units,
+so every rank runs the same per-GPU workload with no data-path collective ("weak" scaling);
+value = units all ranks processed / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(stats, F, K):
+    """B_link = 8n + 4 vol(S) + 4 n F + 4 R (K+1)(1+F), summed exactly from the plan.
+    Returned as (whole path, gather-kernel share = feature rows read once + output written once)."""
+    n, vol, R = stats["total_nodes"], stats["total_volume"], stats["total_rows"]
+    gather = 4 * n * F + 4 * R * (K + 1) * (1 + F)
+    return 8 * n + 4 * vol + gather, gather
+
+
+def cpu_baseline(w, link_index, y, budget_s, max_links):
+    """The oracle (reference-structured CPU restatement, oracle/s3grl_oracle.py) timed on one
+    core over a bounded sample of the same link list.  kind = "port"."""
+    import torch
+
+    import oracle
+
+    torch.set_num_threads(1)
+    rng = np.random.default_rng(6)
+    half = max_links // 2
+    idx = np.concatenate([rng.choice(np.flatnonzero(y == 1), half, replace=False),
+                          rng.choice(np.flatnonzero(y == 0), half, replace=False)])
+    idx = idx[rng.permutation(len(idx))]
+    kw = {"sign_k": w.sign_k, "k_node_set_strategy": "intersection"}
+    fn = {"pos": oracle.get_PoS_prepped_ds, "pos_plus": oracle.get_PoS_Plus_prepped_ds}.get(w.mode)
+    done, t0 = 0, time.perf_counter()
+    chunk = 50
+    if w.mode == "sop":
+        t0 = time.perf_counter()
+        P = oracle.global_normalized_powers(w.A, w.sign_k, np.float32)
+        sel = idx[:max_links]
+        oracle.get_SoP_prepped_ds(P, link_index[:, sel], w.A, w.X, 1, dtype=np.float32)
+        done = len(sel)
+    else:
+        while done < len(idx) and time.perf_counter() - t0 < budget_s:
+            sel = idx[done:done + chunk]
+            fn(link_index[:, sel], w.num_hops, w.A, w.X, 1, kw, dtype=np.float32)
+            done += len(sel)
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "link pairs/s", "cores": 1, "kind": "port",
+            "sample": f"{done} links (half pos, half neg, seed 6) of the same list in {dt:.1f} s, "
+                      f"1 thread; host has {os.cpu_count()} cpus"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="pubmed_pos_k3")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-links", type=int, default=2000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-links", type=int, default=0, help="truncate the link list (debug)")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    import __graft_entry__ as ge
+
+    ge.build()
+    from s3grl_amd import workloads
+    from s3grl_amd.engine import Engine
+
+    w = workloads.make(args.workload)
+    link_index, y = w.split.all_links()
+    if args.max_links:
+        link_index, y = link_index[:, :args.max_links], y[:args.max_links]
+    L = link_index.shape[1]
+    F, K = w.X.shape[1], w.sign_k
+
+    eng = Engine(f"cuda:{local_rank}")
+    g = eng.graph(w.A)
+    x = eng.features(w.X)
+    links = eng.links(link_index)
+
+    out = None
+
+    def step():
+        nonlocal out
+        if w.mode == "sop":
+            res = eng.precompute(g, x, links, mode="sop", sign_k=K, out=out)
+            out = res.rows
+            return res.stats
+        plan = eng.plan(g, links, mode=w.mode, num_hops=w.num_hops, sign_k=K)
+        if out is None:
+            out = torch.empty((plan.stats["total_rows"], K + 1, F + 1), dtype=torch.float32,
+                              device=eng.device)
+        plan.run(x, out)
+        st = dict(plan.stats)
+        plan.close()
+        return st
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    stats = None
+    for _ in range(args.warmup):
+        stats = step()
+    barrier()
+    eng.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stats = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tm = eng.timings()
+    eng.set_profiling(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * L * args.steps / dt
+        line = {
+            "metric": "link-pair precomputes/sec", "value": value, "unit": "link pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64" if w.mode == "sop" else "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "mode": w.mode, "sign_k": K, "num_hops": w.num_hops,
+                       "links_per_step_per_gpu": L, "num_nodes": w.split.num_nodes,
+                       "features": F, "graph": "real topology, synthetic features (BASELINE.md §3)"},
+        }
+        if w.mode != "sop" and stats:
+            path_bytes, gather_bytes = algorithmic_bytes(stats, F, K)
+            launches = max(tm["gather_launches"], 1.0)
+            gather_ms = tm["gather_ms"] / launches
+            achieved = gather_bytes / (gather_ms * 1e-3) / 1e9 if gather_ms > 0 else 0.0
+            traffic = None
+            pmc = REPO / "profiles" / "pmc_latest.json"
+            if pmc.exists():
+                try:
+                    rec = json.loads(pmc.read_text())
+                    if rec.get("workload") == args.workload and rec.get("links") == L:
+                        traffic = rec.get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            line["roofline"] = {
+                "bound": "hbm", "kernel": "gather_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": gather_bytes, "kernel_ms": gather_ms,
+                "path_algorithmic_bytes_per_step": path_bytes,
+                "path_achieved_GBps": path_bytes / (ms_per_step * 1e-3) / 1e9,
+                "phase_ms": {"structure": tm["structure_ms"] / max(tm["plans"], 1.0),
+                             "propagate": tm["propagate_ms"] / max(tm["plans"], 1.0),
+                             "gather": gather_ms},
+                "mean_subgraph_nodes": stats["total_nodes"] / max(L, 1),
+                "mean_support": stats["total_support"] / max(stats["num_row_pairs"], 1),
+            }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(w, link_index, y, args.cpu_seconds, args.cpu_links)
+            line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -144,11 +144,13 @@ s3grl_status s3grl_sop_destroy(s3grl_sop* s);
 s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t* links,
                            int64_t num_links, float* rows);
 
-/* last kernel timings of this context in milliseconds (HIP events on the context's stream):
- * what[0]=structure (count+build), [1]=propagate, [2]=gather, [3]=sop setup, [4]=sop run;
- * plus launches of the dominant kernel in what[5]. Host array of 8 doubles. */
+/* Per-phase device time accumulated since profiling was last switched on, in milliseconds,
+ * from HIP events recorded on the context's stream around the kernels themselves:
+ * what[0]=structure (count+scan+build+jobs), [1]=propagate, [2]=gather (the dominant kernel),
+ * [3]=sop setup, [4]=sop run, [5]=number of gather launches in [2], [6]=number of plans in
+ * [0],[1], [7]=number of sop runs in [4].  Host array of 8 doubles. */
 s3grl_status s3grl_context_timings(s3grl_context* ctx, double* what);
-/* enable/disable the per-phase HIP-event timing above (off by default: events serialise) */
+/* switch the HIP-event timing on/off and zero the accumulators (off by default) */
 s3grl_status s3grl_context_set_profiling(s3grl_context* ctx, int32_t enabled);
 
 #ifdef __cplusplus

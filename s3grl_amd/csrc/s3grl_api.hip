@@ -153,15 +153,30 @@ s3grl_status s3grl_context_destroy(s3grl_context* ctx) {
   return S3GRL_OK;
 }
 
+// The gather launch is asynchronous: its two events are resolved lazily (next profiled call or
+// s3grl_context_timings), so profiling adds no synchronisation of its own to a step.
+static s3grl_status resolve_pending_gather(s3grl_context* ctx) {
+  if (!ctx->gather_pending) return S3GRL_OK;
+  S3GRL_HIP_TRY(hipEventSynchronize(ctx->ev[4]));
+  float ms = 0;
+  S3GRL_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
+  ctx->timings[2] += ms;
+  ctx->timings[5] += 1.0;
+  ctx->gather_pending = false;
+  return S3GRL_OK;
+}
+
 s3grl_status s3grl_context_set_profiling(s3grl_context* ctx, int32_t enabled) {
   if (!ctx) return S3GRL_ERR_INVALID_ARGUMENT;
+  S3GRL_TRY(resolve_pending_gather(ctx));
   ctx->profiling = enabled != 0;
+  for (double& t : ctx->timings) t = 0.0;   // (re)start accumulation
   return S3GRL_OK;
 }
 
 s3grl_status s3grl_context_timings(s3grl_context* ctx, double* what) {
   if (!ctx || !what) return S3GRL_ERR_INVALID_ARGUMENT;
-  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  S3GRL_TRY(resolve_pending_gather(ctx));
   std::memcpy(what, ctx->timings, sizeof(ctx->timings));
   return S3GRL_OK;
 }
@@ -367,9 +382,10 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   if (ctx->profiling) {
     float ms = 0;
     S3GRL_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
-    ctx->timings[0] = ms;
+    ctx->timings[0] += ms;
     S3GRL_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
-    ctx->timings[1] = ms;
+    ctx->timings[1] += ms;
+    ctx->timings[6] += 1.0;
   }
   if (!keep) plan->nodes = nullptr;
   *out = plan.release();
@@ -390,7 +406,7 @@ s3grl_status s3grl_plan_row_ptr(const s3grl_plan* p, int64_t* row_ptr) {
 }
 
 s3grl_status s3grl_plan_row_nodes(const s3grl_plan* p, int64_t* row_nodes) {
-  if (!p || !row_nodes) return S3GRL_ERR_INVALID_ARGUMENT;
+  if (!p || (!row_nodes && p->stats.total_rows)) return S3GRL_ERR_INVALID_ARGUMENT;
   if (p->stats.total_rows)
     S3GRL_HIP_TRY(hipMemcpyAsync(row_nodes, p->row_nodes, (size_t)p->stats.total_rows * 8,
                                  hipMemcpyDeviceToDevice, p->ctx->stream));
@@ -451,17 +467,12 @@ s3grl_status s3grl_run(s3grl_context* ctx, const s3grl_plan* p, const float* X, 
   const float* Xa;
   int64_t lda;
   S3GRL_TRY(aligned_features(ctx, p->graph->num_nodes, X, ldx, F, &Xa, &lda));
+  if (ctx->profiling) S3GRL_TRY(resolve_pending_gather(ctx));
   S3GRL_TRY(record(ctx, 3));
   S3GRL_TRY(launch_gather(ctx, p->jobs, p->njobs, p->c_ids, p->c_coef, p->job_z, p->cfg.sign_k, Xa,
                           lda, F, rows));
   S3GRL_TRY(record(ctx, 4));
-  if (ctx->profiling) {
-    S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    float ms = 0;
-    S3GRL_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
-    ctx->timings[2] = ms;
-    ctx->timings[5] = 1.0;
-  }
+  if (ctx->profiling) ctx->gather_pending = true;
   return S3GRL_OK;
 }
 

@@ -71,6 +71,7 @@ struct s3grl_context {
   hipStream_t stream = nullptr;
   s3grl::Arena arena;
   bool profiling = false;
+  bool gather_pending = false;  // ev[3], ev[4] recorded but not yet read
   double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int64_t* d_scalars = nullptr;  // small device scratch for totals

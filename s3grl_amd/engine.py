@@ -204,14 +204,18 @@ class Engine:
         return x.to(device=self.device, dtype=torch.float32).contiguous()
 
     def links(self, link_index):
-        """[2, L] (the reference's layout) or [L, 2] -> int64 [L, 2] on the device."""
+        """`link_index` in the reference's layout, [2, L] (tuned_SIGN.py:147 iterates
+        `link_index.t().tolist()`), -> int64 [L, 2] on the device."""
         li = torch.as_tensor(link_index)
-        if li.dim() != 2:
-            raise ValueError("link_index must be 2-D")
-        if li.shape[0] == 2 and li.shape[1] != 2:
-            li = li.t()
-        elif li.shape[1] != 2:
+        if li.dim() != 2 or li.shape[0] != 2:
             raise ValueError("link_index must be [2, L]")
+        return li.t().to(device=self.device, dtype=torch.int64).contiguous()
+
+    def link_pairs(self, pairs):
+        """[L, 2] (src, dst) rows -> int64 [L, 2] on the device."""
+        li = torch.as_tensor(pairs)
+        if li.dim() != 2 or li.shape[1] != 2:
+            raise ValueError("pairs must be [L, 2]")
         return li.to(device=self.device, dtype=torch.int64).contiguous()
 
     # ---- the batched native entry ----------------------------------------------------------
@@ -260,7 +264,7 @@ class Engine:
         buf = (C.c_double * 8)()
         N.check(N.lib().s3grl_context_timings(self._ctx, buf), "s3grl_context_timings")
         keys = ["structure_ms", "propagate_ms", "gather_ms", "sop_setup_ms", "sop_run_ms",
-                "gather_launches"]
+                "gather_launches", "plans", "sop_runs"]
         return {k: float(buf[i]) for i, k in enumerate(keys)}
 
     def close(self):
