@@ -68,7 +68,7 @@ typedef struct s3grl_cfg {
   int32_t sign_k;    /* number of operators K >= 1 */
   int32_t strategy;  /* s3grl_strategy, PoS Plus only */
   int32_t directed;  /* must be 0 (A_csc == None in every non-ogbl-citation2 run) */
-  int32_t reserved[3];
+  int32_t reserved[3]; /* must be 0 */
 } s3grl_cfg;
 
 /* sizes a plan measured while extracting; the benchmark's algorithmic-bytes figure
@@ -122,9 +122,10 @@ s3grl_status s3grl_plan_get_stats(const s3grl_plan* p, s3grl_plan_stats* out);
 s3grl_status s3grl_plan_row_ptr(const s3grl_plan* p, int64_t* row_ptr);
 /* device int64 [total_rows] out: global node id of every output row */
 s3grl_status s3grl_plan_row_nodes(const s3grl_plan* p, int64_t* row_nodes);
-/* parity hook: node_ptr int64 [L+1] (always), then, when non-NULL, nodes int32 [Σn] in
- * ascending id per link and dists int8 [Σn] (hop distance from {src,dst}) — the quantities
- * reference utils.k_hop_subgraph returns as `nodes`, `dists` (utils.py:53-54,73-74). */
+/* parity hook: node_ptr int64 [L+1] (always), then, when non-NULL, nodes int32 [Σn] per link in
+ * hop-major order, ascending id inside a hop, and dists int8 [Σn] (hop distance from
+ * {src,dst}) — the quantities reference utils.k_hop_subgraph returns as `nodes`, `dists`
+ * (utils.py:53-54,73-74; its order inside a hop is CPython set order). */
 s3grl_status s3grl_plan_export_subgraphs(const s3grl_plan* p, int64_t* node_ptr, int32_t* nodes,
                                          int8_t* dists);
 

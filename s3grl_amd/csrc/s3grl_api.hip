@@ -73,6 +73,16 @@ __global__ void max_i32_kernel(const int32_t* __restrict__ in, int64_t n, int64_
   if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<long long*>(out), (long long)m);
 }
 
+// job_n[job_off[l] + p] = n_nodes[l]: every row pair of a link gets a list of the link's size
+__global__ void expand_job_n_kernel(const int32_t* __restrict__ n_nodes,
+                                    const int64_t* __restrict__ job_off, int64_t L,
+                                    int32_t* __restrict__ job_n) {
+  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L) return;
+  const int n = n_nodes[l];
+  for (int64_t j = job_off[l]; j < job_off[l + 1]; ++j) job_n[j] = n;
+}
+
 template <typename T>
 s3grl_status arena_alloc(s3grl_context* ctx, size_t count, T** out, std::vector<void*>* owned) {
   void* p = nullptr;
@@ -134,8 +144,8 @@ s3grl_status s3grl_context_create(int32_t device, void* stream, s3grl_context** 
   ctx->device = device;
   ctx->stream = static_cast<hipStream_t>(stream);
   for (auto& e : ctx->ev) S3GRL_HIP_TRY(hipEventCreate(&e));
-  S3GRL_HIP_TRY(hipMalloc(&ctx->d_scalars, 16 * sizeof(int64_t)));
-  S3GRL_HIP_TRY(hipHostMalloc(&ctx->h_scalars, 16 * sizeof(int64_t)));
+  S3GRL_HIP_TRY(hipMalloc(&ctx->d_scalars, 32 * sizeof(int64_t)));
+  S3GRL_HIP_TRY(hipHostMalloc(&ctx->h_scalars, 32 * sizeof(int64_t)));
   *out = ctx;
   return S3GRL_OK;
 }
@@ -229,8 +239,9 @@ s3grl_status s3grl_plan_destroy(s3grl_plan* p) {
 s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links,
                                int64_t L, const s3grl_cfg* cfg, s3grl_plan** out) {
   if (!ctx || !g || !cfg || !out || L < 0 || (L > 0 && !links)) return S3GRL_ERR_INVALID_ARGUMENT;
-  if (cfg->sign_k < 1 || cfg->sign_k > kMaxSignK || cfg->num_hops < 0) {
-    set_last_error("sign_k must be in 1..8 and num_hops >= 0");
+  if (cfg->sign_k < 1 || cfg->sign_k > kMaxSignK || cfg->num_hops < 0 ||
+      cfg->num_hops > kMaxLevels - 2) {
+    set_last_error("sign_k must be in 1..8 and num_hops in 0..30");
     return S3GRL_ERR_INVALID_ARGUMENT;
   }
   if (cfg->mode != S3GRL_MODE_POS && cfg->mode != S3GRL_MODE_POS_PLUS) {
@@ -251,10 +262,9 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
                    std::to_string(kMaxNodesLds));
     return S3GRL_ERR_GRAPH_TOO_LARGE;
   }
-  if (L >= (int64_t)INT32_MAX) return S3GRL_ERR_INVALID_ARGUMENT;
+  if (L >= (int64_t)INT32_MAX / kNumClasses) return S3GRL_ERR_INVALID_ARGUMENT;
   S3GRL_HIP_TRY(hipSetDevice(ctx->device));
   const int K = cfg->sign_k;
-  const bool keep = (cfg->reserved[0] & 1) != 0;
 
   std::unique_ptr<s3grl_plan, s3grl_status (*)(s3grl_plan*)> plan(new s3grl_plan(),
                                                                   s3grl_plan_destroy);
@@ -270,9 +280,11 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
 
   S3GRL_TRY(arena_alloc(ctx, (size_t)(L + 1), &plan->row_ptr, own));
   S3GRL_TRY(arena_alloc(ctx, (size_t)(L + 1), &plan->node_off, own));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)(L + 1), &plan->job_off, own));
   if (L == 0) {
     S3GRL_HIP_TRY(hipMemsetAsync(plan->row_ptr, 0, 8, ctx->stream));
     S3GRL_HIP_TRY(hipMemsetAsync(plan->node_off, 0, 8, ctx->stream));
+    S3GRL_HIP_TRY(hipMemsetAsync(plan->job_off, 0, 8, ctx->stream));
     *out = plan.release();
     return S3GRL_OK;
   }
@@ -280,29 +292,33 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   S3GRL_TRY(arena_alloc(ctx, (size_t)L * 2, &plan->links, own));
   S3GRL_HIP_TRY(hipMemcpyAsync(plan->links, links, (size_t)L * 16, hipMemcpyDeviceToDevice,
                                ctx->stream));
-  int32_t *vol, *cn_cap;
-  int64_t *edge_off, *cn_off = nullptr;
+  int32_t *n_rows, *n_jobs, *class_list, *class_count;
+  int64_t* scan_ws;
   S3GRL_TRY(arena_alloc(ctx, (size_t)L, &plan->n_nodes, own));
-  S3GRL_TRY(arena_alloc(ctx, (size_t)L, &vol, tr));
-  S3GRL_TRY(arena_alloc(ctx, (size_t)L, &cn_cap, tr));
-  S3GRL_TRY(arena_alloc(ctx, (size_t)(L + 1), &edge_off, tr));
-  if (plus) S3GRL_TRY(arena_alloc(ctx, (size_t)(L + 1), &cn_off, tr));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)L, &n_rows, tr));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)L, &n_jobs, tr));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)L * kNumClasses, &class_list, tr));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)scan_workspace_elems(L), &scan_ws, tr));
 
-  // d_scalars: [0] err flag (int32), [1] max n, [2] Σ edges, [3] Σ support
+  // d_scalars (int64 x 32): [0] err flag, [1] max n, [2] Σ edges, [3] Σ support, [4] Σ vol,
+  // [5] max R, [8..15] class counts (int32 x 16)
   int64_t* ds = ctx->d_scalars;
   int64_t* hs = ctx->h_scalars;
-  S3GRL_HIP_TRY(hipMemsetAsync(ds, 0, 16 * sizeof(int64_t), ctx->stream));
-  S3GRL_TRY(launch_count(ctx, g, plan->links, L, cfg->num_hops, plus ? 1 : 0, plan->n_nodes, vol,
-                         cn_cap, reinterpret_cast<int32_t*>(ds)));
-  S3GRL_TRY(launch_scan_i32_to_i64(ctx, plan->n_nodes, L, plan->node_off));
-  S3GRL_TRY(launch_scan_i32_to_i64(ctx, vol, L, edge_off));
-  if (plus) S3GRL_TRY(launch_scan_i32_to_i64(ctx, cn_cap, L, cn_off));
+  class_count = reinterpret_cast<int32_t*>(ds + 8);
+  S3GRL_HIP_TRY(hipMemsetAsync(ds, 0, 32 * sizeof(int64_t), ctx->stream));
+  S3GRL_TRY(launch_count(ctx, g, plan->links, L, cfg->num_hops, plus ? 1 : 0, plan->n_nodes, n_rows,
+                         n_jobs, reinterpret_cast<int32_t*>(ds), ds + 4));
+  S3GRL_TRY(launch_scan_i32_to_i64(ctx, plan->n_nodes, L, plan->node_off, scan_ws));
+  S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_rows, L, plan->row_ptr, scan_ws));
+  S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_jobs, L, plan->job_off, scan_ws));
   hipLaunchKernelGGL(max_i32_kernel, dim3(256), dim3(256), 0, ctx->stream, plan->n_nodes, L, ds + 1);
+  hipLaunchKernelGGL(max_i32_kernel, dim3(256), dim3(256), 0, ctx->stream, n_rows, L, ds + 5);
   S3GRL_HIP_TRY(hipGetLastError());
-  S3GRL_HIP_TRY(hipMemcpyAsync(hs, ds, 2 * 8, hipMemcpyDeviceToHost, ctx->stream));
-  S3GRL_HIP_TRY(hipMemcpyAsync(hs + 4, plan->node_off + L, 8, hipMemcpyDeviceToHost, ctx->stream));
-  S3GRL_HIP_TRY(hipMemcpyAsync(hs + 5, edge_off + L, 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (plus) S3GRL_HIP_TRY(hipMemcpyAsync(hs + 6, cn_off + L, 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_TRY(launch_classify(ctx, plan->n_nodes, L, class_count, class_list));
+  S3GRL_HIP_TRY(hipMemcpyAsync(hs, ds, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipMemcpyAsync(hs + 16, plan->node_off + L, 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipMemcpyAsync(hs + 17, plan->row_ptr + L, 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipMemcpyAsync(hs + 18, plan->job_off + L, 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
   const int err = (int)(hs[0] & 0xffffffff);
   if (err == 2) {
@@ -313,66 +329,46 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
     set_last_error("a link endpoint is outside [0, num_nodes)");
     return S3GRL_ERR_INVALID_ARGUMENT;
   }
-  const int64_t max_n = hs[1], tot_n = hs[4], tot_vol = hs[5], tot_cn = plus ? hs[6] : 0;
+  const int64_t max_n = hs[1], tot_vol = hs[4], max_R = hs[5];
+  const int64_t tot_n = hs[16], tot_rows = hs[17], njobs = hs[18];
+  int32_t class_count_host[kNumClasses + 1];
+  std::memcpy(class_count_host, hs + 8, sizeof(class_count_host));
   plan->stats.total_nodes = tot_n;
   plan->stats.total_volume = tot_vol;
   plan->stats.max_nodes = max_n;
-
-  int32_t *rowstart, *cnt, *lcsr, *cn_tmp = nullptr, *cn_count, *n_rows, *n_jobs;
-  float* dinv;
-  std::vector<void*>* nodes_owner = keep ? own : tr;
-  S3GRL_TRY(arena_alloc(ctx, (size_t)tot_n, &plan->nodes, nodes_owner));
-  if (keep) S3GRL_TRY(arena_alloc(ctx, (size_t)tot_n, &plan->dists, own));
-  S3GRL_TRY(arena_alloc(ctx, (size_t)tot_n, &rowstart, tr));
-  S3GRL_TRY(arena_alloc(ctx, (size_t)tot_n, &cnt, tr));
-  S3GRL_TRY(arena_alloc(ctx, (size_t)tot_n, &dinv, tr));
-  S3GRL_TRY(arena_alloc(ctx, (size_t)std::max<int64_t>(tot_vol, 1), &lcsr, tr));
-  if (plus) S3GRL_TRY(arena_alloc(ctx, (size_t)std::max<int64_t>(tot_cn, 1), &cn_tmp, tr));
-  S3GRL_TRY(arena_alloc(ctx, (size_t)L, &cn_count, tr));
-  S3GRL_TRY(arena_alloc(ctx, (size_t)L, &n_rows, tr));
-  S3GRL_TRY(arena_alloc(ctx, (size_t)L, &n_jobs, tr));
-  S3GRL_TRY(arena_alloc(ctx, (size_t)(L + 1), &plan->job_off, own));
-
-  S3GRL_TRY(launch_build(ctx, g, plan->links, L, cfg->num_hops, plus ? 1 : 0, plan->node_off,
-                         edge_off, cn_off, plan->nodes, keep ? plan->dists : nullptr, rowstart, cnt,
-                         dinv, lcsr, cn_tmp, cn_count, n_rows, n_jobs, ds + 2));
-  S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_rows, L, plan->row_ptr));
-  S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_jobs, L, plan->job_off));
-  int64_t tot_rows = 2 * L, njobs = L;
-  if (plus) {
-    S3GRL_HIP_TRY(hipMemcpyAsync(hs + 8, plan->row_ptr + L, 8, hipMemcpyDeviceToHost, ctx->stream));
-    S3GRL_HIP_TRY(hipMemcpyAsync(hs + 9, plan->job_off + L, 8, hipMemcpyDeviceToHost, ctx->stream));
-    S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    tot_rows = hs[8];
-    njobs = hs[9];
-  }
   plan->stats.total_rows = tot_rows;
   plan->stats.num_row_pairs = njobs;
   plan->njobs = njobs;
 
-  int32_t* job_n;
-  int64_t* coef_off;
-  S3GRL_TRY(arena_alloc(ctx, (size_t)njobs, &plan->jobs, own));
-  S3GRL_TRY(arena_alloc(ctx, (size_t)njobs, &job_n, tr));
-  S3GRL_TRY(arena_alloc(ctx, (size_t)(njobs + 1), &coef_off, tr));
-  S3GRL_TRY(arena_alloc(ctx, (size_t)tot_rows, &plan->row_nodes, own));
-  S3GRL_TRY(arena_alloc(ctx, (size_t)njobs * K * 2, &plan->job_z, own));
-  S3GRL_TRY(launch_make_jobs(ctx, plan->links, L, plan->node_off, plan->row_ptr, plan->job_off,
-                             cn_off, cn_tmp, plan->nodes, plan->n_nodes, K, plan->jobs,
-                             plan->row_nodes, job_n));
-  S3GRL_TRY(launch_scan_i32_to_i64(ctx, job_n, njobs, coef_off));
-  int64_t tot_coef = tot_n;  // PoS: one job per link
+  // coefficient lists: one per row pair, sized by the link's node count
+  const int64_t* coef_off = plan->node_off;   // PoS: job == link
+  int64_t tot_coef = tot_n;
   if (plus) {
-    S3GRL_HIP_TRY(hipMemcpyAsync(hs + 10, coef_off + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
+    int32_t* job_n;
+    int64_t* co;
+    S3GRL_TRY(arena_alloc(ctx, (size_t)scan_workspace_elems(njobs), &scan_ws, tr));
+    S3GRL_TRY(arena_alloc(ctx, (size_t)njobs, &job_n, tr));
+    S3GRL_TRY(arena_alloc(ctx, (size_t)(njobs + 1), &co, tr));
+    hipLaunchKernelGGL(expand_job_n_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0,
+                       ctx->stream, plan->n_nodes, plan->job_off, L, job_n);
+    S3GRL_HIP_TRY(hipGetLastError());
+    S3GRL_TRY(launch_scan_i32_to_i64(ctx, job_n, njobs, co, scan_ws));
+    S3GRL_HIP_TRY(hipMemcpyAsync(hs + 20, co + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
     S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    tot_coef = hs[10];
+    tot_coef = hs[20];
+    coef_off = co;
   }
-  S3GRL_TRY(arena_alloc(ctx, (size_t)std::max<int64_t>(tot_coef, 1), &plan->c_ids, own));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)std::max<int64_t>(tot_n, 1), &plan->c_ids, own));
   S3GRL_TRY(arena_alloc(ctx, (size_t)std::max<int64_t>(tot_coef, 1) * 2 * K, &plan->c_coef, own));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)njobs, &plan->jobs, own));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)njobs * K * 2, &plan->job_z, own));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)tot_rows, &plan->row_nodes, own));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)L * kMaxLevels, &plan->lvl, own));
   S3GRL_TRY(record(ctx, 1));
-  S3GRL_TRY(launch_propagate(ctx, plan->jobs, njobs, coef_off, plan->links, plan->node_off, edge_off,
-                             plan->nodes, rowstart, cnt, dinv, lcsr, K, max_n, plan->c_ids,
-                             plan->c_coef, plan->job_z, ds + 3));
+  S3GRL_TRY(launch_links(ctx, g, plan->links, L, class_list, class_count_host, cfg->num_hops,
+                         plus ? 1 : 0, (int)std::max<int64_t>(max_R - 2, 0) + 1, K, plan->node_off,
+                         plan->row_ptr, plan->job_off, coef_off, plan->c_ids, plan->c_coef,
+                         plan->jobs, plan->job_z, plan->row_nodes, plan->lvl, ds + 2, ds + 3));
   S3GRL_TRY(record(ctx, 2));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs + 2, ds + 2, 2 * 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -387,7 +383,6 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
     ctx->timings[1] += ms;
     ctx->timings[6] += 1.0;
   }
-  if (!keep) plan->nodes = nullptr;
   *out = plan.release();
   return S3GRL_OK;
 }
@@ -419,15 +414,9 @@ s3grl_status s3grl_plan_export_subgraphs(const s3grl_plan* p, int64_t* node_ptr,
   hipStream_t st = p->ctx->stream;
   S3GRL_HIP_TRY(hipMemcpyAsync(node_ptr, p->node_off, (size_t)(p->L + 1) * 8,
                                hipMemcpyDeviceToDevice, st));
-  if (nodes || dists) {
-    if (!p->nodes || !p->dists) {
-      set_last_error("plan was created without cfg.reserved[0] bit 0 (keep subgraphs)");
-      return S3GRL_ERR_INVALID_ARGUMENT;
-    }
-    const size_t n = (size_t)p->stats.total_nodes;
-    if (nodes && n) S3GRL_HIP_TRY(hipMemcpyAsync(nodes, p->nodes, n * 4, hipMemcpyDeviceToDevice, st));
-    if (dists && n) S3GRL_HIP_TRY(hipMemcpyAsync(dists, p->dists, n, hipMemcpyDeviceToDevice, st));
-  }
+  const size_t n = (size_t)p->stats.total_nodes;
+  if (nodes && n) S3GRL_HIP_TRY(hipMemcpyAsync(nodes, p->c_ids, n * 4, hipMemcpyDeviceToDevice, st));
+  if (dists && n) S3GRL_TRY(launch_dists(p->ctx, p->node_off, p->lvl, p->L, dists));
   return S3GRL_OK;
 }
 

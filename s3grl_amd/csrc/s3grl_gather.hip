@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_kernel(
   const int col0 = blockIdx.y * (CH * 256);  // first feature column of this wave's tile
   const Job job = jobs[jid];
   const int cnt = __builtin_amdgcn_readfirstlane(job.support);
-  const int32_t* __restrict__ ids = c_ids + job.coef_off;
+  const int32_t* __restrict__ ids = c_ids + job.ids_off;
   const float* __restrict__ cf = c_coef + job.coef_off * (2 * K);
 
   // this lane's columns: col0 + (lane + 64 c) * 4 .. +3

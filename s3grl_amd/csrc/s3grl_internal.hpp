@@ -34,17 +34,21 @@ void set_last_error(const std::string& msg);
 constexpr int kBlock = 256;            // threads per workgroup in the structure kernels
 constexpr int kMaxNodesLds = 327680;   // 4 bitmaps of N bits must fit 160 KiB of LDS
 constexpr int kMaxSignK = 8;
+constexpr int kMaxLevels = 32;         // BFS levels tracked per link (num_hops <= 30)
+// link_kernel keeps a whole subgraph on-chip; links are binned by node count into LDS classes
+constexpr int kNumClasses = 6;
+#define S3GRL_CLASS_BOUNDS {384, 1024, 2048, 3072, 4608, 6400}
+constexpr int kClassBoundHost[kNumClasses] = S3GRL_CLASS_BOUNDS;
 
 // One gather job = one pair of output rows of one link (rows 2p, 2p+1 of that link).
 struct Job {
-  int64_t coef_off;   // first entry of this job's (id, coefficient) list
+  int64_t coef_off;   // first entry of this job's coefficient list  [support][K][2]
+  int64_t ids_off;    // first entry of the link's node-id list (shared by its row pairs)
   int64_t out_row;    // index of the first output row
   int32_t link;       // link index
-  int32_t support;    // entries in the list after compaction
+  int32_t support;    // list entries this job reads (a hop-major prefix of the link's nodes)
   int32_t node_a;     // global id of row a
   int32_t node_b;     // global id of row b, or -1 when the pair has a single row
-  int32_t local_a;    // local ids inside the link's subgraph
-  int32_t local_b;
   int32_t z_a;        // label column of operator 0 (1 for src/dst)
   int32_t z_b;
 };
@@ -74,7 +78,7 @@ struct s3grl_context {
   bool gather_pending = false;  // ev[3], ev[4] recorded but not yet read
   double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  int64_t* d_scalars = nullptr;  // small device scratch for totals
+  int64_t* d_scalars = nullptr;  // small device scratch for totals (32 x int64)
   int64_t* h_scalars = nullptr;  // pinned host mirror
   float* x_padded = nullptr;     // 16-byte aligned copy of X when the caller's is not
   size_t x_padded_bytes = 0;
@@ -100,13 +104,12 @@ struct s3grl_plan {
   int64_t* node_off = nullptr;   // [L+1]
   int64_t* row_ptr = nullptr;    // [L+1]
   int64_t* job_off = nullptr;    // [L+1]
-  int32_t* nodes = nullptr;      // [Σn] global ids, ascending per link
-  int8_t* dists = nullptr;       // [Σn] hop distance
-  // per job
+  int32_t* lvl = nullptr;        // [L, kMaxLevels] cumulative node count per BFS level
+  int32_t* c_ids = nullptr;      // [Σn] subgraph nodes, hop-major, ascending id inside a hop
+  // per job (row pair)
   s3grl::Job* jobs = nullptr;    // [njobs]
   int64_t njobs = 0;
   float* job_z = nullptr;        // [njobs, K, 2] label column of operators 1..K
-  int32_t* c_ids = nullptr;      // [Σ_jobs n] global node ids with a non-zero coefficient
   float* c_coef = nullptr;       // [Σ_jobs n, K, 2]
   int64_t* row_nodes = nullptr;  // [ΣR]
   std::vector<void*> owned;      // everything above, for release
@@ -127,25 +130,21 @@ namespace s3grl {
 
 // structure.hip
 s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
-                          int hops, int plus, int32_t* n_nodes, int32_t* vol, int32_t* cn_cap,
-                          int32_t* err_flag);
-s3grl_status launch_scan_i32_to_i64(s3grl_context* ctx, const int32_t* in, int64_t n, int64_t* out);
-s3grl_status launch_build(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
-                          int hops, int plus, const int64_t* node_off, const int64_t* edge_off,
-                          const int64_t* cn_off, int32_t* nodes, int8_t* dists, int32_t* rowstart,
-                          int32_t* cnt, float* dinv, int32_t* lcsr, int32_t* cn_tmp,
-                          int32_t* cn_count, int32_t* n_rows, int32_t* n_jobs, int64_t* tot_edges);
-s3grl_status launch_make_jobs(s3grl_context* ctx, const int64_t* links, int64_t L,
-                              const int64_t* node_off, const int64_t* row_ptr,
-                              const int64_t* job_off, const int64_t* cn_off, const int32_t* cn_tmp,
-                              const int32_t* nodes, const int32_t* n_nodes, int K, Job* jobs,
-                              int64_t* row_nodes, int32_t* job_n);
-s3grl_status launch_propagate(s3grl_context* ctx, Job* jobs, int64_t njobs, const int64_t* coef_off,
-                              const int64_t* links, const int64_t* node_off,
-                              const int64_t* edge_off, const int32_t* nodes,
-                              const int32_t* rowstart, const int32_t* cnt, const float* dinv,
-                              const int32_t* lcsr, int K, int64_t max_nodes, int32_t* c_ids,
-                              float* c_coef, float* job_z, int64_t* tot_support);
+                          int hops, int plus, int32_t* n_nodes, int32_t* n_rows, int32_t* n_jobs,
+                          int32_t* err_flag, int64_t* tot_vol);
+int64_t scan_workspace_elems(int64_t n);
+s3grl_status launch_scan_i32_to_i64(s3grl_context* ctx, const int32_t* in, int64_t n, int64_t* out,
+                                    int64_t* workspace);
+s3grl_status launch_classify(s3grl_context* ctx, const int32_t* n_nodes, int64_t L,
+                             int32_t* class_count, int32_t* class_list);
+s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
+                          const int32_t* class_list, const int32_t* class_count_host, int hops,
+                          int plus, int cn_cap, int K, const int64_t* node_off,
+                          const int64_t* row_ptr, const int64_t* job_off, const int64_t* coef_off,
+                          int32_t* c_ids, float* c_coef, Job* jobs, float* job_z, int64_t* row_nodes,
+                          int32_t* lvl, int64_t* tot_edges, int64_t* tot_support);
+s3grl_status launch_dists(s3grl_context* ctx, const int64_t* node_off, const int32_t* lvl, int64_t L,
+                          int8_t* dists);
 // gather.hip
 s3grl_status launch_gather(s3grl_context* ctx, const Job* jobs, int64_t njobs, const int32_t* c_ids,
                            const float* c_coef, const float* job_z, int K, const float* X,

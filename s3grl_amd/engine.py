@@ -89,7 +89,7 @@ class Plan:
         return out
 
     def export_subgraphs(self):
-        """(node_ptr [L+1], nodes [Σn] ascending per link, dists [Σn]) — parity hook."""
+        """(node_ptr [L+1], nodes [Σn] hop-major / ascending id per hop, dists [Σn])."""
         dev = self.engine.device
         node_ptr = torch.empty(self.num_links + 1, dtype=torch.int64, device=dev)
         nodes = torch.empty(self.stats["total_nodes"], dtype=torch.int32, device=dev)
@@ -220,7 +220,7 @@ class Engine:
 
     # ---- the batched native entry ----------------------------------------------------------
     def plan(self, graph, links, *, mode="pos", num_hops=1, sign_k=3, strategy="intersection",
-             directed=False, keep_subgraphs=False):
+             directed=False):
         cfg = N.Cfg()
         cfg.mode = {"pos": N.MODE_POS, "pos_plus": N.MODE_POS_PLUS}[mode]
         cfg.num_hops = int(num_hops)
@@ -229,7 +229,6 @@ class Engine:
             raise NotImplementedError(f"check strat {strategy}")      # tuned_SIGN.py:235
         cfg.strategy = N.STRATEGY[strategy]
         cfg.directed = int(bool(directed))
-        cfg.reserved[0] = 1 if keep_subgraphs else 0
         return Plan(self, graph, links, cfg)
 
     def precompute(self, graph, x, links, *, mode="pos", num_hops=1, sign_k=3,
