@@ -68,7 +68,8 @@ typedef struct s3grl_cfg {
   int32_t sign_k;    /* number of operators K >= 1 */
   int32_t strategy;  /* s3grl_strategy, PoS Plus only */
   int32_t directed;  /* must be 0 (A_csc == None in every non-ogbl-citation2 run) */
-  int32_t reserved[3]; /* must be 0 */
+  int32_t reserved[3]; /* [0] bit 0: exact total_sub_edges even when sign_k < num_hops (one extra
+                          pass over the outer rows); others must be 0 */
 } s3grl_cfg;
 
 /* sizes a plan measured while extracting; the benchmark's algorithmic-bytes figure

@@ -1,5 +1,6 @@
 // extern "C" entry points of libs3grl_hip.so (see include/s3grl.h) and host orchestration.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -292,10 +293,11 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   S3GRL_TRY(arena_alloc(ctx, (size_t)L * 2, &plan->links, own));
   S3GRL_HIP_TRY(hipMemcpyAsync(plan->links, links, (size_t)L * 16, hipMemcpyDeviceToDevice,
                                ctx->stream));
-  int32_t *n_rows, *n_jobs, *class_list, *class_count;
+  int32_t *n_rows, *n_jobs, *p_nodes, *class_list, *class_count;
   int64_t* scan_ws;
   S3GRL_TRY(arena_alloc(ctx, (size_t)L, &plan->n_nodes, own));
   S3GRL_TRY(arena_alloc(ctx, (size_t)L, &n_rows, tr));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)L, &p_nodes, tr));
   S3GRL_TRY(arena_alloc(ctx, (size_t)L, &n_jobs, tr));
   S3GRL_TRY(arena_alloc(ctx, (size_t)L * kNumClasses, &class_list, tr));
   S3GRL_TRY(arena_alloc(ctx, (size_t)scan_workspace_elems(L), &scan_ws, tr));
@@ -306,15 +308,16 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   int64_t* hs = ctx->h_scalars;
   class_count = reinterpret_cast<int32_t*>(ds + 8);
   S3GRL_HIP_TRY(hipMemsetAsync(ds, 0, 32 * sizeof(int64_t), ctx->stream));
-  S3GRL_TRY(launch_count(ctx, g, plan->links, L, cfg->num_hops, plus ? 1 : 0, plan->n_nodes, n_rows,
-                         n_jobs, reinterpret_cast<int32_t*>(ds), ds + 4));
+  S3GRL_TRY(launch_count(ctx, g, plan->links, L, cfg->num_hops, plus ? 1 : 0, K, plan->n_nodes,
+                         p_nodes, n_rows, n_jobs, reinterpret_cast<int32_t*>(ds), ds + 4));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, plan->n_nodes, L, plan->node_off, scan_ws));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_rows, L, plan->row_ptr, scan_ws));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_jobs, L, plan->job_off, scan_ws));
   hipLaunchKernelGGL(max_i32_kernel, dim3(256), dim3(256), 0, ctx->stream, plan->n_nodes, L, ds + 1);
   hipLaunchKernelGGL(max_i32_kernel, dim3(256), dim3(256), 0, ctx->stream, n_rows, L, ds + 5);
   S3GRL_HIP_TRY(hipGetLastError());
-  S3GRL_TRY(launch_classify(ctx, plan->n_nodes, L, class_count, class_list));
+  // PoS has no common-neighbour rows: the LDS classes are known without a round trip
+  if (!plus) S3GRL_TRY(launch_classify(ctx, g, 1, K, plan->n_nodes, p_nodes, L, class_count, class_list));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs, ds, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs + 16, plan->node_off + L, 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs + 17, plan->row_ptr + L, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -331,8 +334,19 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   }
   const int64_t max_n = hs[1], tot_vol = hs[4], max_R = hs[5];
   const int64_t tot_n = hs[16], tot_rows = hs[17], njobs = hs[18];
+  const int cn_cap = (int)std::max<int64_t>(max_R - 2, 0) + 1;
+  if (plus) {
+    S3GRL_TRY(launch_classify(ctx, g, cn_cap, K, plan->n_nodes, p_nodes, L, class_count, class_list));
+    S3GRL_HIP_TRY(hipMemcpyAsync(hs + 8, ds + 8, 8 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
   int32_t class_count_host[kNumClasses + 1];
   std::memcpy(class_count_host, hs + 8, sizeof(class_count_host));
+  if (getenv("S3GRL_DEBUG")) {
+    fprintf(stderr, "[s3grl] L=%lld max_n=%lld classes:", (long long)L, (long long)max_n);
+    for (int c = 0; c <= kNumClasses; ++c) fprintf(stderr, " %d", class_count_host[c]);
+    fprintf(stderr, "\n");
+  }
   plan->stats.total_nodes = tot_n;
   plan->stats.total_volume = tot_vol;
   plan->stats.max_nodes = max_n;
@@ -366,7 +380,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   S3GRL_TRY(arena_alloc(ctx, (size_t)L * kMaxLevels, &plan->lvl, own));
   S3GRL_TRY(record(ctx, 1));
   S3GRL_TRY(launch_links(ctx, g, plan->links, L, class_list, class_count_host, cfg->num_hops,
-                         plus ? 1 : 0, (int)std::max<int64_t>(max_R - 2, 0) + 1, K, plan->node_off,
+                         plus ? 1 : 0, cn_cap, cfg->reserved[0] & 1, K, p_nodes, plan->node_off,
                          plan->row_ptr, plan->job_off, coef_off, plan->c_ids, plan->c_coef,
                          plan->jobs, plan->job_z, plan->row_nodes, plan->lvl, ds + 2, ds + 3));
   S3GRL_TRY(record(ctx, 2));

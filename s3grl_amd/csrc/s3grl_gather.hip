@@ -7,7 +7,9 @@
 // replaces the reference's `power_of_a[selected_rows] @ subg_x` (tuned_SIGN.py:175,185 and
 // :240,258) and its two dense copies of X_S (utils.py:83, tuned_SIGN.py:179).
 //
-// One wavefront owns one row pair.  The (node id, 2K coefficients) list is wave-uniform, so it
+// One wavefront owns one row pair.  The node-id list and the [K][support] coefficient rows are
+// wave-uniform, so they
+// are
 // is read through the scalar cache into SGPRs; each lane owns 4·CH feature columns and keeps
 // 2K·4·CH fp32 accumulators in VGPRs; every X row of the support is fetched ONCE per pair with
 // 16-byte loads (64 lanes × 16 B = one 1 KiB wave-instruction per 256 columns), UNROLL rows
@@ -34,7 +36,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_kernel(
   const Job job = jobs[jid];
   const int cnt = __builtin_amdgcn_readfirstlane(job.support);
   const int32_t* __restrict__ ids = c_ids + job.ids_off;
-  const float* __restrict__ cf = c_coef + job.coef_off * (2 * K);
+  // coefficients of this pair: [K][cnt] float2 (row a, row b), operator-major
+  const float2* __restrict__ cf = reinterpret_cast<const float2*>(c_coef) + job.coef_off;
 
   // this lane's columns: col0 + (lane + 64 c) * 4 .. +3
   int coff[CH];
@@ -64,29 +67,28 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_kernel(
         v[u][c] = cok[c] ? *reinterpret_cast<const float4_t*>(xr + coff[c]) : (float4_t)(0.f);
     }
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      const float* __restrict__ q = cf + (int64_t)(j + u) * (2 * K);
+    for (int i = 0; i < K; ++i) {
 #pragma unroll
-      for (int i = 0; i < K; ++i) {
-        const float ca = q[2 * i], cb = q[2 * i + 1];
+      for (int u = 0; u < kUnroll; ++u) {
+        const float2 q = cf[(int64_t)i * cnt + j + u];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-          acc[i][0][c] += ca * v[u][c];
-          acc[i][1][c] += cb * v[u][c];
+          acc[i][0][c] += q.x * v[u][c];
+          acc[i][1][c] += q.y * v[u][c];
         }
       }
     }
   }
   for (; j < cnt; ++j) {
     const float* __restrict__ xr = X + (int64_t)ids[j] * ldx;
-    const float* __restrict__ q = cf + (int64_t)j * (2 * K);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const float4_t v = cok[c] ? *reinterpret_cast<const float4_t*>(xr + coff[c]) : (float4_t)(0.f);
 #pragma unroll
       for (int i = 0; i < K; ++i) {
-        acc[i][0][c] += q[2 * i] * v;
-        acc[i][1][c] += q[2 * i + 1] * v;
+        const float2 q = cf[(int64_t)i * cnt + j];
+        acc[i][0][c] += q.x * v;
+        acc[i][1][c] += q.y * v;
       }
     }
   }

@@ -35,14 +35,14 @@ constexpr int kBlock = 256;            // threads per workgroup in the structure
 constexpr int kMaxNodesLds = 327680;   // 4 bitmaps of N bits must fit 160 KiB of LDS
 constexpr int kMaxSignK = 8;
 constexpr int kMaxLevels = 32;         // BFS levels tracked per link (num_hops <= 30)
-// link_kernel keeps a whole subgraph on-chip; links are binned by node count into LDS classes
+// link_kernel keeps a whole subgraph on-chip; links are binned by LDS need into classes
 constexpr int kNumClasses = 6;
-#define S3GRL_CLASS_BOUNDS {384, 1024, 2048, 3072, 4608, 6400}
-constexpr int kClassBoundHost[kNumClasses] = S3GRL_CLASS_BOUNDS;
+// variable LDS bytes per link (list + state on the propagation prefix), upper bound per class
+#define S3GRL_CLASS_BOUNDS {6144, 12288, 24576, 49152, 98304, 163840}
 
 // One gather job = one pair of output rows of one link (rows 2p, 2p+1 of that link).
 struct Job {
-  int64_t coef_off;   // first entry of this job's coefficient list  [support][K][2]
+  int64_t coef_off;   // first float2 of this job's coefficients, laid out [K][support]
   int64_t ids_off;    // first entry of the link's node-id list (shared by its row pairs)
   int64_t out_row;    // index of the first output row
   int32_t link;       // link index
@@ -130,19 +130,21 @@ namespace s3grl {
 
 // structure.hip
 s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
-                          int hops, int plus, int32_t* n_nodes, int32_t* n_rows, int32_t* n_jobs,
-                          int32_t* err_flag, int64_t* tot_vol);
+                          int hops, int plus, int K, int32_t* n_nodes, int32_t* p_nodes,
+                          int32_t* n_rows, int32_t* n_jobs, int32_t* err_flag, int64_t* tot_vol);
 int64_t scan_workspace_elems(int64_t n);
 s3grl_status launch_scan_i32_to_i64(s3grl_context* ctx, const int32_t* in, int64_t n, int64_t* out,
                                     int64_t* workspace);
-s3grl_status launch_classify(s3grl_context* ctx, const int32_t* n_nodes, int64_t L,
+s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_cap, int K,
+                             const int32_t* n_nodes, const int32_t* p_nodes, int64_t L,
                              int32_t* class_count, int32_t* class_list);
 s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                           const int32_t* class_list, const int32_t* class_count_host, int hops,
-                          int plus, int cn_cap, int K, const int64_t* node_off,
-                          const int64_t* row_ptr, const int64_t* job_off, const int64_t* coef_off,
-                          int32_t* c_ids, float* c_coef, Job* jobs, float* job_z, int64_t* row_nodes,
-                          int32_t* lvl, int64_t* tot_edges, int64_t* tot_support);
+                          int plus, int cn_cap, int full_stats, int K, const int32_t* p_nodes,
+                          const int64_t* node_off, const int64_t* row_ptr, const int64_t* job_off,
+                          const int64_t* coef_off, int32_t* c_ids, float* c_coef, Job* jobs,
+                          float* job_z, int64_t* row_nodes, int32_t* lvl, int64_t* tot_edges,
+                          int64_t* tot_support);
 s3grl_status launch_dists(s3grl_context* ctx, const int64_t* node_off, const int32_t* lvl, int64_t L,
                           int8_t* dists);
 // gather.hip

@@ -117,11 +117,13 @@ __device__ __forceinline__ int common_neighbours(const int32_t* __restrict__ ind
 // ---------------------------------------------------------------------------------------
 // count: level-synchronous BFS on LDS bitmaps, one thread per frontier word (reference
 // utils.py:53-74: `fringe = neighbors(fringe, A) - visited`, early break on an empty fringe).
+// Outputs per link: n = |S|, R rows, and p = |P|, the hop-major prefix of S that can carry a
+// non-zero entry of r_{K-1}: the only nodes link_kernel keeps propagation state for.
 __global__ __launch_bounds__(kBlock) void count_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int N, int W,
-    const int64_t* __restrict__ links, int hops, int plus, int32_t* __restrict__ n_nodes,
-    int32_t* __restrict__ n_rows, int32_t* __restrict__ n_jobs, int32_t* __restrict__ err_flag,
-    unsigned long long* __restrict__ tot_vol) {
+    const int64_t* __restrict__ links, int hops, int plus, int K, int32_t* __restrict__ n_nodes,
+    int32_t* __restrict__ p_nodes, int32_t* __restrict__ n_rows, int32_t* __restrict__ n_jobs,
+    int32_t* __restrict__ err_flag, unsigned long long* __restrict__ tot_vol) {
   extern __shared__ uint32_t smem[];
   uint32_t* vis = smem;
   uint32_t* cur = smem + W;
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
     if (tid == 0) {
       atomicMax(err_flag, s64 == d64 ? 2 : 1);
       n_nodes[l] = 0;
+      p_nodes[l] = 0;
       n_rows[l] = 0;
       n_jobs[l] = 0;
     }
@@ -153,6 +156,8 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
     atomicOr(&cur[dst >> 5], 1u << (dst & 31));
   }
   __syncthreads();
+  // cum_a / cum_b: nodes within K-1 / K hops (what P is for a row at hop 0 / hop 1)
+  int n = 2, cum_a = 2, cum_b = 2;
   for (int d = 1; d <= hops; ++d) {
     for (int t = tid; t < W; t += kBlock) {
       uint32_t w = cur[t];
@@ -170,19 +175,22 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
       }
     }
     __syncthreads();
-    int any = 0;
+    int added = 0;
     for (int t = tid; t < W; t += kBlock) {
       const uint32_t c = nxt[t];
       cur[t] = c;
       nxt[t] = 0;
-      any |= (c != 0);
+      added += __popc(c);
     }
-    if (!__syncthreads_or(any)) break;
+    added = block_sum<kBlock>(added, sh);
+    if (added == 0) break;
+    n += added;
+    if (d <= K - 1) cum_a = n;
+    if (d <= K) cum_b = n;
   }
-  int n = 0, dv = 0;
+  int dv = 0;
   for (int t = tid; t < W; t += kBlock) {
     uint32_t w = vis[t];
-    n += __popc(w);
     while (w) {
       const int b = __ffs(w) - 1;
       w &= w - 1;
@@ -190,12 +198,12 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
       dv += indptr[v + 1] - indptr[v];
     }
   }
-  n = block_sum<kBlock>(n, sh);
   dv = block_sum<kBlock>(dv, sh);
   int R = 2;
   if (plus && wave_id() == 0) R = 2 + common_neighbours(indptr, indices, vis, src, dst, nullptr);
   if (tid == 0) {
     n_nodes[l] = n;
+    p_nodes[l] = R > 2 ? cum_b : cum_a;
     n_rows[l] = R;
     n_jobs[l] = (R + 1) / 2;
     atomicAdd(tot_vol, (unsigned long long)dv);
@@ -264,62 +272,85 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restri
 }
 
 // ---------------------------------------------------------------------------------------
-__global__ void classify_kernel(const int32_t* __restrict__ n_nodes, int64_t L,
+// LDS bytes link_kernel needs beyond its fixed part: list[n] + dinvP[p] + two float2 state
+// arrays [p] (+ alignment slack).
+__host__ __device__ __forceinline__ int link_lds_need(int n, int p) { return 4 * n + 20 * p + 16; }
+
+struct ClassBounds {
+  int b[kNumClasses];
+};
+
+__global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
+                                const int32_t* __restrict__ p_nodes, int64_t L, ClassBounds bound,
                                 int32_t* __restrict__ class_count, int32_t* __restrict__ class_list) {
   const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= L) return;
-  const int n = n_nodes[l];
-  if (n == 0) return;
-  const int bound[kNumClasses] = S3GRL_CLASS_BOUNDS;
+  const int n = l < L ? n_nodes[l] : 0;
+  const int need = l < L ? link_lds_need(n, p_nodes[l]) : 0;
   int c = 0;
 #pragma unroll
-  for (int k = 0; k < kNumClasses; ++k) c += n > bound[k] ? 1 : 0;
-  if (c == kNumClasses) {
-    atomicAdd(&class_count[kNumClasses], 1);  // too large for LDS: reported by the host
-    return;
+  for (int k = 0; k < kNumClasses; ++k) c += need > bound.b[k] ? 1 : 0;
+  if (n == 0) c = -1;
+  // one atomic per (wave, class) instead of one per link
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k <= kNumClasses; ++k) {
+    const unsigned long long m = __ballot(c == k);
+    if (m == 0) continue;
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&class_count[k], __popcll(m));
+    base = __shfl(base, leader);
+    if (c == k && k < kNumClasses)
+      class_list[(int64_t)k * L + base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)l;
   }
-  const int slot = atomicAdd(&class_count[c], 1);
-  class_list[(int64_t)c * L + slot] = (int32_t)l;
 }
 
 // ---------------------------------------------------------------------------------------
-// The fused per-link kernel.  LDS layout (dynamic, 16-byte aligned base):
-//   vis[W] nxt[W] wpre[W]            bitmaps / rank prefix             (uint32)
-//   list[nmax]                       S in hop-major, ascending-id order (global ids)
-//   dinv[nmax]                       D^-1/2 of the masked induced subgraph, by local rank
-//   cur[nmax], nxs[nmax]             float2 propagation state s_i = dinv·r_i (rows a, b)
-//   cn[cn_cap]                       common neighbours (global ids)
-//   misc: lvl_end[kMaxLevels], z[2][K][2], scan scratch
-template <int T, int K>
+// The fused per-link kernel.  LDS layout (dynamic, 16-byte aligned base), n = |S|, p = |P|:
+//   vis[W]                 S as a bitmap over global ids
+//   inP[W]                 P as a bitmap (the BFS's next-frontier bitmap until the BFS is done)
+//   wpreP[W]               word-level popcount prefix of inP: local id of u ∈ P = rank in P
+//   cn[cn_cap] lvl_end[kMaxLevels] zbuf[4K] sh[32]
+//   list[n]                S in hop-major order, ascending id inside a hop (global ids)
+//   dinvP[p]               D^-1/2 of the masked induced subgraph for the nodes of P
+//   cur[p], nxs[p]         float2 propagation state s_i = dinv·r_i (rows a, b of the pair)
+// P = the hop-major prefix of S that r_{K-1} can reach; only the LAST operator touches the
+// rest of S, and it needs no state there: its degree and its sum come out of the same pass.
+template <int T, int K, int G>
 __global__ __launch_bounds__(T) void link_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int W,
     const int64_t* __restrict__ links, const int32_t* __restrict__ class_list, int hops, int plus,
-    int nmax, int cn_cap, const int64_t* __restrict__ node_off, const int64_t* __restrict__ row_ptr,
+    int cn_cap, int full_stats, const int32_t* __restrict__ p_nodes,
+    const int64_t* __restrict__ node_off, const int64_t* __restrict__ row_ptr,
     const int64_t* __restrict__ job_off, const int64_t* __restrict__ coef_off,
     int32_t* __restrict__ c_ids, float* __restrict__ c_coef, Job* __restrict__ jobs,
     float* __restrict__ job_z, int64_t* __restrict__ row_nodes, int32_t* __restrict__ lvl_out,
     unsigned long long* __restrict__ tot_edges, unsigned long long* __restrict__ tot_support) {
   extern __shared__ uint32_t smem[];
+  const int tid = threadIdx.x;
+  const int l = class_list[blockIdx.x];
+  const int64_t noff = node_off[l];
+  const int n_alloc = (int)(node_off[l + 1] - noff);
+  const int p_alloc = p_nodes[l];
+
   uint32_t* vis = smem;
-  uint32_t* nxt = smem + W;
-  uint32_t* wpre = smem + 2 * W;
-  int32_t* list = reinterpret_cast<int32_t*>(smem + 3 * W);
-  float* dinv = reinterpret_cast<float*>(list + nmax);
-  // float2 arrays need 8-byte alignment: 3W + 2 nmax words may be odd
-  float2* cur = reinterpret_cast<float2*>(smem + ((3 * W + 2 * nmax + 1) & ~1));
-  float2* nxs = cur + nmax;
-  int32_t* cn = reinterpret_cast<int32_t*>(nxs + nmax);
+  uint32_t* inP = smem + W;
+  uint32_t* wpreP = smem + 2 * W;
+  int32_t* cn = reinterpret_cast<int32_t*>(smem + 3 * W);
   int* lvl_end = cn + cn_cap;
   float* zbuf = reinterpret_cast<float*>(lvl_end + kMaxLevels);  // [2 (src,dst)][K][2 (rows)]
   int* sh = reinterpret_cast<int*>(zbuf + 4 * K);
+  int32_t* list = sh + 32;
+  float* dinvP = reinterpret_cast<float*>(list + n_alloc);
+  const int fixed_words = 3 * W + cn_cap + kMaxLevels + 4 * K + 32;
+  float2* cur = reinterpret_cast<float2*>(smem + ((fixed_words + n_alloc + p_alloc + 1) & ~1));
+  float2* nxs = cur + p_alloc;
 
-  const int tid = threadIdx.x;
-  const int l = class_list[blockIdx.x];
   const int src = (int)links[2 * (int64_t)l], dst = (int)links[2 * (int64_t)l + 1];
-  const int64_t noff = node_off[l];
-  const int g = tid & 7;
+  const int g = tid & (G - 1);
 
-  // ---- BFS: frontier = a segment of `list`, 8 lanes per frontier node -------------------
+  // ---- BFS: frontier = a segment of `list`, G lanes per frontier node -------------------
+  uint32_t* nxt = inP;
   for (int t = tid; t < W; t += T) {
     vis[t] = 0;
     nxt[t] = 0;
@@ -335,13 +366,13 @@ __global__ __launch_bounds__(T) void link_kernel(
   __syncthreads();
   int n = 2, nlev = 1;  // levels 0..nlev-1 are complete
   for (int d = 1; d <= hops; ++d) {
-    const int f0 = d >= 2 ? lvl_end[min(d, kMaxLevels) - 2] : 0, f1 = n;
-    for (int base = f0; base < f1; base += T / 8) {
-      const int t = base + (tid >> 3);
+    const int f0 = d >= 2 ? lvl_end[d - 2] : 0, f1 = n;
+    for (int base = f0; base < f1; base += T / G) {
+      const int t = base + tid / G;
       if (t < f1) {
         const int v = list[t];
         const int e1 = indptr[v + 1];
-        for (int c = indptr[v] + g; c < e1; c += 8) {
+        for (int c = indptr[v] + g; c < e1; c += G) {
           const int u = indices[c];
           const uint32_t m = 1u << (u & 31);
           const uint32_t old = atomicOr(&vis[u >> 5], m);
@@ -367,136 +398,139 @@ __global__ __launch_bounds__(T) void link_kernel(
     }
     if (added == 0) break;  // uniform: `added` is a block-wide total
     n += added;
-    if (d < kMaxLevels) {
-      if (tid == 0) lvl_end[d] = n;
-      nlev = d + 1;
-    } else if (tid == 0) {
-      lvl_end[kMaxLevels - 1] = n;  // deeper levels are merged into the last one
-    }
+    if (tid == 0) lvl_end[d] = n;
+    nlev = d + 1;
     __syncthreads();
   }
   __syncthreads();
 
-  // ---- local ids: rank in ascending global id ------------------------------------------
+  // ---- rows of this link ----------------------------------------------------------------
+  const int64_t rp = row_ptr[l];
+  const int R = (int)(row_ptr[l + 1] - rp);
+  const int max_row_hop = R > 2 ? 1 : 0;  // common neighbours sit at hop 1
+  const int p = lvl_end[min(K - 1 + max_row_hop, nlev - 1)];
+
+  // ---- P as bitmap + rank prefix; node list out -------------------------------------------
+  for (int t = tid; t < p; t += T) {
+    const int v = list[t];
+    atomicOr(&inP[v >> 5], 1u << (v & 31));
+  }
+  for (int t = tid; t < n; t += T) c_ids[noff + t] = list[t];
+  if (plus && wave_id() == 0) common_neighbours(indptr, indices, vis, src, dst, cn);
+  __syncthreads();
   {
     int carry = 0;
     for (int base = 0; base < W; base += T) {
       const int t = base + tid;
-      const int pc = t < W ? __popc(vis[t]) : 0;
+      const int pc = t < W ? __popc(inP[t]) : 0;
       int total;
       const int ex = block_excl_scan<T>(pc, sh, total);
-      if (t < W) wpre[t] = carry + ex;
+      if (t < W) wpreP[t] = carry + ex;
       carry += total;
     }
   }
   __syncthreads();
-  const int srcl = rank_of(vis, wpre, src), dstl = rank_of(vis, wpre, dst);
+  if (tid == 0)
+    for (int d = 0; d < kMaxLevels; ++d)
+      lvl_out[(int64_t)l * kMaxLevels + d] = d < nlev ? lvl_end[d] : n;
+  for (int r = tid; r < R; r += T) row_nodes[rp + r] = r == 0 ? src : (r == 1 ? dst : cn[r - 2]);
 
-  // ---- degrees of the masked induced subgraph -> D^-1/2 (inf -> 0) ---------------------
+  // ---- D^-1/2 on P (inf -> 0) -------------------------------------------------------------
   // reference tuned_SIGN.py:153-161: structure only, target link removed, no self-loops added
   int edges_local = 0;
-  for (int base = 0; base < n; base += T / 8) {
-    const int t = base + (tid >> 3);
-    if (t < n) {
+  for (int base = 0; base < p; base += T / G) {
+    const int t = base + tid / G;
+    if (t < p) {
       const int v = list[t];
       const int e1 = indptr[v + 1];
       const bool is_src = v == src, is_dst = v == dst;
       int cnt = 0;
-      for (int c = indptr[v] + g; c < e1; c += 8) {
+      for (int c = indptr[v] + g; c < e1; c += G) {
         const int u = indices[c];
         cnt += (test_bit(vis, u) && !((is_src && u == dst) || (is_dst && u == src))) ? 1 : 0;
       }
-      cnt += __shfl_xor(cnt, 4);
-      cnt += __shfl_xor(cnt, 2);
-      cnt += __shfl_xor(cnt, 1);
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
       if (g == 0) {
-        dinv[rank_of(vis, wpre, v)] = cnt > 0 ? 1.0f / sqrtf((float)cnt) : 0.0f;
+        dinvP[rank_of(inP, wpreP, v)] = cnt > 0 ? 1.0f / sqrtf((float)cnt) : 0.0f;
         edges_local += cnt;
-        c_ids[noff + t] = v;
       }
     }
   }
-  edges_local = block_sum<T>(edges_local, sh);
-
-  // ---- rows of this link ----------------------------------------------------------------
-  const int64_t rp = row_ptr[l];
-  const int R = (int)(row_ptr[l + 1] - rp);
-  if (plus && wave_id() == 0) common_neighbours(indptr, indices, vis, src, dst, cn);
-  if (tid == 0) {
-    atomicAdd(tot_edges, (unsigned long long)edges_local);
-    for (int d = 0; d < kMaxLevels; ++d)
-      lvl_out[(int64_t)l * kMaxLevels + d] = d < nlev ? lvl_end[d] : n;
-  }
   __syncthreads();
-  for (int r = tid; r < R; r += T) row_nodes[rp + r] = r == 0 ? src : (r == 1 ? dst : cn[r - 2]);
 
   // ---- per row pair: K pull steps --------------------------------------------------------
-  // State s_i[w] = dinv[w]·r_i[w] (float2: rows a and b):
+  // State s_i[u] = dinv[u]·r_i[u] for u ∈ P (float2: rows a and b of the pair):
   //   r_i[w] = dinv[w] · Σ_{u ∈ N_S(w)} s_{i-1}[u]            (Â symmetric: pull == r_{i-1}·Â)
-  // Each r_i[w] is summed in the stored order of w's row and reduced over 8 lanes by a fixed
+  // Each r_i[w] is summed in the stored order of w's row and reduced over G lanes by a fixed
   // xor tree: bit-reproducible.  All terms are >= 0: no cancellation.  A walk of length i
-  // from a row at hop h_r stays within hop h_r + i, so step i only visits that list prefix.
+  // from a row at hop h_r stays within hop h_r + i, so step i only visits that list prefix;
+  // the last step visits everything it can reach and derives dinv[w] from the same pass.
   const int npairs = (R + 1) / 2;
-  for (int p = 0; p < npairs; ++p) {
-    const int64_t jid = job_off[l] + p;
+  for (int pr = 0; pr < npairs; ++pr) {
+    const int64_t jid = job_off[l] + pr;
     const int64_t coff = coef_off[jid];
-    const int node_a = p == 0 ? src : cn[2 * p - 2];
-    const int node_b = p == 0 ? dst : (2 * p + 1 < R ? cn[2 * p - 1] : -1);
-    const int la = rank_of(vis, wpre, node_a);
-    const int lb = node_b >= 0 ? rank_of(vis, wpre, node_b) : -1;
-    const int row_hop = p == 0 ? 0 : 1;
+    const int node_a = pr == 0 ? src : cn[2 * pr - 2];
+    const int node_b = pr == 0 ? dst : (2 * pr + 1 < R ? cn[2 * pr - 1] : -1);
+    const int row_hop = pr == 0 ? 0 : 1;
     const int support = lvl_end[min(K + row_hop, nlev - 1)];
+    // with full_stats the last pass also walks the rows beyond its reach, to count edges
+    const int last_rows = (pr == 0 && full_stats) ? n : support;
 
-    for (int w = tid; w < n; w += T) {
+    for (int w = tid; w < p; w += T) {
       cur[w] = make_float2(0.f, 0.f);
       nxs[w] = make_float2(0.f, 0.f);
     }
     if (tid < 4 * K) zbuf[tid] = 0.f;
     __syncthreads();
     if (tid == 0) {
-      cur[la].x = dinv[la];
-      if (lb >= 0) cur[lb].y = dinv[lb];
+      const int la = rank_of(inP, wpreP, node_a);
+      cur[la].x = dinvP[la];
+      if (node_b >= 0) {
+        const int lb = rank_of(inP, wpreP, node_b);
+        cur[lb].y = dinvP[lb];
+      }
     }
     __syncthreads();
 
     float2* s_in = cur;
     float2* s_out = nxs;
-    float* coef = c_coef + coff * (2 * K);
+    float2* coef = reinterpret_cast<float2*>(c_coef) + coff * K;  // [K][support] float2
 #pragma unroll 1
-    for (int i = 0; i < K; ++i) {
-      const int limit = lvl_end[min(i + 1 + row_hop, nlev - 1)];
-      for (int base = 0; base < support; base += T / 8) {
-        const int t = base + (tid >> 3);
+    for (int i = 0; i < K - 1; ++i) {
+      const int limit = lvl_end[min(i + 1 + row_hop, nlev - 1)];  // <= p
+      for (int base = 0; base < support; base += T / G) {
+        const int t = base + tid / G;
         if (t < limit) {
           const int v = list[t];
-          const int w = rank_of(vis, wpre, v);
           const int e1 = indptr[v + 1];
           const bool is_src = v == src, is_dst = v == dst;
           float sx = 0.f, sy = 0.f;
-          for (int c = indptr[v] + g; c < e1; c += 8) {
+          for (int c = indptr[v] + g; c < e1; c += G) {
             const int u = indices[c];
-            if (test_bit(vis, u) && !((is_src && u == dst) || (is_dst && u == src))) {
-              const float2 sv = s_in[rank_of(vis, wpre, u)];
+            if (test_bit(inP, u) && !((is_src && u == dst) || (is_dst && u == src))) {
+              const float2 sv = s_in[rank_of(inP, wpreP, u)];
               sx += sv.x;
               sy += sv.y;
             }
           }
 #pragma unroll
-          for (int o = 4; o > 0; o >>= 1) {
+          for (int o = G / 2; o > 0; o >>= 1) {
             sx += __shfl_xor(sx, o);
             sy += __shfl_xor(sy, o);
           }
           if (g == 0) {
-            const float dw = dinv[w];
+            const int w = rank_of(inP, wpreP, v);
+            const float dw = dinvP[w];
             const float rx = dw * sx, ry = dw * sy;
             s_out[w] = make_float2(dw * rx, dw * ry);
-            *reinterpret_cast<float2*>(coef + ((int64_t)t * K + i) * 2) = make_float2(rx, ry);
+            coef[(int64_t)i * support + t] = make_float2(rx, ry);
             // label column of operator i+1: Σ_w r[w] z_w = r[src] + r[dst]  (tuned_SIGN.py:177-185)
-            if (w == srcl) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
-            if (w == dstl) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
+            if (is_src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
+            if (is_dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
           }
         } else if (t < support && g == 0) {
-          *reinterpret_cast<float2*>(coef + ((int64_t)t * K + i) * 2) = make_float2(0.f, 0.f);
+          coef[(int64_t)i * support + t] = make_float2(0.f, 0.f);
         }
       }
       __syncthreads();
@@ -504,15 +538,59 @@ __global__ __launch_bounds__(T) void link_kernel(
       s_in = s_out;
       s_out = tmp;
     }
+    {  // last operator: degree and sum of every reachable row in one pass over its CSR row
+      const int i = K - 1;
+      int edges_pass = 0;
+      for (int base = 0; base < last_rows; base += T / G) {
+        const int t = base + tid / G;
+        if (t < last_rows) {
+          const int v = list[t];
+          const int e1 = indptr[v + 1];
+          const bool is_src = v == src, is_dst = v == dst;
+          float sx = 0.f, sy = 0.f;
+          int cnt = 0;
+          for (int c = indptr[v] + g; c < e1; c += G) {
+            const int u = indices[c];
+            const uint32_t bit = 1u << (u & 31);
+            if ((vis[u >> 5] & bit) && !((is_src && u == dst) || (is_dst && u == src))) {
+              ++cnt;
+              if (inP[u >> 5] & bit) {
+                const float2 sv = s_in[rank_of(inP, wpreP, u)];
+                sx += sv.x;
+                sy += sv.y;
+              }
+            }
+          }
+#pragma unroll
+          for (int o = G / 2; o > 0; o >>= 1) {
+            cnt += __shfl_xor(cnt, o);
+            sx += __shfl_xor(sx, o);
+            sy += __shfl_xor(sy, o);
+          }
+          if (g == 0) {
+            edges_pass += cnt;
+            if (t < support) {
+              const float dw = cnt > 0 ? 1.0f / sqrtf((float)cnt) : 0.0f;
+              const float rx = dw * sx, ry = dw * sy;
+              coef[(int64_t)i * support + t] = make_float2(rx, ry);
+              if (is_src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
+              if (is_dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
+            }
+          }
+        }
+      }
+      if (pr == 0) edges_local = (last_rows == n) ? edges_pass : edges_local;
+      __syncthreads();
+    }
     if (tid < 2 * K) {
       const int i = tid >> 1, r = tid & 1;
       job_z[(jid * K + i) * 2 + r] = zbuf[(0 * K + i) * 2 + r] + zbuf[(1 * K + i) * 2 + r];
     }
     if (tid == 0) {
       Job j;
-      j.coef_off = coff;
+      j.coef_off = coff * K;
       j.ids_off = noff;
-      j.out_row = rp + 2 * p;
+      j.out_row = rp + 2 * pr;
       j.link = l;
       j.support = support;
       j.node_a = node_a;
@@ -524,6 +602,10 @@ __global__ __launch_bounds__(T) void link_kernel(
     }
     __syncthreads();
   }
+  // edges of the masked induced subgraph: exact when the last pass of pair 0 covered all of S
+  // (always with full_stats; otherwise whenever K >= num_hops), else the edges of P's rows
+  edges_local = block_sum<T>(edges_local, sh);
+  if (tid == 0) atomicAdd(tot_edges, (unsigned long long)edges_local);
 }
 
 // hop distance of every exported node from the per-link level ends
@@ -546,16 +628,16 @@ __global__ void dists_kernel(const int64_t* __restrict__ node_off, const int32_t
 static inline int words_for(int64_t N) { return (int)((N + 31) / 32); }
 
 s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
-                          int hops, int plus, int32_t* n_nodes, int32_t* n_rows, int32_t* n_jobs,
-                          int32_t* err_flag, int64_t* tot_vol) {
+                          int hops, int plus, int K, int32_t* n_nodes, int32_t* p_nodes,
+                          int32_t* n_rows, int32_t* n_jobs, int32_t* err_flag, int64_t* tot_vol) {
   if (L == 0) return S3GRL_OK;
   const int W = words_for(g->num_nodes);
   const size_t lds = (size_t)(3 * W + 8) * 4;
   S3GRL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(count_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(count_kernel, dim3((unsigned)L), dim3(kBlock), lds, ctx->stream, g->indptr,
-                     g->indices, (int)g->num_nodes, W, links, hops, plus, n_nodes, n_rows, n_jobs,
-                     err_flag, reinterpret_cast<unsigned long long*>(tot_vol));
+                     g->indices, (int)g->num_nodes, W, links, hops, plus, K, n_nodes, p_nodes, n_rows,
+                     n_jobs, err_flag, reinterpret_cast<unsigned long long*>(tot_vol));
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -578,11 +660,34 @@ s3grl_status launch_scan_i32_to_i64(s3grl_context* ctx, const int32_t* in, int64
   return S3GRL_OK;
 }
 
-s3grl_status launch_classify(s3grl_context* ctx, const int32_t* n_nodes, int64_t L,
+// fixed part of link_kernel's LDS: 3 bitmaps + cn + lvl_end + zbuf + scan scratch
+static inline int link_fixed_words(int64_t num_nodes, int cn_cap, int K) {
+  return 3 * words_for(num_nodes) + cn_cap + kMaxLevels + 4 * K + 32;
+}
+
+// class c holds the links whose variable LDS need is <= bound[c] bytes; the last bound is
+// whatever the 160 KiB of a CU leave after the fixed part
+static ClassBounds class_bounds(int64_t num_nodes, int cn_cap, int K) {
+  static const int nominal[kNumClasses] = S3GRL_CLASS_BOUNDS;
+  const int avail = 163840 - 4 * link_fixed_words(num_nodes, cn_cap, K);
+  ClassBounds cb;
+  for (int c = 0; c < kNumClasses; ++c) cb.b[c] = std::min(nominal[c], avail);
+  cb.b[kNumClasses - 1] = avail;
+  return cb;
+}
+
+s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_cap, int K,
+                             const int32_t* n_nodes, const int32_t* p_nodes, int64_t L,
                              int32_t* class_count, int32_t* class_list) {
   if (L == 0) return S3GRL_OK;
+  const ClassBounds cb = class_bounds(g->num_nodes, cn_cap, K);
+  if (cb.b[kNumClasses - 1] < 1024) {
+    set_last_error("num_nodes " + std::to_string(g->num_nodes) +
+                   ": the LDS bitmaps leave no room for a subgraph");
+    return S3GRL_ERR_GRAPH_TOO_LARGE;
+  }
   hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream,
-                     n_nodes, L, class_count, class_list);
+                     n_nodes, p_nodes, L, cb, class_count, class_list);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -593,7 +698,8 @@ struct LinkArgs {
   const s3grl_graph* g;
   const int64_t* links;
   const int32_t* class_list;
-  int hops, plus, cn_cap;
+  int hops, plus, cn_cap, full_stats;
+  const int32_t* p_nodes;
   const int64_t *node_off, *row_ptr, *job_off, *coef_off;
   int32_t* c_ids;
   float* c_coef;
@@ -604,30 +710,30 @@ struct LinkArgs {
   int64_t *tot_edges, *tot_support;
 };
 
-template <int T, int K>
-s3grl_status launch_link_class(s3grl_context* ctx, const LinkArgs& a, int64_t L, int cls, int count) {
-  const int nmax = kClassBoundHost[cls];
+template <int T, int K, int G>
+s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t L, int cls, int count) {
   const int W = words_for(a.g->num_nodes);
-  const size_t words = (size_t)((3 * W + 2 * nmax + 1) & ~1) + 4 * (size_t)nmax + a.cn_cap +
-                       kMaxLevels + 4 * K + 32;
-  const size_t lds = words * 4;
-  if (lds > 163840) {
-    set_last_error("link_kernel needs " + std::to_string(lds) + " B of LDS (num_nodes " +
-                   std::to_string(a.g->num_nodes) + ", subgraph class " + std::to_string(nmax) +
-                   "): above the 160 KiB of a gfx950 CU");
-    return S3GRL_ERR_GRAPH_TOO_LARGE;
-  }
-  auto kern = link_kernel<T, K>;
+  const ClassBounds cb = class_bounds(a.g->num_nodes, a.cn_cap, K);
+  const size_t lds = (size_t)4 * link_fixed_words(a.g->num_nodes, a.cn_cap, K) + cb.b[cls];
+  auto kern = link_kernel<T, K, G>;
   S3GRL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(T), lds, ctx->stream, a.g->indptr,
-                     a.g->indices, W, a.links, a.class_list + (int64_t)cls * L, a.hops, a.plus, nmax,
-                     a.cn_cap, a.node_off, a.row_ptr, a.job_off, a.coef_off, a.c_ids, a.c_coef,
-                     a.jobs, a.job_z, a.row_nodes, a.lvl,
+                     a.g->indices, W, a.links, a.class_list + (int64_t)cls * L, a.hops, a.plus,
+                     a.cn_cap, a.full_stats, a.p_nodes, a.node_off, a.row_ptr, a.job_off, a.coef_off,
+                     a.c_ids, a.c_coef, a.jobs, a.job_z, a.row_nodes, a.lvl,
                      reinterpret_cast<unsigned long long*>(a.tot_edges),
                      reinterpret_cast<unsigned long long*>(a.tot_support));
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
+}
+
+// lanes per CSR row: 4 for sparse graphs (PubMed/Cora: mean degree ~4), 8 otherwise
+template <int T, int K>
+s3grl_status launch_link_class(s3grl_context* ctx, const LinkArgs& a, int64_t L, int cls, int count) {
+  const double mean_deg = (double)a.g->nnz / (double)std::max<int64_t>(a.g->num_nodes, 1);
+  if (mean_deg <= 6.0) return launch_link_class_g<T, K, 4>(ctx, a, L, cls, count);
+  return launch_link_class_g<T, K, 8>(ctx, a, L, cls, count);
 }
 
 template <int K>
@@ -638,8 +744,8 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
     const int count = class_count_host[c];
     if (count == 0) continue;
     // larger subgraphs leave room for fewer workgroups per CU: give them more waves each
-    if (c <= 1) S3GRL_TRY((launch_link_class<256, K>(ctx, a, L, c, count)));
-    else if (c <= 3) S3GRL_TRY((launch_link_class<512, K>(ctx, a, L, c, count)));
+    if (c <= 2) S3GRL_TRY((launch_link_class<256, K>(ctx, a, L, c, count)));
+    else if (c == 3) S3GRL_TRY((launch_link_class<512, K>(ctx, a, L, c, count)));
     else S3GRL_TRY((launch_link_class<1024, K>(ctx, a, L, c, count)));
   }
   return S3GRL_OK;
@@ -649,19 +755,20 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
 
 s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                           const int32_t* class_list, const int32_t* class_count_host, int hops,
-                          int plus, int cn_cap, int K, const int64_t* node_off,
-                          const int64_t* row_ptr, const int64_t* job_off, const int64_t* coef_off,
-                          int32_t* c_ids, float* c_coef, Job* jobs, float* job_z, int64_t* row_nodes,
-                          int32_t* lvl, int64_t* tot_edges, int64_t* tot_support) {
+                          int plus, int cn_cap, int full_stats, int K, const int32_t* p_nodes,
+                          const int64_t* node_off, const int64_t* row_ptr, const int64_t* job_off,
+                          const int64_t* coef_off, int32_t* c_ids, float* c_coef, Job* jobs,
+                          float* job_z, int64_t* row_nodes, int32_t* lvl, int64_t* tot_edges,
+                          int64_t* tot_support) {
   if (L == 0) return S3GRL_OK;
   if (class_count_host[kNumClasses] > 0) {
     set_last_error(std::to_string(class_count_host[kNumClasses]) +
-                   " link(s) have subgraphs above " + std::to_string(kClassBoundHost[kNumClasses - 1]) +
-                   " nodes: beyond the LDS-resident path of this build");
+                   " link(s) have subgraphs that do not fit the 160 KiB LDS-resident path of this "
+                   "build");
     return S3GRL_ERR_GRAPH_TOO_LARGE;
   }
-  LinkArgs a{g, links, class_list, hops, plus, cn_cap, node_off, row_ptr, job_off, coef_off,
-             c_ids, c_coef, jobs, job_z, row_nodes, lvl, tot_edges, tot_support};
+  LinkArgs a{g, links, class_list, hops, plus, cn_cap, full_stats, p_nodes, node_off, row_ptr,
+             job_off, coef_off, c_ids, c_coef, jobs, job_z, row_nodes, lvl, tot_edges, tot_support};
   switch (K) {
     case 1: return launch_links_k<1>(ctx, a, L, class_count_host);
     case 2: return launch_links_k<2>(ctx, a, L, class_count_host);

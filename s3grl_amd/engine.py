@@ -220,7 +220,7 @@ class Engine:
 
     # ---- the batched native entry ----------------------------------------------------------
     def plan(self, graph, links, *, mode="pos", num_hops=1, sign_k=3, strategy="intersection",
-             directed=False):
+             directed=False, full_stats=False):
         cfg = N.Cfg()
         cfg.mode = {"pos": N.MODE_POS, "pos_plus": N.MODE_POS_PLUS}[mode]
         cfg.num_hops = int(num_hops)
@@ -229,6 +229,7 @@ class Engine:
             raise NotImplementedError(f"check strat {strategy}")      # tuned_SIGN.py:235
         cfg.strategy = N.STRATEGY[strategy]
         cfg.directed = int(bool(directed))
+        cfg.reserved[0] = 1 if full_stats else 0   # exact total_sub_edges even when K < num_hops
         return Plan(self, graph, links, cfg)
 
     def precompute(self, graph, x, links, *, mode="pos", num_hops=1, sign_k=3,

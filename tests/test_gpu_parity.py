@@ -45,7 +45,7 @@ def test_subgraph_node_sets_bit_exact(eng, name):
     G = eng.graph(A)
     links = eng.links(g["links"].T)
     for h in g["hops"]:
-        plan = eng.plan(G, links, mode="pos_plus", num_hops=int(h), sign_k=2)
+        plan = eng.plan(G, links, mode="pos_plus", num_hops=int(h), sign_k=2, full_stats=True)
         node_ptr, nodes, dists = (t.cpu().numpy() for t in plan.export_subgraphs())
         row_ptr = plan.row_ptr().cpu().numpy()
         row_nodes = plan.row_nodes().cpu().numpy()
