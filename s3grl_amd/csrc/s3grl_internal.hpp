@@ -120,9 +120,9 @@ struct s3grl_sop {
   const s3grl_graph* graph = nullptr;
   int32_t K = 0;
   int64_t F = 0;
-  int64_t ldy = 0;       // leading dimension of X copy / Y_i (multiple of 4)
-  float* dinv = nullptr; // [N]
-  float* Y = nullptr;    // [K+1, N, ldy]; Y[0] = X
+  int64_t ldy = 0;        // leading dimension of Y_i (even)
+  double* dinv = nullptr; // [N] global D^-1/2
+  double* Y = nullptr;    // [K+1, N, ldy] f64; Y[0] = X, Y[i] = Â Y[i-1]
   std::vector<void*> owned;
 };
 
@@ -152,12 +152,7 @@ s3grl_status launch_gather(s3grl_context* ctx, const Job* jobs, int64_t njobs, c
                            const float* c_coef, const float* job_z, int K, const float* X,
                            int64_t ldx, int64_t F, float* rows);
 // sop.hip
-s3grl_status launch_global_dinv(s3grl_context* ctx, const s3grl_graph* g, float* dinv);
 s3grl_status launch_copy_pad(s3grl_context* ctx, const float* X, int64_t ldx, int64_t N, int64_t F,
                              float* Y, int64_t ldy);
-s3grl_status launch_spmm_norm(s3grl_context* ctx, const s3grl_graph* g, const float* dinv,
-                              const float* Yin, float* Yout, int64_t F, int64_t ldy);
-s3grl_status launch_sop_links(s3grl_context* ctx, const s3grl_sop* s, const int64_t* links,
-                              int64_t L, float* rows);
 
 }  // namespace s3grl

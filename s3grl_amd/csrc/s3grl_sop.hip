@@ -1,5 +1,23 @@
 // SoP path (global operators) and feature-layout helpers, gfx950.
+//
+// Reference: sgrl_link_pred.py:161-178 builds Â = D^-1/2 A D^-1/2 of the WHOLE train graph and
+// Â², …, Â^K by SpGEMM; tuned_SIGN.py:49-134 then, per link (s, d) and operator i, takes row s
+// of Â^i with column d zeroed (and row d with column s zeroed), multiplies by X, and prepends
+// the diagonal entry Â^i[s,s] (Â^i[d,d]).
+//
+// Here no power of Â is ever materialised.  With Y_i = Â^i X (K global SpMMs, once):
+//     x_i[s] = [ Â^i[s,s] | Y_i[s] − Â^i[s,d]·X[d] ]      x_i[d] = [ Â^i[d,d] | Y_i[d] − Â^i[s,d]·X[s] ]
+// and the three scalars per operator are meet-in-the-middle dot products of short propagated
+// rows:  Â^i[s,d] = r_a(s)·r_b(d), a + b = i, a = ⌊i/2⌋ (Â is symmetric), formed per link inside
+// the ⌈K/2⌉-hop ball of {s,d} in LDS.  Everything is computed in f64 and rounded to f32 once:
+// the subtraction cancels exactly where the reference's masked sum is exactly zero (a leaf s
+// hanging off d), which f32 intermediates would turn into 1e-8-sized noise.
+#include <algorithm>
+#include <cstring>
+#include <memory>
+
 #include "s3grl_internal.hpp"
+#include "s3grl_device.hpp"
 
 namespace s3grl {
 namespace {
@@ -13,6 +31,233 @@ __global__ void copy_pad_kernel(const float* __restrict__ X, int64_t ldx, int64_
     const int64_t r = i / ldy, c = i - r * ldy;
     Y[i] = c < F ? X[r * ldx + c] : 0.f;
   }
+}
+
+__global__ void to_f64_pad_kernel(const float* __restrict__ X, int64_t ldx, int64_t N, int64_t F,
+                                  double* __restrict__ Y, int64_t ldy) {
+  const int64_t total = N * ldy;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / ldy, c = i - r * ldy;
+    Y[i] = c < F ? (double)X[r * ldx + c] : 0.0;
+  }
+}
+
+// deg = stored entries per row (reference sgrl_link_pred.py:170-172), deg^-1/2, inf -> 0
+__global__ void global_dinv_kernel(const int32_t* __restrict__ indptr, int64_t N,
+                                   double* __restrict__ dinv) {
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= N) return;
+  const int deg = indptr[v + 1] - indptr[v];
+  dinv[v] = deg > 0 ? 1.0 / sqrt((double)deg) : 0.0;
+}
+
+// Y_out[v,:] = dinv[v] · Σ_{u ∈ N(v)} dinv[u] · Y_in[u,:]      one wave per row, f64
+__global__ __launch_bounds__(256) void spmm_norm_kernel(
+    const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const double* __restrict__ dinv, const double* __restrict__ Yin, double* __restrict__ Yout,
+    int64_t N, int64_t ldy) {
+  const int lane = threadIdx.x & 63;
+  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= N) return;
+  const int e0 = indptr[v], e1 = indptr[v + 1];
+  const double dv = dinv[v];
+  for (int64_t c0 = 0; c0 < ldy; c0 += 256) {  // 4 columns per lane per tile
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int e = e0; e < e1; ++e) {
+      const int u = indices[e];
+      const double du = dinv[u];
+      const double* __restrict__ yr = Yin + (int64_t)u * ldy + c0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t c = lane + 64 * k;
+        if (c0 + c < ldy) acc[k] += du * yr[c];
+      }
+    }
+    double* __restrict__ yo = Yout + v * ldy + c0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t c = lane + 64 * k;
+      if (c0 + c < ldy) yo[c] = dv * acc[k];
+    }
+  }
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Per link: Â^i[s,d], Â^i[s,s], Â^i[d,d] for i = 1..K.  LDS: vis/nxt/wpre bitmaps, list[n],
+// r[HB][n] double2 (x: propagated from s, y: from d), misc.
+template <int T, int G>
+__global__ __launch_bounds__(T) void sop_scalar_kernel(
+    const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int W,
+    const double* __restrict__ gdinv, const int64_t* __restrict__ links,
+    const int32_t* __restrict__ class_list, const int64_t* __restrict__ node_off, int K, int HB,
+    double* __restrict__ scal /* [L][K][3] = sd, ss, dd */) {
+  extern __shared__ uint32_t smem[];
+  const int tid = threadIdx.x;
+  const int l = class_list[blockIdx.x];
+  const int n_alloc = (int)(node_off[l + 1] - node_off[l]);
+  uint32_t* vis = smem;
+  uint32_t* nxt = smem + W;
+  uint32_t* wpre = smem + 2 * W;
+  int* lvl_end = reinterpret_cast<int*>(smem + 3 * W);
+  int* sh = lvl_end + kMaxLevels;
+  const int red_off = (3 * W + kMaxLevels + 32 + 1) & ~1;           // doubles: 8-byte aligned
+  double* red = reinterpret_cast<double*>(smem + red_off);           // [16 waves][3]
+  int32_t* list = reinterpret_cast<int32_t*>(smem + red_off + 96);
+  double2* r = reinterpret_cast<double2*>(smem + ((red_off + 96 + n_alloc + 3) & ~3));  // [HB][n]
+
+  const int src = (int)links[2 * (int64_t)l], dst = (int)links[2 * (int64_t)l + 1];
+  const int g = tid & (G - 1);
+  int nlev;
+  const int n = bfs_list<T, G>(indptr, indices, W, src, dst, HB, vis, nxt, list, lvl_end, sh, nlev);
+  {
+    int carry = 0;
+    for (int base = 0; base < W; base += T) {
+      const int t = base + tid;
+      const int pc = t < W ? __popc(vis[t]) : 0;
+      int total;
+      const int ex = block_excl_scan<T>(pc, sh, total);
+      if (t < W) wpre[t] = carry + ex;
+      carry += total;
+    }
+  }
+  for (int w = tid; w < n * HB; w += T) r[w] = make_double2(0.0, 0.0);
+  __syncthreads();
+  const int sl = rank_of(vis, wpre, src), dl = rank_of(vis, wpre, dst);
+
+  // r_j[w] = dinv[w] Σ_{u ∈ N(w)} dinv[u] r_{j-1}[u];  r_0 = (e_s, e_d).  A walk of length j from
+  // {s,d} stays within hop j, and every neighbour that matters is inside the ball: no masking,
+  // global degrees (the target link is NOT removed for SoP, sgrl_link_pred.py:166-173).
+  for (int j = 1; j <= HB; ++j) {
+    const int limit = lvl_end[min(j, nlev - 1)];
+    double2* out = r + (int64_t)(j - 1) * n;
+    const double2* in = j >= 2 ? r + (int64_t)(j - 2) * n : nullptr;
+    for (int base = 0; base < limit; base += T / G) {
+      const int t = base + tid / G;
+      if (t < limit) {
+        const int v = list[t];
+        const int e1 = indptr[v + 1];
+        double sx = 0.0, sy = 0.0;
+        for (int c = indptr[v] + g; c < e1; c += G) {
+          const int u = indices[c];
+          if (j == 1) {
+            if (u == src) sx += gdinv[u];
+            if (u == dst) sy += gdinv[u];
+          } else if (test_bit(vis, u)) {
+            const double2 rv = in[rank_of(vis, wpre, u)];
+            const double du = gdinv[u];
+            sx += du * rv.x;
+            sy += du * rv.y;
+          }
+        }
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) {
+          sx += __shfl_xor(sx, o);
+          sy += __shfl_xor(sy, o);
+        }
+        if (g == 0) {
+          const double dv = gdinv[v];
+          out[rank_of(vis, wpre, v)] = make_double2(dv * sx, dv * sy);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // dots: a = ⌊i/2⌋, b = i − a;  r_0(s) = e_s
+  for (int i = 1; i <= K; ++i) {
+    const int a = i / 2, b = i - a;
+    const double2* rb = r + (int64_t)(b - 1) * n;
+    double sd = 0.0, ss = 0.0, dd = 0.0;
+    if (a == 0) {
+      if (tid == 0) {
+        sd = rb[sl].y;   // Â^b[d, s] = Â^b[s, d]
+        ss = rb[sl].x;
+        dd = rb[dl].y;
+      }
+    } else {
+      const double2* ra = r + (int64_t)(a - 1) * n;
+      for (int w = tid; w < n; w += T) {
+        const double2 x = ra[w], y = rb[w];
+        sd += x.x * y.y;
+        ss += x.x * y.x;
+        dd += x.y * y.y;
+      }
+    }
+    sd = wave_sum_f64(sd);
+    ss = wave_sum_f64(ss);
+    dd = wave_sum_f64(dd);
+    if ((tid & 63) == 0) {
+      red[(tid >> 6) * 3 + 0] = sd;
+      red[(tid >> 6) * 3 + 1] = ss;
+      red[(tid >> 6) * 3 + 2] = dd;
+    }
+    __syncthreads();
+    if (tid < 3) {
+      double acc = 0.0;
+      for (int w = 0; w < T / 64; ++w) acc += red[w * 3 + tid];   // fixed order
+      scal[((int64_t)l * K + (i - 1)) * 3 + tid] = acc;
+    }
+    __syncthreads();
+  }
+}
+
+// rows[2l + e, i, :] for e ∈ {src, dst}: one wave per link, f64 arithmetic, f32 out
+__global__ __launch_bounds__(256) void sop_rows_kernel(
+    const int64_t* __restrict__ links, int64_t L, const double* __restrict__ Y, int64_t N,
+    int64_t ldy, int F, int K, const double* __restrict__ scal, float* __restrict__ rows) {
+  const int lane = threadIdx.x & 63;
+  const int64_t l = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (l >= L) return;
+  const int64_t s = links[2 * l], d = links[2 * l + 1];
+  const int Fp = F + 1;
+  float* __restrict__ out_s = rows + (2 * l) * (int64_t)(K + 1) * Fp;
+  float* __restrict__ out_d = out_s + (int64_t)(K + 1) * Fp;
+  const double* __restrict__ x_s = Y + s * ldy;
+  const double* __restrict__ x_d = Y + d * ldy;
+  for (int c = lane; c < F; c += 64) {
+    out_s[1 + c] = (float)x_s[c];   // operator 0: x = [[1|X[s]],[1|X[d]]]  (tuned_SIGN.py:119-125)
+    out_d[1 + c] = (float)x_d[c];
+  }
+  if (lane == 0) {
+    out_s[0] = 1.f;
+    out_d[0] = 1.f;
+  }
+  for (int i = 1; i <= K; ++i) {
+    const double* __restrict__ yi = Y + (int64_t)i * N * ldy;
+    const double sd = scal[(l * K + (i - 1)) * 3 + 0];
+    const double* __restrict__ y_s = yi + s * ldy;
+    const double* __restrict__ y_d = yi + d * ldy;
+    float* __restrict__ o_s = out_s + (int64_t)i * Fp;
+    float* __restrict__ o_d = out_d + (int64_t)i * Fp;
+    for (int c = lane; c < F; c += 64) {
+      o_s[1 + c] = (float)(y_s[c] - sd * x_d[c]);
+      o_d[1 + c] = (float)(y_d[c] - sd * x_s[c]);
+    }
+    if (lane == 0) {
+      o_s[0] = (float)scal[(l * K + (i - 1)) * 3 + 1];
+      o_d[0] = (float)scal[(l * K + (i - 1)) * 3 + 2];
+    }
+  }
+}
+
+static inline int words_for(int64_t N) { return (int)((N + 31) / 32); }
+
+// bins links by LDS need of sop_scalar_kernel (4 + 16·HB bytes per ball node)
+__global__ void sop_classify_kernel(const int32_t* __restrict__ n_nodes, int64_t L, int per_node,
+                                    int b0, int b1, int b2, int32_t* __restrict__ class_count,
+                                    int32_t* __restrict__ class_list) {
+  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L) return;
+  const int need = n_nodes[l] * per_node + 64;
+  const int c = need <= b0 ? 0 : (need <= b1 ? 1 : (need <= b2 ? 2 : 3));
+  const int slot = atomicAdd(&class_count[c], 1);
+  if (c < 3) class_list[(int64_t)c * L + slot] = (int32_t)l;
 }
 
 }  // namespace
@@ -29,16 +274,171 @@ s3grl_status launch_copy_pad(s3grl_context* ctx, const float* X, int64_t ldx, in
 
 }  // namespace s3grl
 
+using namespace s3grl;
+
 extern "C" {
 
-s3grl_status s3grl_sop_create(s3grl_context*, const s3grl_graph*, const float*, int64_t, int64_t,
-                              int32_t, s3grl_sop**) {
-  s3grl::set_last_error("SoP not built yet");
-  return S3GRL_ERR_NOT_IMPLEMENTED;
+s3grl_status s3grl_sop_destroy(s3grl_sop* s) {
+  if (!s) return S3GRL_OK;
+  for (void* q : s->owned) s->ctx->arena.release(q);
+  delete s;
+  return S3GRL_OK;
 }
-s3grl_status s3grl_sop_destroy(s3grl_sop*) { return S3GRL_OK; }
-s3grl_status s3grl_sop_run(s3grl_context*, const s3grl_sop*, const int64_t*, int64_t, float*) {
-  s3grl::set_last_error("SoP not built yet");
-  return S3GRL_ERR_NOT_IMPLEMENTED;
+
+s3grl_status s3grl_sop_create(s3grl_context* ctx, const s3grl_graph* g, const float* X, int64_t ldx,
+                              int64_t F, int32_t K, s3grl_sop** out) {
+  if (!ctx || !g || !out) return S3GRL_ERR_INVALID_ARGUMENT;
+  if (!X) {
+    set_last_error("node features are None");
+    return S3GRL_ERR_NO_FEATURES;
+  }
+  if (K < 1 || K > kMaxSignK || F <= 0 || ldx < F) {
+    set_last_error("sign_k must be in 1..8, F > 0, ldx >= F");
+    return S3GRL_ERR_INVALID_ARGUMENT;
+  }
+  if (g->num_nodes > kMaxNodesLds) {
+    set_last_error("num_nodes exceeds the LDS bitmap limit");
+    return S3GRL_ERR_GRAPH_TOO_LARGE;
+  }
+  S3GRL_HIP_TRY(hipSetDevice(ctx->device));
+  std::unique_ptr<s3grl_sop, s3grl_status (*)(s3grl_sop*)> s(new s3grl_sop(), s3grl_sop_destroy);
+  s->ctx = ctx;
+  s->graph = g;
+  s->K = K;
+  s->F = F;
+  s->ldy = (F + 1) / 2 * 2;
+  const int64_t N = g->num_nodes;
+  void* p = nullptr;
+  S3GRL_TRY(ctx->arena.alloc((size_t)N * 8, &p));
+  s->owned.push_back(p);
+  s->dinv = static_cast<double*>(p);
+  S3GRL_TRY(ctx->arena.alloc((size_t)(K + 1) * N * s->ldy * 8, &p));
+  s->owned.push_back(p);
+  s->Y = static_cast<double*>(p);
+  if (ctx->profiling) S3GRL_HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+  hipLaunchKernelGGL(global_dinv_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream,
+                     g->indptr, N, s->dinv);
+  const int64_t total = N * s->ldy;
+  hipLaunchKernelGGL(to_f64_pad_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 8192)),
+                     dim3(256), 0, ctx->stream, X, ldx, N, F, s->Y, s->ldy);
+  for (int i = 1; i <= K; ++i)
+    hipLaunchKernelGGL(spmm_norm_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ctx->stream,
+                       g->indptr, g->indices, s->dinv, s->Y + (int64_t)(i - 1) * N * s->ldy,
+                       s->Y + (int64_t)i * N * s->ldy, N, s->ldy);
+  S3GRL_HIP_TRY(hipGetLastError());
+  if (ctx->profiling) {
+    S3GRL_HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+    S3GRL_HIP_TRY(hipEventSynchronize(ctx->ev[1]));
+    float ms = 0;
+    S3GRL_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->timings[3] += ms;
+  }
+  *out = s.release();
+  return S3GRL_OK;
 }
+
+s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t* links, int64_t L,
+                           float* rows) {
+  if (!ctx || !s || L < 0 || (L > 0 && (!links || !rows))) return S3GRL_ERR_INVALID_ARGUMENT;
+  if (L == 0) return S3GRL_OK;
+  if (L >= (int64_t)INT32_MAX / 4) return S3GRL_ERR_INVALID_ARGUMENT;
+  S3GRL_HIP_TRY(hipSetDevice(ctx->device));
+  const s3grl_graph* g = s->graph;
+  const int K = s->K, HB = (K + 1) / 2;
+  const int W = words_for(g->num_nodes);
+  std::vector<void*> tmp;
+  struct Rel {
+    s3grl_context* c;
+    std::vector<void*>* v;
+    ~Rel() {
+      for (void* q : *v) c->arena.release(q);
+    }
+  } rel{ctx, &tmp};
+  auto alloc = [&](size_t bytes, void** q) -> s3grl_status {
+    S3GRL_TRY(ctx->arena.alloc(bytes, q));
+    tmp.push_back(*q);
+    return S3GRL_OK;
+  };
+  int32_t *n_nodes, *p_nodes, *n_rows, *n_jobs, *class_list;
+  int64_t *node_off, *scan_ws;
+  double* scal;
+  void* q;
+  S3GRL_TRY(alloc((size_t)L * 4, &q)); n_nodes = (int32_t*)q;
+  S3GRL_TRY(alloc((size_t)L * 4, &q)); p_nodes = (int32_t*)q;
+  S3GRL_TRY(alloc((size_t)L * 4, &q)); n_rows = (int32_t*)q;
+  S3GRL_TRY(alloc((size_t)L * 4, &q)); n_jobs = (int32_t*)q;
+  S3GRL_TRY(alloc((size_t)L * 3 * 4, &q)); class_list = (int32_t*)q;
+  S3GRL_TRY(alloc((size_t)(L + 1) * 8, &q)); node_off = (int64_t*)q;
+  S3GRL_TRY(alloc((size_t)scan_workspace_elems(L) * 8, &q)); scan_ws = (int64_t*)q;
+  S3GRL_TRY(alloc((size_t)L * K * 3 * 8, &q)); scal = (double*)q;
+
+  int64_t* ds = ctx->d_scalars;
+  int64_t* hs = ctx->h_scalars;
+  int32_t* class_count = reinterpret_cast<int32_t*>(ds + 8);
+  if (ctx->profiling) S3GRL_HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+  S3GRL_HIP_TRY(hipMemsetAsync(ds, 0, 32 * sizeof(int64_t), ctx->stream));
+  // the ⌈K/2⌉-hop ball of {s,d}: same BFS as PoS, no row selection
+  S3GRL_TRY(launch_count(ctx, g, links, L, HB, 0, 1, n_nodes, p_nodes, n_rows, n_jobs,
+                         reinterpret_cast<int32_t*>(ds), ds + 4));
+  S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_nodes, L, node_off, scan_ws));
+  const int fixed = 4 * (3 * W + kMaxLevels + 32 + 6 * 16) + 64;
+  const int per_node = 4 + 16 * HB;
+  const int b2 = 163840 - fixed, b1 = std::min(b2, 49152), b0 = std::min(b2, 12288);
+  hipLaunchKernelGGL(sop_classify_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream,
+                     n_nodes, L, per_node, b0, b1, b2, class_count, class_list);
+  S3GRL_HIP_TRY(hipGetLastError());
+  S3GRL_HIP_TRY(hipMemcpyAsync(hs, ds, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const int err = (int)(hs[0] & 0xffffffff);
+  if (err == 2) {
+    set_last_error("a link has src == dst");
+    return S3GRL_ERR_SELF_LINK;
+  }
+  if (err == 1) {
+    set_last_error("a link endpoint is outside [0, num_nodes)");
+    return S3GRL_ERR_INVALID_ARGUMENT;
+  }
+  int32_t cc[4];
+  std::memcpy(cc, hs + 8, sizeof(cc));
+  if (cc[3] > 0 || b2 < 1024) {
+    set_last_error(std::to_string(cc[3]) + " link(s): the " + std::to_string(HB) +
+                   "-hop ball does not fit the 160 KiB LDS-resident SoP scalar path");
+    return S3GRL_ERR_GRAPH_TOO_LARGE;
+  }
+  const int bounds[3] = {b0, b1, b2};
+  const bool sparse = (double)g->nnz / (double)std::max<int64_t>(g->num_nodes, 1) <= 6.0;
+  for (int c = 2; c >= 0; --c) {
+    if (cc[c] == 0) continue;
+    const size_t lds = (size_t)fixed + bounds[c];
+#define S3GRL_SOP_LAUNCH(TT, GG)                                                                   \
+  do {                                                                                             \
+    auto kern = sop_scalar_kernel<TT, GG>;                                                         \
+    S3GRL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+    hipLaunchKernelGGL(kern, dim3((unsigned)cc[c]), dim3(TT), lds, ctx->stream, g->indptr,         \
+                       g->indices, W, s->dinv, links, class_list + (int64_t)c * L, node_off, K,    \
+                       HB, scal);                                                                  \
+  } while (0)
+    if (c == 0) {
+      if (sparse) S3GRL_SOP_LAUNCH(256, 4); else S3GRL_SOP_LAUNCH(256, 8);
+    } else {
+      if (sparse) S3GRL_SOP_LAUNCH(1024, 4); else S3GRL_SOP_LAUNCH(1024, 8);
+    }
+#undef S3GRL_SOP_LAUNCH
+    S3GRL_HIP_TRY(hipGetLastError());
+  }
+  hipLaunchKernelGGL(sop_rows_kernel, dim3((unsigned)((L + 3) / 4)), dim3(256), 0, ctx->stream, links,
+                     L, s->Y, g->num_nodes, s->ldy, (int)s->F, K, scal, rows);
+  S3GRL_HIP_TRY(hipGetLastError());
+  if (ctx->profiling) {
+    S3GRL_HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+    S3GRL_HIP_TRY(hipEventSynchronize(ctx->ev[1]));
+    float ms = 0;
+    S3GRL_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->timings[4] += ms;
+    ctx->timings[7] += 1.0;
+  }
+  return S3GRL_OK;
 }
+
+}  // extern "C"

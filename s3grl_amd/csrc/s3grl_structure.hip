@@ -14,67 +14,10 @@
 // (neighbors) and tuned_SIGN.py:151-175 / :206-240: the reference materialises Â², …, Â^K of
 // the whole n×n subgraph by SpGEMM and keeps R rows; here only those R rows are ever formed.
 #include "s3grl_internal.hpp"
+#include "s3grl_device.hpp"
 
 namespace s3grl {
 namespace {
-
-__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
-
-// Exclusive scan of one int per thread over a T-thread block; `sh` holds >= T/64 ints.
-template <int T>
-__device__ __forceinline__ int block_excl_scan(int v, int* sh, int& total) {
-  const int lane = lane_id(), wid = wave_id();
-  int inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int t = __shfl_up(inc, o);
-    if (lane >= o) inc += t;
-  }
-  if (lane == 63) sh[wid] = inc;
-  __syncthreads();
-  int woff = 0, tot = 0;
-#pragma unroll
-  for (int i = 0; i < T / 64; ++i) {
-    int s = sh[i];
-    if (i < wid) woff += s;
-    tot += s;
-  }
-  __syncthreads();
-  total = tot;
-  return woff + inc - v;
-}
-
-template <int T>
-__device__ __forceinline__ int block_sum(int v, int* sh) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  if (lane_id() == 0) sh[wave_id()] = v;
-  __syncthreads();
-  int tot = 0;
-#pragma unroll
-  for (int i = 0; i < T / 64; ++i) tot += sh[i];
-  __syncthreads();
-  return tot;
-}
-
-__device__ __forceinline__ bool test_bit(const uint32_t* bm, int v) {
-  return (bm[v >> 5] >> (v & 31)) & 1u;
-}
-
-__device__ __forceinline__ int rank_of(const uint32_t* vis, const uint32_t* wpre, int v) {
-  return (int)wpre[v >> 5] + __popc(vis[v >> 5] & ((1u << (v & 31)) - 1u));
-}
-
-// membership in an ascending int list (global CSR row)
-__device__ __forceinline__ bool sorted_contains(const int32_t* a, int n, int x) {
-  int lo = 0, hi = n;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (a[mid] < x) lo = mid + 1; else hi = mid;
-  }
-  return lo < n && a[lo] == x;
-}
 
 // PoS Plus row selection, reference tuned_SIGN.py:233 evaluated on the MASKED sub-CSR whose
 // `.indices` still hold the explicit zeros of the masking:
@@ -349,60 +292,9 @@ __global__ __launch_bounds__(T) void link_kernel(
   const int src = (int)links[2 * (int64_t)l], dst = (int)links[2 * (int64_t)l + 1];
   const int g = tid & (G - 1);
 
-  // ---- BFS: frontier = a segment of `list`, G lanes per frontier node -------------------
-  uint32_t* nxt = inP;
-  for (int t = tid; t < W; t += T) {
-    vis[t] = 0;
-    nxt[t] = 0;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    atomicOr(&vis[src >> 5], 1u << (src & 31));
-    atomicOr(&vis[dst >> 5], 1u << (dst & 31));
-    list[0] = min(src, dst);
-    list[1] = max(src, dst);
-    lvl_end[0] = 2;
-  }
-  __syncthreads();
-  int n = 2, nlev = 1;  // levels 0..nlev-1 are complete
-  for (int d = 1; d <= hops; ++d) {
-    const int f0 = d >= 2 ? lvl_end[d - 2] : 0, f1 = n;
-    for (int base = f0; base < f1; base += T / G) {
-      const int t = base + tid / G;
-      if (t < f1) {
-        const int v = list[t];
-        const int e1 = indptr[v + 1];
-        for (int c = indptr[v] + g; c < e1; c += G) {
-          const int u = indices[c];
-          const uint32_t m = 1u << (u & 31);
-          const uint32_t old = atomicOr(&vis[u >> 5], m);
-          if (!(old & m)) atomicOr(&nxt[u >> 5], m);
-        }
-      }
-    }
-    __syncthreads();
-    // append the new level in ascending id order (deterministic), clear nxt
-    int added = 0;
-    for (int base = 0; base < W; base += T) {
-      const int t = base + tid;
-      uint32_t w = t < W ? nxt[t] : 0u;
-      int total;
-      int pos = n + added + block_excl_scan<T>(__popc(w), sh, total);
-      while (w) {
-        const int b = __ffs(w) - 1;
-        w &= w - 1;
-        list[pos++] = t * 32 + b;
-      }
-      if (t < W) nxt[t] = 0;
-      added += total;
-    }
-    if (added == 0) break;  // uniform: `added` is a block-wide total
-    n += added;
-    if (tid == 0) lvl_end[d] = n;
-    nlev = d + 1;
-    __syncthreads();
-  }
-  __syncthreads();
+  // ---- BFS on the unmasked graph (reference utils.py:53-74) --------------------------------
+  int nlev;
+  const int n = bfs_list<T, G>(indptr, indices, W, src, dst, hops, vis, inP, list, lvl_end, sh, nlev);
 
   // ---- rows of this link ----------------------------------------------------------------
   const int64_t rp = row_ptr[l];
