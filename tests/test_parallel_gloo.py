@@ -1,0 +1,76 @@
+"""World-size-2 gloo test of the sharding + reassembly logic (the N > 1 path).  The per-rank
+compute is the oracle here (CPU), standing in for the engine call — this tests the distributed
+plumbing, not the kernels."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import oracle
+from conftest import csr_from_undirected, load_extract
+from s3grl_amd import parallel
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, plus, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = load_extract("usair")
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = np.random.default_rng(0).random((n, 6))
+    links = g["links"].T
+    kw = {"sign_k": 2, "k_node_set_strategy": "intersection"}
+    fn = oracle.get_PoS_Plus_prepped_ds if plus else oracle.get_PoS_prepped_ds
+
+    def compute(shard):
+        rows, ptr, _ = oracle.collate_rows(fn(shard.numpy(), 1, A, X, 1, kw, dtype=np.float64), 2)
+        if rows.shape[0] == 0:
+            rows = np.zeros((0, 3, 7))
+        return torch.from_numpy(rows), torch.from_numpy(ptr)
+
+    rows, ptr, (lo, hi) = parallel.sharded_precompute(
+        compute, links, rank=rank, world_size=world, cost=parallel.link_cost(A, links))
+    full_rows, full_ptr, _ = oracle.collate_rows(fn(links, 1, A, X, 1, kw, dtype=np.float64), 2)
+    ok = np.array_equal(ptr.numpy(), full_ptr) and np.array_equal(rows.numpy(), full_rows)
+    q.put((rank, ok, lo, hi))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("plus", [False, True])
+def test_sharded_precompute_world2(plus):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, plus, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in res)
+    spans = sorted((lo, hi) for _, _, lo, hi in res)
+    assert spans[0][0] == 0 and spans[0][1] == spans[1][0] and spans[1][1] == 34
+
+
+def test_shard_bounds_balanced_and_contiguous():
+    cost = np.array([1, 1, 1, 1, 100, 1, 1, 1])
+    b = parallel.shard_bounds(8, 2, cost)
+    assert b[0] == 0 and b[-1] == 8 and b == sorted(b)
+    assert parallel.shard_bounds(10, 4) == [0, 2, 5, 7, 10]
+    assert parallel.shard_bounds(0, 3) == [0, 0, 0, 0]
