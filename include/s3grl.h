@@ -93,6 +93,7 @@ typedef struct s3grl_graph s3grl_graph;     /* structure of the train graph A (v
                                                ignores them, tuned_SIGN.py:153-156) */
 typedef struct s3grl_plan s3grl_plan;       /* extraction + operator coefficients of one call */
 typedef struct s3grl_sop s3grl_sop;         /* SoP global state: Â, Y_i = Â^i X */
+typedef struct s3grl_features s3grl_features; /* X prepared for the gather (dense or sparse rows) */
 
 int32_t s3grl_abi_version(void);
 const char* s3grl_status_string(s3grl_status s);
@@ -136,6 +137,21 @@ s3grl_status s3grl_plan_export_subgraphs(const s3grl_plan* p, int64_t* node_ptr,
 s3grl_status s3grl_run(s3grl_context* ctx, const s3grl_plan* p, const float* X, int64_t ldx,
                        int64_t num_features, float* rows);
 
+/* The feature operand x of the reference operators (dense fp32 [N,F], utils.py:83), prepared
+ * once: 16-byte aligned rows (borrowed when X already is: keep X alive and unchanged while the
+ * handle is in use).  flags: 0 or 1 = dense rows (default); 2 = additionally build sparse rows
+ * (column, value pairs) that the gather streams instead — same sums; opt-in because it measured
+ * slower than the dense kernel at 10 % density on MI355X. */
+s3grl_status s3grl_features_create(s3grl_context* ctx, const float* X, int64_t ldx,
+                                   int64_t num_nodes, int64_t num_features, int32_t flags,
+                                   s3grl_features** out);
+s3grl_status s3grl_features_destroy(s3grl_features* f);
+/* host outs (either may be NULL): stored non-zeros (0 when never counted), sparse rows in use */
+s3grl_status s3grl_features_info(const s3grl_features* f, int64_t* nnz, int32_t* is_sparse);
+/* same contract as s3grl_run, with a prepared operand */
+s3grl_status s3grl_run_features(s3grl_context* ctx, const s3grl_plan* p, const s3grl_features* f,
+                                float* rows);
+
 /* SoP: one-off global setup (reference sgrl_link_pred.py:161-178 recomputes it per split):
  * Â = D^-1/2 A D^-1/2 of the whole graph and Y_i = Â^i X, i = 1..K. */
 s3grl_status s3grl_sop_create(s3grl_context* ctx, const s3grl_graph* g, const float* X,
@@ -145,6 +161,20 @@ s3grl_status s3grl_sop_destroy(s3grl_sop* s);
  * image for dst (reference tuned_SIGN.py:71-78,92-113,119-132). */
 s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t* links,
                            int64_t num_links, float* rows);
+
+/* Consumer-side centre / common-neighbour pooling, reference SIGNNet._centre_pool_helper
+ * (models.py:339-369) on the engine's layout: h fp32 [total_rows, H] (the output of
+ * operator_diff), rows of link b = row_ptr[b]..row_ptr[b+1], the first two being src, dst.
+ * mode 0 (k_heuristic == 0): out [B, H] = h[src] * h[dst];  mode 1 / 2 (k_pool_strategy 'mean' /
+ * 'sum'): out [B, 2H] = [h[src] * h[dst] | mean or sum of the remaining rows], zeros when a link
+ * has none (the reference's `size=B`).  'concat' is not implemented.  No host sync (the
+ * reference does np.unique on the CPU per batch, models.py:341).  backward: grad_h [total_rows,
+ * H] is fully overwritten. */
+s3grl_status s3grl_centre_pool_forward(s3grl_context* ctx, const float* h, const int64_t* row_ptr,
+                                       int64_t num_links, int64_t hidden, int32_t mode, float* out);
+s3grl_status s3grl_centre_pool_backward(s3grl_context* ctx, const float* h, const int64_t* row_ptr,
+                                        int64_t num_links, int64_t hidden, int32_t mode,
+                                        const float* grad_out, float* grad_h);
 
 /* Per-phase device time accumulated since profiling was last switched on, in milliseconds,
  * from HIP events recorded on the context's stream around the kernels themselves:

@@ -159,7 +159,6 @@ s3grl_status s3grl_context_destroy(s3grl_context* ctx) {
     if (e) (void)hipEventDestroy(e);
   if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
   if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
-  if (ctx->x_padded) ctx->arena.release(ctx->x_padded);
   delete ctx;
   return S3GRL_OK;
 }
@@ -434,27 +433,31 @@ s3grl_status s3grl_plan_export_subgraphs(const s3grl_plan* p, int64_t* node_ptr,
   return S3GRL_OK;
 }
 
-// X as the gather kernel wants it: 16-byte aligned rows, ld a multiple of 4 floats >= F.
-static s3grl_status aligned_features(s3grl_context* ctx, int64_t N, const float* X, int64_t ldx,
-                                     int64_t F, const float** Xa, int64_t* lda) {
-  const int64_t need = (F + 3) / 4 * 4;
-  if ((reinterpret_cast<uintptr_t>(X) & 15) == 0 && ldx % 4 == 0 && ldx >= need) {
-    *Xa = X;
-    *lda = ldx;
-    return S3GRL_OK;
+static s3grl_status run_with(s3grl_context* ctx, const s3grl_plan* p, const s3grl_features* f,
+                             float* rows) {
+  if (p->njobs == 0) return S3GRL_OK;
+  if (f->N != p->graph->num_nodes) {
+    set_last_error("features have " + std::to_string(f->N) + " rows, the graph " +
+                   std::to_string(p->graph->num_nodes) + " nodes");
+    return S3GRL_ERR_INVALID_ARGUMENT;
   }
-  const size_t bytes = (size_t)N * need * 4;
-  if (ctx->x_padded_bytes < bytes) {
-    if (ctx->x_padded) ctx->arena.release(ctx->x_padded);
-    void* p = nullptr;
-    S3GRL_TRY(ctx->arena.alloc(bytes, &p));
-    ctx->x_padded = static_cast<float*>(p);
-    ctx->x_padded_bytes = bytes;
-  }
-  S3GRL_TRY(launch_copy_pad(ctx, X, ldx, N, F, ctx->x_padded, need));
-  *Xa = ctx->x_padded;
-  *lda = need;
+  if (ctx->profiling) S3GRL_TRY(resolve_pending_gather(ctx));
+  S3GRL_TRY(record(ctx, 3));
+  if (f->sparse)
+    S3GRL_TRY(launch_gather_sparse(ctx, p, f, rows));
+  else
+    S3GRL_TRY(launch_gather(ctx, p->jobs, p->njobs, p->c_ids, p->c_coef, p->job_z, p->cfg.sign_k,
+                            f->dense, f->ld, f->F, rows));
+  S3GRL_TRY(record(ctx, 4));
+  if (ctx->profiling) ctx->gather_pending = true;
   return S3GRL_OK;
+}
+
+s3grl_status s3grl_run_features(s3grl_context* ctx, const s3grl_plan* p, const s3grl_features* f,
+                                float* rows) {
+  if (!ctx || !p || !f || (p->stats.total_rows && !rows)) return S3GRL_ERR_INVALID_ARGUMENT;
+  S3GRL_HIP_TRY(hipSetDevice(ctx->device));
+  return run_with(ctx, p, f, rows);
 }
 
 s3grl_status s3grl_run(s3grl_context* ctx, const s3grl_plan* p, const float* X, int64_t ldx,
@@ -466,17 +469,13 @@ s3grl_status s3grl_run(s3grl_context* ctx, const s3grl_plan* p, const float* X, 
   }
   if (F <= 0 || ldx < F || (p->stats.total_rows && !rows)) return S3GRL_ERR_INVALID_ARGUMENT;
   if (p->njobs == 0) return S3GRL_OK;
-  S3GRL_HIP_TRY(hipSetDevice(ctx->device));
-  const float* Xa;
-  int64_t lda;
-  S3GRL_TRY(aligned_features(ctx, p->graph->num_nodes, X, ldx, F, &Xa, &lda));
-  if (ctx->profiling) S3GRL_TRY(resolve_pending_gather(ctx));
-  S3GRL_TRY(record(ctx, 3));
-  S3GRL_TRY(launch_gather(ctx, p->jobs, p->njobs, p->c_ids, p->c_coef, p->job_z, p->cfg.sign_k, Xa,
-                          lda, F, rows));
-  S3GRL_TRY(record(ctx, 4));
-  if (ctx->profiling) ctx->gather_pending = true;
-  return S3GRL_OK;
+  // plain dense operand, no density analysis (that costs a host round trip): use
+  // s3grl_features_create + s3grl_run_features to let the engine pick sparse rows
+  s3grl_features* f = nullptr;
+  S3GRL_TRY(s3grl_features_create(ctx, X, ldx, p->graph->num_nodes, F, 1, &f));
+  const s3grl_status st = run_with(ctx, p, f, rows);
+  s3grl_features_destroy(f);   // stream-ordered: a padded copy is only reused by later launches
+  return st;
 }
 
 }  // extern "C"

@@ -80,8 +80,6 @@ struct s3grl_context {
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int64_t* d_scalars = nullptr;  // small device scratch for totals (32 x int64)
   int64_t* h_scalars = nullptr;  // pinned host mirror
-  float* x_padded = nullptr;     // 16-byte aligned copy of X when the caller's is not
-  size_t x_padded_bytes = 0;
 };
 
 struct s3grl_graph {
@@ -113,6 +111,19 @@ struct s3grl_plan {
   float* c_coef = nullptr;       // [Σ_jobs n, K, 2]
   int64_t* row_nodes = nullptr;  // [ΣR]
   std::vector<void*> owned;      // everything above, for release
+};
+
+struct s3grl_features {
+  s3grl_context* ctx = nullptr;
+  int64_t N = 0, F = 0;
+  const float* dense = nullptr;   // 16-byte aligned rows (the caller's X or an owned padded copy)
+  int64_t ld = 0;
+  bool sparse = false;            // per-tile CSR below is populated
+  int tiles = 0;                  // column tiles of 512
+  int64_t nnz = 0;
+  const int64_t* sp_ptr = nullptr;  // [tiles*N + 1]
+  const void* sp_ent = nullptr;     // [nnz] (column-in-tile int32, value fp32)
+  std::vector<void*> owned;
 };
 
 struct s3grl_sop {
@@ -151,7 +162,9 @@ s3grl_status launch_dists(s3grl_context* ctx, const int64_t* node_off, const int
 s3grl_status launch_gather(s3grl_context* ctx, const Job* jobs, int64_t njobs, const int32_t* c_ids,
                            const float* c_coef, const float* job_z, int K, const float* X,
                            int64_t ldx, int64_t F, float* rows);
-// sop.hip
+// features.hip
+s3grl_status launch_gather_sparse(s3grl_context* ctx, const s3grl_plan* p, const s3grl_features* f,
+                                  float* rows);
 s3grl_status launch_copy_pad(s3grl_context* ctx, const float* X, int64_t ldx, int64_t N, int64_t F,
                              float* Y, int64_t ldy);
 

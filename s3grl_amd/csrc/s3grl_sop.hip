@@ -22,17 +22,6 @@
 namespace s3grl {
 namespace {
 
-// X [N, F] with arbitrary ld -> [N, ldy] with ldy % 4 == 0, padding columns zeroed.
-__global__ void copy_pad_kernel(const float* __restrict__ X, int64_t ldx, int64_t N, int64_t F,
-                                float* __restrict__ Y, int64_t ldy) {
-  const int64_t total = N * ldy;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / ldy, c = i - r * ldy;
-    Y[i] = c < F ? X[r * ldx + c] : 0.f;
-  }
-}
-
 __global__ void to_f64_pad_kernel(const float* __restrict__ X, int64_t ldx, int64_t N, int64_t F,
                                   double* __restrict__ Y, int64_t ldy) {
   const int64_t total = N * ldy;
@@ -261,16 +250,6 @@ __global__ void sop_classify_kernel(const int32_t* __restrict__ n_nodes, int64_t
 }
 
 }  // namespace
-
-s3grl_status launch_copy_pad(s3grl_context* ctx, const float* X, int64_t ldx, int64_t N, int64_t F,
-                             float* Y, int64_t ldy) {
-  const int64_t total = N * ldy;
-  if (total == 0) return S3GRL_OK;
-  const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32);
-  hipLaunchKernelGGL(copy_pad_kernel, dim3(grid), dim3(256), 0, ctx->stream, X, ldx, N, F, Y, ldy);
-  S3GRL_HIP_TRY(hipGetLastError());
-  return S3GRL_OK;
-}
 
 }  // namespace s3grl
 

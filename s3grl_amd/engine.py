@@ -65,6 +65,43 @@ class Graph:
             pass
 
 
+class Features:
+    """The feature operand x, prepared once for the gather: aligned dense rows (`mode` "auto" /
+    "dense"), or additionally sparse (column, value) rows (`mode` "sparse", opt-in: slower than
+    dense at 10 % density on MI355X)."""
+
+    _MODES = {"auto": 0, "dense": 1, "sparse": 2}
+
+    def __init__(self, engine, x, mode="auto"):
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+        self.engine, self.tensor = engine, x          # keep x alive: the handle may borrow it
+        h = C.c_void_p()
+        N.check(N.lib().s3grl_features_create(engine._ctx, _ptr(x), x.stride(0), x.shape[0],
+                                              x.shape[1], self._MODES[mode], C.byref(h)),
+                "s3grl_features_create")
+        self._h = h
+        engine._children.add(self)
+        nnz, sp = C.c_int64(), C.c_int32()
+        N.check(N.lib().s3grl_features_info(h, C.byref(nnz), C.byref(sp)), "s3grl_features_info")
+        self.nnz, self.is_sparse = int(nnz.value), bool(sp.value)
+
+    @property
+    def shape(self):
+        return self.tensor.shape
+
+    def close(self):
+        if getattr(self, "_h", None):
+            if self.engine._ctx:
+                N.lib().s3grl_features_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Plan:
     def __init__(self, engine, graph, links, cfg):
         self.engine, self.graph, self.cfg = engine, graph, cfg
@@ -102,7 +139,9 @@ class Plan:
         if x is None:
             N.check(N.ERR_NO_FEATURES, "s3grl_run")
         eng = self.engine
-        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+        feat = x if isinstance(x, Features) else None
+        if feat is None:
+            assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
         F = x.shape[1]
         K = self.cfg.sign_k
         R = self.stats["total_rows"]
@@ -110,7 +149,12 @@ class Plan:
             out = torch.empty((R, K + 1, F + 1), dtype=torch.float32, device=eng.device)
         else:
             assert out.is_contiguous() and out.numel() == R * (K + 1) * (F + 1)
-        N.check(N.lib().s3grl_run(eng._ctx, self._h, _ptr(x), x.stride(0), F, _ptr(out)), "s3grl_run")
+        if feat is not None:
+            N.check(N.lib().s3grl_run_features(eng._ctx, self._h, feat._h, _ptr(out)),
+                    "s3grl_run_features")
+        else:
+            N.check(N.lib().s3grl_run(eng._ctx, self._h, _ptr(x), x.stride(0), F, _ptr(out)),
+                    "s3grl_run")
         return out
 
     def close(self):
@@ -131,6 +175,8 @@ class Sop:
     (reference sgrl_link_pred.py:161-178 + tuned_SIGN.py:92-100 in closed form)."""
 
     def __init__(self, engine, graph, x, sign_k):
+        if isinstance(x, Features):
+            x = x.tensor
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
         self.engine, self.graph, self.sign_k = engine, graph, int(sign_k)
         self.F = int(x.shape[1])
@@ -199,9 +245,10 @@ class Engine:
         ix = torch.as_tensor(np.asarray(indices, dtype=np.int32)).to(self.device)
         return Graph(self, ip, ix, num_nodes)
 
-    def features(self, x):
-        x = torch.as_tensor(x)
-        return x.to(device=self.device, dtype=torch.float32).contiguous()
+    def features(self, x, mode="auto"):
+        """Upload x (fp32 [N,F]) and prepare it for the gather; see `Features`."""
+        x = torch.as_tensor(x).to(device=self.device, dtype=torch.float32).contiguous()
+        return Features(self, x, mode)
 
     def links(self, link_index):
         """`link_index` in the reference's layout, [2, L] (tuned_SIGN.py:147 iterates
