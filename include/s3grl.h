@@ -68,8 +68,9 @@ typedef struct s3grl_cfg {
   int32_t sign_k;    /* number of operators K >= 1 */
   int32_t strategy;  /* s3grl_strategy, PoS Plus only */
   int32_t directed;  /* must be 0 (A_csc == None in every non-ogbl-citation2 run) */
-  int32_t reserved[3]; /* [0] bit 0: exact total_sub_edges even when sign_k < num_hops (one extra
-                          pass over the outer rows); others must be 0 */
+  int32_t reserved[3]; /* [0] bit 0: per-link diagnostics — exact total_sub_edges even when
+                          sign_k < num_hops, subgraph export for every link (turns folding of
+                          reversed duplicates off); bit 1: no folding; others must be 0 */
 } s3grl_cfg;
 
 /* sizes a plan measured while extracting; the benchmark's algorithmic-bytes figure
@@ -84,7 +85,11 @@ typedef struct s3grl_plan_stats {
   int64_t num_row_pairs;    /* gather jobs */
   int64_t max_nodes;        /* max n */
   int64_t workspace_bytes;  /* device bytes held by the plan + context arena */
-  int64_t reserved[3];
+  int64_t folded_links;     /* links (d,s) served by the extraction of their reversed duplicate
+                               (s,d) earlier in the list: same subgraph, rows swapped.  The
+                               totals above count them like any other link (algorithmic). */
+  int64_t extracted_nodes;  /* Σ n over the links actually extracted */
+  int64_t reserved[1];
 } s3grl_plan_stats;
 
 typedef struct s3grl_context s3grl_context; /* device, stream, workspace arena */

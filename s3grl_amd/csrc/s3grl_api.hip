@@ -302,13 +302,29 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   S3GRL_TRY(arena_alloc(ctx, (size_t)scan_workspace_elems(L), &scan_ws, tr));
 
   // d_scalars (int64 x 32): [0] err flag, [1] max n, [2] Σ edges, [3] Σ support, [4] Σ vol,
-  // [5] max R, [8..15] class counts (int32 x 16)
+  // [5] max R, [6] Σ n counting folded links twice, [7] folded links, [8..15] class counts
   int64_t* ds = ctx->d_scalars;
   int64_t* hs = ctx->h_scalars;
   class_count = reinterpret_cast<int32_t*>(ds + 8);
   S3GRL_HIP_TRY(hipMemsetAsync(ds, 0, 32 * sizeof(int64_t), ctx->stream));
-  S3GRL_TRY(launch_count(ctx, g, plan->links, L, cfg->num_hops, plus ? 1 : 0, K, plan->n_nodes,
-                         p_nodes, n_rows, n_jobs, reinterpret_cast<int32_t*>(ds), ds + 4));
+  // reversed duplicates (both directions of a train edge) are folded into one extraction
+  int32_t *partner = nullptr, *mirror_of = nullptr;
+  const bool fold = !(cfg->reserved[0] & 3) && !getenv("S3GRL_NO_MIRROR");
+  if (fold) {
+    uint64_t* keys;
+    int32_t* vals;
+    const int64_t slots = mirror_table_slots(L);
+    S3GRL_TRY(arena_alloc(ctx, (size_t)slots, &keys, tr));
+    S3GRL_TRY(arena_alloc(ctx, (size_t)slots, &vals, tr));
+    S3GRL_TRY(arena_alloc(ctx, (size_t)L, &partner, tr));
+    S3GRL_TRY(arena_alloc(ctx, (size_t)L, &mirror_of, tr));
+    S3GRL_TRY(launch_find_mirrors(ctx, plan->links, L, g->num_nodes, keys, vals, slots, partner,
+                                  mirror_of, ds + 7));
+  }
+  S3GRL_TRY(launch_count(ctx, g, plan->links, L, cfg->num_hops, plus ? 1 : 0, K, partner, mirror_of,
+                         plan->n_nodes, p_nodes, n_rows, n_jobs, reinterpret_cast<int32_t*>(ds),
+                         ds + 4, ds + 6));
+  if (fold) S3GRL_TRY(launch_mirror_rows(ctx, partner, L, n_rows));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, plan->n_nodes, L, plan->node_off, scan_ws));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_rows, L, plan->row_ptr, scan_ws));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_jobs, L, plan->job_off, scan_ws));
@@ -346,15 +362,17 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
     for (int c = 0; c <= kNumClasses; ++c) fprintf(stderr, " %d", class_count_host[c]);
     fprintf(stderr, "\n");
   }
-  plan->stats.total_nodes = tot_n;
+  plan->stats.total_nodes = hs[6];          // algorithmic: a folded link counts like any other
   plan->stats.total_volume = tot_vol;
+  plan->stats.folded_links = hs[7];
+  plan->stats.extracted_nodes = tot_n;
   plan->stats.max_nodes = max_n;
   plan->stats.total_rows = tot_rows;
   plan->stats.num_row_pairs = njobs;
   plan->njobs = njobs;
 
   // coefficient lists: one per row pair, sized by the link's node count
-  const int64_t* coef_off = plan->node_off;   // PoS: job == link
+  const int64_t* coef_off = nullptr;          // PoS: one pair per link, list at node_off[link]
   int64_t tot_coef = tot_n;
   if (plus) {
     int32_t* job_n;
@@ -380,8 +398,9 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   S3GRL_TRY(record(ctx, 1));
   S3GRL_TRY(launch_links(ctx, g, plan->links, L, class_list, class_count_host, cfg->num_hops,
                          plus ? 1 : 0, cn_cap, cfg->reserved[0] & 1, K, p_nodes, plan->node_off,
-                         plan->row_ptr, plan->job_off, coef_off, plan->c_ids, plan->c_coef,
-                         plan->jobs, plan->job_z, plan->row_nodes, plan->lvl, ds + 2, ds + 3));
+                         plan->row_ptr, plan->job_off, coef_off, mirror_of, plan->c_ids,
+                         plan->c_coef, plan->jobs, plan->job_z, plan->row_nodes, plan->lvl, ds + 2,
+                         ds + 3));
   S3GRL_TRY(record(ctx, 2));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs + 2, ds + 2, 2 * 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -427,7 +446,7 @@ s3grl_status s3grl_plan_export_subgraphs(const s3grl_plan* p, int64_t* node_ptr,
   hipStream_t st = p->ctx->stream;
   S3GRL_HIP_TRY(hipMemcpyAsync(node_ptr, p->node_off, (size_t)(p->L + 1) * 8,
                                hipMemcpyDeviceToDevice, st));
-  const size_t n = (size_t)p->stats.total_nodes;
+  const size_t n = (size_t)p->stats.extracted_nodes;
   if (nodes && n) S3GRL_HIP_TRY(hipMemcpyAsync(nodes, p->c_ids, n * 4, hipMemcpyDeviceToDevice, st));
   if (dists && n) S3GRL_TRY(launch_dists(p->ctx, p->node_off, p->lvl, p->L, dists));
   return S3GRL_OK;

@@ -170,26 +170,31 @@ __global__ __launch_bounds__(256) void gather_sparse_kernel(
     }
   }
 
-  // epilogue: same output contract as the dense kernel
+  // epilogue: same output contract as the dense kernel (incl. the folded reversed duplicate)
   const int Fp = F + 1;
   const int64_t rstride = (int64_t)(K + 1) * Fp;
   const int nrow = job.node_b >= 0 ? 2 : 1;
+  const int ncopy = job.mirror_row >= 0 ? 2 : 1;
   for (int r = 0; r < nrow; ++r) {
-    float* __restrict__ out = rows + (job.out_row + r) * rstride;
     const int node = r == 0 ? job.node_a : job.node_b;
     const float* __restrict__ xr = X + (int64_t)node * ldx + col0;
-    for (int c = lane; c < width; c += 64) {
-      out[1 + col0 + c] = xr[c];
+    for (int m = 0; m < ncopy; ++m) {
+      const int64_t orow = m == 0 ? job.out_row + r
+                                  : job.mirror_row + (job.mirror_swap ? 1 - r : r);
+      float* __restrict__ out = rows + orow * rstride;
+      for (int c = lane; c < width; c += 64) {
+        out[1 + col0 + c] = xr[c];
 #pragma unroll
-      for (int i = 0; i < K; ++i) {
-        const float2 a = acc[c * K + i];
-        out[(int64_t)(i + 1) * Fp + 1 + col0 + c] = r == 0 ? a.x : a.y;
+        for (int i = 0; i < K; ++i) {
+          const float2 a = acc[c * K + i];
+          out[(int64_t)(i + 1) * Fp + 1 + col0 + c] = r == 0 ? a.x : a.y;
+        }
       }
-    }
-    if (tile == 0 && lane <= K) {
-      const float z = lane == 0 ? (float)(r == 0 ? job.z_a : job.z_b)
-                                : job_z[((int64_t)jid * K + (lane - 1)) * 2 + r];
-      out[(int64_t)lane * Fp] = z;
+      if (tile == 0 && lane <= K) {
+        const float z = lane == 0 ? (float)(r == 0 ? job.z_a : job.z_b)
+                                  : job_z[((int64_t)jid * K + (lane - 1)) * 2 + r];
+        out[(int64_t)lane * Fp] = z;
+      }
     }
   }
 }

@@ -51,6 +51,10 @@ struct Job {
   int32_t node_b;     // global id of row b, or -1 when the pair has a single row
   int32_t z_a;        // label column of operator 0 (1 for src/dst)
   int32_t z_b;
+  int64_t mirror_row; // first output row of the same pair of the REVERSED link (dst,src) when
+                      // that link is in the list too and was folded into this one, else -1
+  int32_t mirror_swap;// rows a,b go to mirror_row+1, mirror_row (the src/dst pair), else same order
+  int32_t pad;
 };
 
 // Grow-only caching device allocator: plans are created and destroyed every benchmark step,
@@ -141,8 +145,18 @@ namespace s3grl {
 
 // structure.hip
 s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
-                          int hops, int plus, int K, int32_t* n_nodes, int32_t* p_nodes,
-                          int32_t* n_rows, int32_t* n_jobs, int32_t* err_flag, int64_t* tot_vol);
+                          int hops, int plus, int K, const int32_t* partner,
+                          const int32_t* mirror_of, int32_t* n_nodes, int32_t* p_nodes,
+                          int32_t* n_rows, int32_t* n_jobs, int32_t* err_flag, int64_t* tot_vol,
+                          int64_t* tot_nodes_alg);
+// folds a reversed duplicate (dst,src) of a link (src,dst) into it: partner[l] = primary of a
+// folded link (else -1), mirror_of[l] = the link folded into l (else -1)
+int64_t mirror_table_slots(int64_t L);
+s3grl_status launch_find_mirrors(s3grl_context* ctx, const int64_t* links, int64_t L, int64_t N,
+                                 uint64_t* keys, int32_t* vals, int64_t slots, int32_t* partner,
+                                 int32_t* mirror_of, int64_t* n_mirrored);
+s3grl_status launch_mirror_rows(s3grl_context* ctx, const int32_t* partner, int64_t L,
+                                int32_t* n_rows);
 int64_t scan_workspace_elems(int64_t n);
 s3grl_status launch_scan_i32_to_i64(s3grl_context* ctx, const int32_t* in, int64_t n, int64_t* out,
                                     int64_t* workspace);
@@ -153,9 +167,9 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           const int32_t* class_list, const int32_t* class_count_host, int hops,
                           int plus, int cn_cap, int full_stats, int K, const int32_t* p_nodes,
                           const int64_t* node_off, const int64_t* row_ptr, const int64_t* job_off,
-                          const int64_t* coef_off, int32_t* c_ids, float* c_coef, Job* jobs,
-                          float* job_z, int64_t* row_nodes, int32_t* lvl, int64_t* tot_edges,
-                          int64_t* tot_support);
+                          const int64_t* coef_off, const int32_t* mirror_of, int32_t* c_ids,
+                          float* c_coef, Job* jobs, float* job_z, int64_t* row_nodes, int32_t* lvl,
+                          int64_t* tot_edges, int64_t* tot_support);
 s3grl_status launch_dists(s3grl_context* ctx, const int64_t* node_off, const int32_t* lvl, int64_t L,
                           int8_t* dists);
 // gather.hip

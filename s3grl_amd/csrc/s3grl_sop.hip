@@ -357,8 +357,8 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
   if (ctx->profiling) S3GRL_HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
   S3GRL_HIP_TRY(hipMemsetAsync(ds, 0, 32 * sizeof(int64_t), ctx->stream));
   // the ⌈K/2⌉-hop ball of {s,d}: same BFS as PoS, no row selection
-  S3GRL_TRY(launch_count(ctx, g, links, L, HB, 0, 1, n_nodes, p_nodes, n_rows, n_jobs,
-                         reinterpret_cast<int32_t*>(ds), ds + 4));
+  S3GRL_TRY(launch_count(ctx, g, links, L, HB, 0, 1, nullptr, nullptr, n_nodes, p_nodes, n_rows,
+                         n_jobs, reinterpret_cast<int32_t*>(ds), ds + 4, ds + 6));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_nodes, L, node_off, scan_ws));
   const int fixed = 4 * (3 * W + kMaxLevels + 32 + 6 * 16) + 64;
   const int per_node = 4 + 16 * HB;

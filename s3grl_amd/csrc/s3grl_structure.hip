@@ -64,9 +64,11 @@ __device__ __forceinline__ int common_neighbours(const int32_t* __restrict__ ind
 // non-zero entry of r_{K-1}: the only nodes link_kernel keeps propagation state for.
 __global__ __launch_bounds__(kBlock) void count_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int N, int W,
-    const int64_t* __restrict__ links, int hops, int plus, int K, int32_t* __restrict__ n_nodes,
-    int32_t* __restrict__ p_nodes, int32_t* __restrict__ n_rows, int32_t* __restrict__ n_jobs,
-    int32_t* __restrict__ err_flag, unsigned long long* __restrict__ tot_vol) {
+    const int64_t* __restrict__ links, int hops, int plus, int K,
+    const int32_t* __restrict__ partner, const int32_t* __restrict__ mirror_of,
+    int32_t* __restrict__ n_nodes, int32_t* __restrict__ p_nodes, int32_t* __restrict__ n_rows,
+    int32_t* __restrict__ n_jobs, int32_t* __restrict__ err_flag,
+    unsigned long long* __restrict__ tot_vol, unsigned long long* __restrict__ tot_nodes_alg) {
   extern __shared__ uint32_t smem[];
   uint32_t* vis = smem;
   uint32_t* cur = smem + W;
@@ -81,6 +83,15 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
       n_nodes[l] = 0;
       p_nodes[l] = 0;
       n_rows[l] = 0;
+      n_jobs[l] = 0;
+    }
+    return;
+  }
+  if (partner && partner[l] >= 0) {  // reversed duplicate: the primary link does the work
+    if (tid == 0) {
+      n_nodes[l] = 0;
+      p_nodes[l] = 0;
+      n_rows[l] = 0;  // copied from the primary by mirror_rows_kernel
       n_jobs[l] = 0;
     }
     return;
@@ -149,8 +160,80 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
     p_nodes[l] = R > 2 ? cum_b : cum_a;
     n_rows[l] = R;
     n_jobs[l] = (R + 1) / 2;
-    atomicAdd(tot_vol, (unsigned long long)dv);
+    // algorithmic totals count a folded link as if it had been extracted on its own
+    const unsigned long long mult = (mirror_of && mirror_of[l] >= 0) ? 2ull : 1ull;
+    atomicAdd(tot_vol, mult * (unsigned long long)dv);
+    atomicAdd(tot_nodes_alg, mult * (unsigned long long)n);
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// Reversed duplicates.  The reference's train split holds BOTH directions of every train edge
+// (PyG to_undirected, consumed at utils.py:628), and the link (d,s) has exactly the subgraph,
+// the masked operator and the rows of (s,d) with src/dst swapped.  One open-addressing table
+// over the links with src < dst, one lookup per link with src > dst; at most one fold per link.
+constexpr uint64_t kEmptyKey = ~0ull;
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdull;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ull;
+  x ^= x >> 33;
+  return x;
+}
+
+__global__ void mirror_insert_kernel(const int64_t* __restrict__ links, int64_t L, int64_t N,
+                                     uint64_t* __restrict__ keys, int32_t* __restrict__ vals,
+                                     uint64_t mask) {
+  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L) return;
+  const int64_t s = links[2 * l], d = links[2 * l + 1];
+  if (s < 0 || d < 0 || s >= N || d >= N || s >= d) return;
+  const uint64_t key = ((uint64_t)s << 32) | (uint64_t)d;
+  uint64_t slot = mix64(key) & mask;
+  for (;;) {
+    const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[slot]), kEmptyKey, key);
+    if (old == kEmptyKey || old == key) {
+      atomicMin(&vals[slot], (int32_t)l);  // the lowest link index owns the key: deterministic
+      return;
+    }
+    slot = (slot + 1) & mask;  // the table has >= 2L slots: a free one exists
+  }
+}
+
+__global__ void mirror_lookup_kernel(const int64_t* __restrict__ links, int64_t L, int64_t N,
+                                     const uint64_t* __restrict__ keys,
+                                     const int32_t* __restrict__ vals, uint64_t mask,
+                                     int32_t* __restrict__ partner, int32_t* __restrict__ mirror_of,
+                                     unsigned long long* __restrict__ n_mirrored) {
+  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L) return;
+  const int64_t s = links[2 * l], d = links[2 * l + 1];
+  if (s < 0 || d < 0 || s >= N || d >= N || s <= d) return;
+  const uint64_t key = ((uint64_t)d << 32) | (uint64_t)s;
+  uint64_t slot = mix64(key) & mask;
+  for (;;) {
+    const uint64_t k = keys[slot];
+    if (k == kEmptyKey) return;
+    if (k == key) {
+      const int32_t P = vals[slot];
+      if (atomicCAS(&mirror_of[P], -1, (int32_t)l) == -1) {
+        partner[l] = P;
+        atomicAdd(n_mirrored, 1ull);
+      }
+      return;
+    }
+    slot = (slot + 1) & mask;
+  }
+}
+
+__global__ void mirror_rows_kernel(const int32_t* __restrict__ partner, int64_t L,
+                                   int32_t* __restrict__ n_rows) {
+  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L) return;
+  const int32_t P = partner[l];
+  if (P >= 0) n_rows[l] = n_rows[P];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -266,15 +349,18 @@ __global__ __launch_bounds__(T) void link_kernel(
     int cn_cap, int full_stats, const int32_t* __restrict__ p_nodes,
     const int64_t* __restrict__ node_off, const int64_t* __restrict__ row_ptr,
     const int64_t* __restrict__ job_off, const int64_t* __restrict__ coef_off,
-    int32_t* __restrict__ c_ids, float* __restrict__ c_coef, Job* __restrict__ jobs,
-    float* __restrict__ job_z, int64_t* __restrict__ row_nodes, int32_t* __restrict__ lvl_out,
-    unsigned long long* __restrict__ tot_edges, unsigned long long* __restrict__ tot_support) {
+    const int32_t* __restrict__ mirror_of, int32_t* __restrict__ c_ids, float* __restrict__ c_coef,
+    Job* __restrict__ jobs, float* __restrict__ job_z, int64_t* __restrict__ row_nodes,
+    int32_t* __restrict__ lvl_out, unsigned long long* __restrict__ tot_edges,
+    unsigned long long* __restrict__ tot_support) {
   extern __shared__ uint32_t smem[];
   const int tid = threadIdx.x;
   const int l = class_list[blockIdx.x];
   const int64_t noff = node_off[l];
   const int n_alloc = (int)(node_off[l + 1] - noff);
   const int p_alloc = p_nodes[l];
+  const int mirror = mirror_of ? mirror_of[l] : -1;          // reversed duplicate folded into l
+  const int64_t mrp = mirror >= 0 ? row_ptr[mirror] : -1;
 
   uint32_t* vis = smem;
   uint32_t* inP = smem + W;
@@ -325,7 +411,10 @@ __global__ __launch_bounds__(T) void link_kernel(
   if (tid == 0)
     for (int d = 0; d < kMaxLevels; ++d)
       lvl_out[(int64_t)l * kMaxLevels + d] = d < nlev ? lvl_end[d] : n;
-  for (int r = tid; r < R; r += T) row_nodes[rp + r] = r == 0 ? src : (r == 1 ? dst : cn[r - 2]);
+  for (int r = tid; r < R; r += T) {
+    row_nodes[rp + r] = r == 0 ? src : (r == 1 ? dst : cn[r - 2]);
+    if (mirror >= 0) row_nodes[mrp + r] = r == 0 ? dst : (r == 1 ? src : cn[r - 2]);
+  }
 
   // ---- D^-1/2 on P (inf -> 0) -------------------------------------------------------------
   // reference tuned_SIGN.py:153-161: structure only, target link removed, no self-loops added
@@ -361,7 +450,8 @@ __global__ __launch_bounds__(T) void link_kernel(
   const int npairs = (R + 1) / 2;
   for (int pr = 0; pr < npairs; ++pr) {
     const int64_t jid = job_off[l] + pr;
-    const int64_t coff = coef_off[jid];
+    // PoS: one pair per link, its list sits at the link's node offset; PoS Plus: per-pair offsets
+    const int64_t coff = coef_off ? coef_off[jid] : noff;
     const int node_a = pr == 0 ? src : cn[2 * pr - 2];
     const int node_b = pr == 0 ? dst : (2 * pr + 1 < R ? cn[2 * pr - 1] : -1);
     const int row_hop = pr == 0 ? 0 : 1;
@@ -489,15 +579,18 @@ __global__ __launch_bounds__(T) void link_kernel(
       j.node_b = node_b;
       j.z_a = (node_a == src || node_a == dst) ? 1 : 0;
       j.z_b = (node_b == src || node_b == dst) ? 1 : 0;
+      j.mirror_row = mirror >= 0 ? mrp + 2 * pr : -1;
+      j.mirror_swap = pr == 0 ? 1 : 0;
+      j.pad = 0;
       jobs[jid] = j;
-      atomicAdd(tot_support, (unsigned long long)support);
+      atomicAdd(tot_support, (unsigned long long)support * (mirror >= 0 ? 2ull : 1ull));
     }
     __syncthreads();
   }
   // edges of the masked induced subgraph: exact when the last pass of pair 0 covered all of S
   // (always with full_stats; otherwise whenever K >= num_hops), else the edges of P's rows
   edges_local = block_sum<T>(edges_local, sh);
-  if (tid == 0) atomicAdd(tot_edges, (unsigned long long)edges_local);
+  if (tid == 0) atomicAdd(tot_edges, (unsigned long long)edges_local * (mirror >= 0 ? 2ull : 1ull));
 }
 
 // hop distance of every exported node from the per-link level ends
@@ -519,17 +612,53 @@ __global__ void dists_kernel(const int64_t* __restrict__ node_off, const int32_t
 // ---------------------------------------------------------------------------------------
 static inline int words_for(int64_t N) { return (int)((N + 31) / 32); }
 
+int64_t mirror_table_slots(int64_t L) {
+  int64_t s = 1024;
+  while (s < 2 * L) s <<= 1;
+  return s;
+}
+
+s3grl_status launch_find_mirrors(s3grl_context* ctx, const int64_t* links, int64_t L, int64_t N,
+                                 uint64_t* keys, int32_t* vals, int64_t slots, int32_t* partner,
+                                 int32_t* mirror_of, int64_t* n_mirrored) {
+  if (L == 0) return S3GRL_OK;
+  S3GRL_HIP_TRY(hipMemsetAsync(keys, 0xff, (size_t)slots * 8, ctx->stream));
+  S3GRL_HIP_TRY(hipMemsetAsync(vals, 0x7f, (size_t)slots * 4, ctx->stream));
+  S3GRL_HIP_TRY(hipMemsetAsync(partner, 0xff, (size_t)L * 4, ctx->stream));
+  S3GRL_HIP_TRY(hipMemsetAsync(mirror_of, 0xff, (size_t)L * 4, ctx->stream));
+  const unsigned grid = (unsigned)((L + 255) / 256);
+  hipLaunchKernelGGL(mirror_insert_kernel, dim3(grid), dim3(256), 0, ctx->stream, links, L, N, keys,
+                     vals, (uint64_t)(slots - 1));
+  hipLaunchKernelGGL(mirror_lookup_kernel, dim3(grid), dim3(256), 0, ctx->stream, links, L, N, keys,
+                     vals, (uint64_t)(slots - 1), partner, mirror_of,
+                     reinterpret_cast<unsigned long long*>(n_mirrored));
+  S3GRL_HIP_TRY(hipGetLastError());
+  return S3GRL_OK;
+}
+
+s3grl_status launch_mirror_rows(s3grl_context* ctx, const int32_t* partner, int64_t L,
+                                int32_t* n_rows) {
+  if (L == 0) return S3GRL_OK;
+  hipLaunchKernelGGL(mirror_rows_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream,
+                     partner, L, n_rows);
+  S3GRL_HIP_TRY(hipGetLastError());
+  return S3GRL_OK;
+}
+
 s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
-                          int hops, int plus, int K, int32_t* n_nodes, int32_t* p_nodes,
-                          int32_t* n_rows, int32_t* n_jobs, int32_t* err_flag, int64_t* tot_vol) {
+                          int hops, int plus, int K, const int32_t* partner,
+                          const int32_t* mirror_of, int32_t* n_nodes, int32_t* p_nodes,
+                          int32_t* n_rows, int32_t* n_jobs, int32_t* err_flag, int64_t* tot_vol,
+                          int64_t* tot_nodes_alg) {
   if (L == 0) return S3GRL_OK;
   const int W = words_for(g->num_nodes);
   const size_t lds = (size_t)(3 * W + 8) * 4;
   S3GRL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(count_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(count_kernel, dim3((unsigned)L), dim3(kBlock), lds, ctx->stream, g->indptr,
-                     g->indices, (int)g->num_nodes, W, links, hops, plus, K, n_nodes, p_nodes, n_rows,
-                     n_jobs, err_flag, reinterpret_cast<unsigned long long*>(tot_vol));
+                     g->indices, (int)g->num_nodes, W, links, hops, plus, K, partner, mirror_of, n_nodes,
+                     p_nodes, n_rows, n_jobs, err_flag, reinterpret_cast<unsigned long long*>(tot_vol),
+                     reinterpret_cast<unsigned long long*>(tot_nodes_alg));
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -593,6 +722,7 @@ struct LinkArgs {
   int hops, plus, cn_cap, full_stats;
   const int32_t* p_nodes;
   const int64_t *node_off, *row_ptr, *job_off, *coef_off;
+  const int32_t* mirror_of;
   int32_t* c_ids;
   float* c_coef;
   Job* jobs;
@@ -613,7 +743,7 @@ s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t 
   hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(T), lds, ctx->stream, a.g->indptr,
                      a.g->indices, W, a.links, a.class_list + (int64_t)cls * L, a.hops, a.plus,
                      a.cn_cap, a.full_stats, a.p_nodes, a.node_off, a.row_ptr, a.job_off, a.coef_off,
-                     a.c_ids, a.c_coef, a.jobs, a.job_z, a.row_nodes, a.lvl,
+                     a.mirror_of, a.c_ids, a.c_coef, a.jobs, a.job_z, a.row_nodes, a.lvl,
                      reinterpret_cast<unsigned long long*>(a.tot_edges),
                      reinterpret_cast<unsigned long long*>(a.tot_support));
   S3GRL_HIP_TRY(hipGetLastError());
@@ -649,9 +779,9 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           const int32_t* class_list, const int32_t* class_count_host, int hops,
                           int plus, int cn_cap, int full_stats, int K, const int32_t* p_nodes,
                           const int64_t* node_off, const int64_t* row_ptr, const int64_t* job_off,
-                          const int64_t* coef_off, int32_t* c_ids, float* c_coef, Job* jobs,
-                          float* job_z, int64_t* row_nodes, int32_t* lvl, int64_t* tot_edges,
-                          int64_t* tot_support) {
+                          const int64_t* coef_off, const int32_t* mirror_of, int32_t* c_ids,
+                          float* c_coef, Job* jobs, float* job_z, int64_t* row_nodes, int32_t* lvl,
+                          int64_t* tot_edges, int64_t* tot_support) {
   if (L == 0) return S3GRL_OK;
   if (class_count_host[kNumClasses] > 0) {
     set_last_error(std::to_string(class_count_host[kNumClasses]) +
@@ -660,7 +790,8 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
     return S3GRL_ERR_GRAPH_TOO_LARGE;
   }
   LinkArgs a{g, links, class_list, hops, plus, cn_cap, full_stats, p_nodes, node_off, row_ptr,
-             job_off, coef_off, c_ids, c_coef, jobs, job_z, row_nodes, lvl, tot_edges, tot_support};
+             job_off, coef_off, mirror_of, c_ids, c_coef, jobs, job_z, row_nodes, lvl, tot_edges,
+             tot_support};
   switch (K) {
     case 1: return launch_links_k<1>(ctx, a, L, class_count_host);
     case 2: return launch_links_k<2>(ctx, a, L, class_count_host);

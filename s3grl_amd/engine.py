@@ -129,8 +129,8 @@ class Plan:
         """(node_ptr [L+1], nodes [Σn] hop-major / ascending id per hop, dists [Σn])."""
         dev = self.engine.device
         node_ptr = torch.empty(self.num_links + 1, dtype=torch.int64, device=dev)
-        nodes = torch.empty(self.stats["total_nodes"], dtype=torch.int32, device=dev)
-        dists = torch.empty(self.stats["total_nodes"], dtype=torch.int8, device=dev)
+        nodes = torch.empty(self.stats["extracted_nodes"], dtype=torch.int32, device=dev)
+        dists = torch.empty(self.stats["extracted_nodes"], dtype=torch.int8, device=dev)
         N.check(N.lib().s3grl_plan_export_subgraphs(self._h, _ptr(node_ptr), _ptr(nodes),
                                                     _ptr(dists)), "s3grl_plan_export_subgraphs")
         return node_ptr, nodes, dists
@@ -267,7 +267,7 @@ class Engine:
 
     # ---- the batched native entry ----------------------------------------------------------
     def plan(self, graph, links, *, mode="pos", num_hops=1, sign_k=3, strategy="intersection",
-             directed=False, full_stats=False):
+             directed=False, full_stats=False, fold_reversed=True):
         cfg = N.Cfg()
         cfg.mode = {"pos": N.MODE_POS, "pos_plus": N.MODE_POS_PLUS}[mode]
         cfg.num_hops = int(num_hops)
@@ -276,7 +276,9 @@ class Engine:
             raise NotImplementedError(f"check strat {strategy}")      # tuned_SIGN.py:235
         cfg.strategy = N.STRATEGY[strategy]
         cfg.directed = int(bool(directed))
-        cfg.reserved[0] = 1 if full_stats else 0   # exact total_sub_edges even when K < num_hops
+        # bit 0: per-link diagnostics (exact edge totals, export of every subgraph);
+        # bit 1: do not fold reversed duplicates (d,s) into (s,d)
+        cfg.reserved[0] = (1 if full_stats else 0) | (0 if fold_reversed else 2)
         return Plan(self, graph, links, cfg)
 
     def precompute(self, graph, x, links, *, mode="pos", num_hops=1, sign_k=3,

@@ -394,3 +394,32 @@ def test_centre_pool_forward_backward(eng, H, strategy):
     assert torch.equal(row_ptr_from_batch(batch), rp)
     with pytest.raises(NotImplementedError):
         centre_pool(ht, rp, k_heuristic=1, k_pool_strategy="concat")
+
+
+def test_reversed_duplicates_are_folded_bit_exactly(eng):
+    """(d,s) after (s,d) in the list is served by one extraction; the result must be bit-identical
+    to computing every link on its own (fold_reversed=False), for PoS and PoS Plus."""
+    import torch
+
+    g = load_extract("usair")
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = np.random.default_rng(9).standard_normal((n, 33))
+    base = g["links"][:20]
+    links = np.concatenate([base, base[::-1, ::-1], base[:5], base[:3, ::-1]])   # reversed + repeats
+    G = eng.graph(A)
+    f = eng.features(X)
+    L = eng.links(links.T.copy())
+    for mode in ("pos", "pos_plus"):
+        outs = []
+        for fold in (True, False):
+            plan = eng.plan(G, L, mode=mode, num_hops=2, sign_k=3, fold_reversed=fold)
+            outs.append((plan.run(f), plan.row_ptr(), plan.row_nodes(), dict(plan.stats)))
+            plan.close()
+        (r1, p1, n1, s1), (r0, p0, n0, s0) = outs
+        assert s1["folded_links"] >= 20 and s0["folded_links"] == 0
+        assert torch.equal(p1, p0) and torch.equal(n1, n0) and torch.equal(r1, r0)
+        for k in ("total_nodes", "total_volume", "total_support", "total_rows"):
+            assert s1[k] == s0[k], k                       # algorithmic totals do not change
+        assert s1["extracted_nodes"] < s0["extracted_nodes"]
+    G.close()
