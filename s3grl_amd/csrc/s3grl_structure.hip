@@ -62,6 +62,9 @@ __device__ __forceinline__ int common_neighbours(const int32_t* __restrict__ ind
 // utils.py:53-74: `fringe = neighbors(fringe, A) - visited`, early break on an empty fringe).
 // Outputs per link: n = |S|, R rows, and p = |P|, the hop-major prefix of S that can carry a
 // non-zero entry of r_{K-1}: the only nodes link_kernel keeps propagation state for.
+constexpr int kCountList = 3072;
+
+template <int G>
 __global__ __launch_bounds__(kBlock) void count_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int N, int W,
     const int64_t* __restrict__ links, int hops, int plus, int K,
@@ -97,6 +100,7 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
     return;
   }
   const int src = (int)s64, dst = (int)d64;
+  int32_t* list = reinterpret_cast<int32_t*>(sh + 8);   // frontier nodes of the levels < hops
   for (int t = tid; t < W; t += kBlock) {
     vis[t] = 0;
     cur[t] = 0;
@@ -106,38 +110,80 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
   if (tid == 0) {
     atomicOr(&vis[src >> 5], 1u << (src & 31));
     atomicOr(&vis[dst >> 5], 1u << (dst & 31));
-    atomicOr(&cur[src >> 5], 1u << (src & 31));
-    atomicOr(&cur[dst >> 5], 1u << (dst & 31));
+    list[0] = src;
+    list[1] = dst;
   }
   __syncthreads();
-  // cum_a / cum_b: nodes within K-1 / K hops (what P is for a row at hop 0 / hop 1)
-  int n = 2, cum_a = 2, cum_b = 2;
+  // The frontier is a node list (G lanes per node: no serial row walks) as long as the levels
+  // below `hops` fit kCountList entries; beyond that it degrades to a bitmap walked one thread
+  // per word.  cum_a / cum_b: nodes within K-1 / K hops (P for a row at hop 0 / hop 1).
+  const int g = tid & (G - 1);
+  int n = 2, cum_a = 2, cum_b = 2, f0 = 0, f1 = 2;
+  bool use_list = true;
   for (int d = 1; d <= hops; ++d) {
-    for (int t = tid; t < W; t += kBlock) {
-      uint32_t w = cur[t];
-      while (w) {
-        const int b = __ffs(w) - 1;
-        w &= w - 1;
-        const int v = t * 32 + b;
-        const int e1 = indptr[v + 1];
-        for (int e = indptr[v]; e < e1; ++e) {
-          const int u = indices[e];
-          const uint32_t m = 1u << (u & 31);
-          const uint32_t old = atomicOr(&vis[u >> 5], m);
-          if (!(old & m)) atomicOr(&nxt[u >> 5], m);
+    if (use_list) {
+      for (int base = f0; base < f1; base += kBlock / G) {
+        const int t = base + tid / G;
+        if (t < f1) {
+          const int v = list[t];
+          const int e1 = indptr[v + 1];
+          for (int c = indptr[v] + g; c < e1; c += G) {
+            const int u = indices[c];
+            const uint32_t m = 1u << (u & 31);
+            const uint32_t old = atomicOr(&vis[u >> 5], m);
+            if (!(old & m)) atomicOr(&nxt[u >> 5], m);
+          }
+        }
+      }
+    } else {
+      for (int t = tid; t < W; t += kBlock) {
+        uint32_t w = cur[t];
+        while (w) {
+          const int b = __ffs(w) - 1;
+          w &= w - 1;
+          const int v = t * 32 + b;
+          const int e1 = indptr[v + 1];
+          for (int e = indptr[v]; e < e1; ++e) {
+            const int u = indices[e];
+            const uint32_t m = 1u << (u & 31);
+            const uint32_t old = atomicOr(&vis[u >> 5], m);
+            if (!(old & m)) atomicOr(&nxt[u >> 5], m);
+          }
         }
       }
     }
     __syncthreads();
     int added = 0;
-    for (int t = tid; t < W; t += kBlock) {
-      const uint32_t c = nxt[t];
-      cur[t] = c;
-      nxt[t] = 0;
-      added += __popc(c);
-    }
+    for (int t = tid; t < W; t += kBlock) added += __popc(nxt[t]);
     added = block_sum<kBlock>(added, sh);
     if (added == 0) break;
+    if (d < hops) {  // the new level is the next frontier
+      if (use_list && f1 + added <= kCountList) {
+        int done = 0;
+        for (int base = 0; base < W; base += kBlock) {
+          const int t = base + tid;
+          uint32_t w = t < W ? nxt[t] : 0u;
+          int total;
+          int pos = f1 + done + block_excl_scan<kBlock>(__popc(w), sh, total);
+          while (w) {
+            const int b = __ffs(w) - 1;
+            w &= w - 1;
+            list[pos++] = t * 32 + b;
+          }
+          if (t < W) nxt[t] = 0;
+          done += total;
+        }
+        f0 = f1;
+        f1 += added;
+      } else {
+        use_list = false;
+        for (int t = tid; t < W; t += kBlock) {
+          cur[t] = nxt[t];
+          nxt[t] = 0;
+        }
+      }
+      __syncthreads();
+    }
     n += added;
     if (d <= K - 1) cum_a = n;
     if (d <= K) cum_b = n;
@@ -652,10 +698,12 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           int64_t* tot_nodes_alg) {
   if (L == 0) return S3GRL_OK;
   const int W = words_for(g->num_nodes);
-  const size_t lds = (size_t)(3 * W + 8) * 4;
-  S3GRL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(count_kernel),
+  const size_t lds = (size_t)(3 * W + 8 + kCountList) * 4;
+  const bool sparse = (double)g->nnz / (double)std::max<int64_t>(g->num_nodes, 1) <= 6.0;
+  auto kern = sparse ? count_kernel<4> : count_kernel<8>;
+  S3GRL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(count_kernel, dim3((unsigned)L), dim3(kBlock), lds, ctx->stream, g->indptr,
+  hipLaunchKernelGGL(kern, dim3((unsigned)L), dim3(kBlock), lds, ctx->stream, g->indptr,
                      g->indices, (int)g->num_nodes, W, links, hops, plus, K, partner, mirror_of, n_nodes,
                      p_nodes, n_rows, n_jobs, err_flag, reinterpret_cast<unsigned long long*>(tot_vol),
                      reinterpret_cast<unsigned long long*>(tot_nodes_alg));
