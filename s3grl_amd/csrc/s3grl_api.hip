@@ -323,7 +323,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   }
   S3GRL_TRY(launch_count(ctx, g, plan->links, L, cfg->num_hops, plus ? 1 : 0, K, partner, mirror_of,
                          plan->n_nodes, p_nodes, n_rows, n_jobs, reinterpret_cast<int32_t*>(ds),
-                         ds + 4, ds + 6));
+                         ds + 6));
   if (fold) S3GRL_TRY(launch_mirror_rows(ctx, partner, L, n_rows));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, plan->n_nodes, L, plan->node_off, scan_ws));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_rows, L, plan->row_ptr, scan_ws));
@@ -347,7 +347,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
     set_last_error("a link endpoint is outside [0, num_nodes)");
     return S3GRL_ERR_INVALID_ARGUMENT;
   }
-  const int64_t max_n = hs[1], tot_vol = hs[4], max_R = hs[5];
+  const int64_t max_n = hs[1], max_R = hs[5];
   const int64_t tot_n = hs[16], tot_rows = hs[17], njobs = hs[18];
   const int cn_cap = (int)std::max<int64_t>(max_R - 2, 0) + 1;
   if (plus) {
@@ -363,7 +363,6 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
     fprintf(stderr, "\n");
   }
   plan->stats.total_nodes = hs[6];          // algorithmic: a folded link counts like any other
-  plan->stats.total_volume = tot_vol;
   plan->stats.folded_links = hs[7];
   plan->stats.extracted_nodes = tot_n;
   plan->stats.max_nodes = max_n;
@@ -400,12 +399,13 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
                          plus ? 1 : 0, cn_cap, cfg->reserved[0] & 1, K, p_nodes, plan->node_off,
                          plan->row_ptr, plan->job_off, coef_off, mirror_of, plan->c_ids,
                          plan->c_coef, plan->jobs, plan->job_z, plan->row_nodes, plan->lvl, ds + 2,
-                         ds + 3));
+                         ds + 3, ds + 4));
   S3GRL_TRY(record(ctx, 2));
-  S3GRL_HIP_TRY(hipMemcpyAsync(hs + 2, ds + 2, 2 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipMemcpyAsync(hs + 2, ds + 2, 3 * 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
   plan->stats.total_sub_edges = hs[2];
   plan->stats.total_support = hs[3];
+  plan->stats.total_volume = hs[4];
   plan->stats.workspace_bytes = (int64_t)ctx->arena.bytes_held();
   if (ctx->profiling) {
     float ms = 0;

@@ -68,6 +68,22 @@ __device__ __forceinline__ bool sorted_contains(const int32_t* a, int n, int x) 
   return lo < n && a[lo] == x;
 }
 
+// Word-level popcount prefix of a bitmap (local id = rank): thread-contiguous runs, one block scan.
+template <int T>
+__device__ __forceinline__ void rank_prefix(const uint32_t* bm, uint32_t* wpre, int W, int* sh) {
+  const int tid = threadIdx.x;
+  const int C = (W + T - 1) / T;
+  const int w0 = min(tid * C, W), w1 = min(w0 + C, W);
+  int mine = 0;
+  for (int t = w0; t < w1; ++t) mine += __popc(bm[t]);
+  int total;
+  int run = block_excl_scan<T>(mine, sh, total);
+  for (int t = w0; t < w1; ++t) {
+    wpre[t] = run;
+    run += __popc(bm[t]);
+  }
+}
+
 // Level-synchronous BFS from {src,dst} to depth `hops` on the UNMASKED graph (reference
 // utils.py:53-74: `fringe = neighbors(fringe, A) - visited`, early break on an empty fringe).
 // The frontier is a segment of `list`, G lanes per frontier node; every finished level is
@@ -111,19 +127,22 @@ __device__ __forceinline__ int bfs_list(const int32_t* __restrict__ indptr,
       }
     }
     __syncthreads();
-    int added = 0;
-    for (int base = 0; base < W; base += T) {
-      const int t = base + tid;
-      uint32_t w = t < W ? nxt[t] : 0u;
-      int total;
-      int pos = n + added + block_excl_scan<T>(__popc(w), sh, total);
+    // append the new level in ascending id order: every thread owns a contiguous run of
+    // bitmap words, one block scan over the per-thread popcounts (2 barriers per level)
+    const int C = (W + T - 1) / T;
+    const int w0 = min(tid * C, W), w1 = min(w0 + C, W);
+    int mine = 0;
+    for (int t = w0; t < w1; ++t) mine += __popc(nxt[t]);
+    int added;
+    int pos = n + block_excl_scan<T>(mine, sh, added);
+    for (int t = w0; t < w1; ++t) {
+      uint32_t w = nxt[t];
+      nxt[t] = 0;
       while (w) {
         const int b = __ffs(w) - 1;
         w &= w - 1;
         list[pos++] = t * 32 + b;
       }
-      if (t < W) nxt[t] = 0;
-      added += total;
     }
     if (added == 0) break;  // uniform: `added` is a block-wide total
     n += added;

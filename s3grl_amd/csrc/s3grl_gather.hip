@@ -59,9 +59,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_kernel(
   int j = 0;
   for (; j + kUnroll <= cnt; j += kUnroll) {
     float4_t v[kUnroll][CH];
+    int id[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) id[u] = ids[j + u];
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
-      const float* __restrict__ xr = X + (int64_t)ids[j + u] * ldx;
+      const float* __restrict__ xr = X + (int64_t)id[u] * ldx;
 #pragma unroll
       for (int c = 0; c < CH; ++c)
         v[u][c] = cok[c] ? *reinterpret_cast<const float4_t*>(xr + coff[c]) : (float4_t)(0.f);

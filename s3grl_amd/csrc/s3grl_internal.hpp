@@ -147,7 +147,7 @@ namespace s3grl {
 s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                           int hops, int plus, int K, const int32_t* partner,
                           const int32_t* mirror_of, int32_t* n_nodes, int32_t* p_nodes,
-                          int32_t* n_rows, int32_t* n_jobs, int32_t* err_flag, int64_t* tot_vol,
+                          int32_t* n_rows, int32_t* n_jobs, int32_t* err_flag,
                           int64_t* tot_nodes_alg);
 // folds a reversed duplicate (dst,src) of a link (src,dst) into it: partner[l] = primary of a
 // folded link (else -1), mirror_of[l] = the link folded into l (else -1)
@@ -169,7 +169,7 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           const int64_t* node_off, const int64_t* row_ptr, const int64_t* job_off,
                           const int64_t* coef_off, const int32_t* mirror_of, int32_t* c_ids,
                           float* c_coef, Job* jobs, float* job_z, int64_t* row_nodes, int32_t* lvl,
-                          int64_t* tot_edges, int64_t* tot_support);
+                          int64_t* tot_edges, int64_t* tot_support, int64_t* tot_vol);
 s3grl_status launch_dists(s3grl_context* ctx, const int64_t* node_off, const int32_t* lvl, int64_t L,
                           int8_t* dists);
 // gather.hip

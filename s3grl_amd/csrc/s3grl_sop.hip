@@ -104,17 +104,7 @@ __global__ __launch_bounds__(T) void sop_scalar_kernel(
   const int g = tid & (G - 1);
   int nlev;
   const int n = bfs_list<T, G>(indptr, indices, W, src, dst, HB, vis, nxt, list, lvl_end, sh, nlev);
-  {
-    int carry = 0;
-    for (int base = 0; base < W; base += T) {
-      const int t = base + tid;
-      const int pc = t < W ? __popc(vis[t]) : 0;
-      int total;
-      const int ex = block_excl_scan<T>(pc, sh, total);
-      if (t < W) wpre[t] = carry + ex;
-      carry += total;
-    }
-  }
+  rank_prefix<T>(vis, wpre, W, sh);
   for (int w = tid; w < n * HB; w += T) r[w] = make_double2(0.0, 0.0);
   __syncthreads();
   const int sl = rank_of(vis, wpre, src), dl = rank_of(vis, wpre, dst);
@@ -358,7 +348,7 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
   S3GRL_HIP_TRY(hipMemsetAsync(ds, 0, 32 * sizeof(int64_t), ctx->stream));
   // the ⌈K/2⌉-hop ball of {s,d}: same BFS as PoS, no row selection
   S3GRL_TRY(launch_count(ctx, g, links, L, HB, 0, 1, nullptr, nullptr, n_nodes, p_nodes, n_rows,
-                         n_jobs, reinterpret_cast<int32_t*>(ds), ds + 4, ds + 6));
+                         n_jobs, reinterpret_cast<int32_t*>(ds), ds + 6));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_nodes, L, node_off, scan_ws));
   const int fixed = 4 * (3 * W + kMaxLevels + 32 + 6 * 16) + 64;
   const int per_node = 4 + 16 * HB;

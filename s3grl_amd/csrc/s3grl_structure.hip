@@ -13,6 +13,8 @@
 // Restates (not translates) reference utils.py:47-85 (k_hop_subgraph), utils.py:33-44
 // (neighbors) and tuned_SIGN.py:151-175 / :206-240: the reference materialises Â², …, Â^K of
 // the whole n×n subgraph by SpGEMM and keeps R rows; here only those R rows are ever formed.
+#include <cstdlib>
+
 #include "s3grl_internal.hpp"
 #include "s3grl_device.hpp"
 
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
     const int32_t* __restrict__ partner, const int32_t* __restrict__ mirror_of,
     int32_t* __restrict__ n_nodes, int32_t* __restrict__ p_nodes, int32_t* __restrict__ n_rows,
     int32_t* __restrict__ n_jobs, int32_t* __restrict__ err_flag,
-    unsigned long long* __restrict__ tot_vol, unsigned long long* __restrict__ tot_nodes_alg) {
+    unsigned long long* __restrict__ tot_nodes_alg) {
   extern __shared__ uint32_t smem[];
   uint32_t* vis = smem;
   uint32_t* cur = smem + W;
@@ -153,31 +155,30 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
       }
     }
     __syncthreads();
-    int added = 0;
-    for (int t = tid; t < W; t += kBlock) added += __popc(nxt[t]);
-    added = block_sum<kBlock>(added, sh);
+    // every thread owns a contiguous run of bitmap words: one block scan per level
+    const int C = (W + kBlock - 1) / kBlock;
+    const int w0 = min(tid * C, W), w1 = min(w0 + C, W);
+    int mine = 0;
+    for (int t = w0; t < w1; ++t) mine += __popc(nxt[t]);
+    int added;
+    int pos = f1 + block_excl_scan<kBlock>(mine, sh, added);
     if (added == 0) break;
     if (d < hops) {  // the new level is the next frontier
       if (use_list && f1 + added <= kCountList) {
-        int done = 0;
-        for (int base = 0; base < W; base += kBlock) {
-          const int t = base + tid;
-          uint32_t w = t < W ? nxt[t] : 0u;
-          int total;
-          int pos = f1 + done + block_excl_scan<kBlock>(__popc(w), sh, total);
+        for (int t = w0; t < w1; ++t) {
+          uint32_t w = nxt[t];
+          nxt[t] = 0;
           while (w) {
             const int b = __ffs(w) - 1;
             w &= w - 1;
             list[pos++] = t * 32 + b;
           }
-          if (t < W) nxt[t] = 0;
-          done += total;
         }
         f0 = f1;
         f1 += added;
       } else {
         use_list = false;
-        for (int t = tid; t < W; t += kBlock) {
+        for (int t = w0; t < w1; ++t) {
           cur[t] = nxt[t];
           nxt[t] = 0;
         }
@@ -188,17 +189,6 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
     if (d <= K - 1) cum_a = n;
     if (d <= K) cum_b = n;
   }
-  int dv = 0;
-  for (int t = tid; t < W; t += kBlock) {
-    uint32_t w = vis[t];
-    while (w) {
-      const int b = __ffs(w) - 1;
-      w &= w - 1;
-      const int v = t * 32 + b;
-      dv += indptr[v + 1] - indptr[v];
-    }
-  }
-  dv = block_sum<kBlock>(dv, sh);
   int R = 2;
   if (plus && wave_id() == 0) R = 2 + common_neighbours(indptr, indices, vis, src, dst, nullptr);
   if (tid == 0) {
@@ -208,7 +198,6 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
     n_jobs[l] = (R + 1) / 2;
     // algorithmic totals count a folded link as if it had been extracted on its own
     const unsigned long long mult = (mirror_of && mirror_of[l] >= 0) ? 2ull : 1ull;
-    atomicAdd(tot_vol, mult * (unsigned long long)dv);
     atomicAdd(tot_nodes_alg, mult * (unsigned long long)n);
   }
 }
@@ -392,13 +381,13 @@ template <int T, int K, int G>
 __global__ __launch_bounds__(T) void link_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int W,
     const int64_t* __restrict__ links, const int32_t* __restrict__ class_list, int hops, int plus,
-    int cn_cap, int full_stats, const int32_t* __restrict__ p_nodes,
+    int cn_cap, int full_stats, int debug_stop, const int32_t* __restrict__ p_nodes,
     const int64_t* __restrict__ node_off, const int64_t* __restrict__ row_ptr,
     const int64_t* __restrict__ job_off, const int64_t* __restrict__ coef_off,
     const int32_t* __restrict__ mirror_of, int32_t* __restrict__ c_ids, float* __restrict__ c_coef,
     Job* __restrict__ jobs, float* __restrict__ job_z, int64_t* __restrict__ row_nodes,
     int32_t* __restrict__ lvl_out, unsigned long long* __restrict__ tot_edges,
-    unsigned long long* __restrict__ tot_support) {
+    unsigned long long* __restrict__ tot_support, unsigned long long* __restrict__ tot_vol) {
   extern __shared__ uint32_t smem[];
   const int tid = threadIdx.x;
   const int l = class_list[blockIdx.x];
@@ -428,6 +417,7 @@ __global__ __launch_bounds__(T) void link_kernel(
   int nlev;
   const int n = bfs_list<T, G>(indptr, indices, W, src, dst, hops, vis, inP, list, lvl_end, sh, nlev);
 
+  if (debug_stop == 1) return;  // profiling aid: BFS only
   // ---- rows of this link ----------------------------------------------------------------
   const int64_t rp = row_ptr[l];
   const int R = (int)(row_ptr[l + 1] - rp);
@@ -439,20 +429,15 @@ __global__ __launch_bounds__(T) void link_kernel(
     const int v = list[t];
     atomicOr(&inP[v >> 5], 1u << (v & 31));
   }
-  for (int t = tid; t < n; t += T) c_ids[noff + t] = list[t];
+  int vol_local = 0;   // vol(S) = Σ global degrees, the 4·vol(S) term of the algorithmic bytes
+  for (int t = tid; t < n; t += T) {
+    const int v = list[t];
+    c_ids[noff + t] = v;
+    vol_local += indptr[v + 1] - indptr[v];
+  }
   if (plus && wave_id() == 0) common_neighbours(indptr, indices, vis, src, dst, cn);
   __syncthreads();
-  {
-    int carry = 0;
-    for (int base = 0; base < W; base += T) {
-      const int t = base + tid;
-      const int pc = t < W ? __popc(inP[t]) : 0;
-      int total;
-      const int ex = block_excl_scan<T>(pc, sh, total);
-      if (t < W) wpreP[t] = carry + ex;
-      carry += total;
-    }
-  }
+  rank_prefix<T>(inP, wpreP, W, sh);
   __syncthreads();
   if (tid == 0)
     for (int d = 0; d < kMaxLevels; ++d)
@@ -462,6 +447,7 @@ __global__ __launch_bounds__(T) void link_kernel(
     if (mirror >= 0) row_nodes[mrp + r] = r == 0 ? dst : (r == 1 ? src : cn[r - 2]);
   }
 
+  if (debug_stop == 2) return;  // + P bitmap / ranks / lists
   // ---- D^-1/2 on P (inf -> 0) -------------------------------------------------------------
   // reference tuned_SIGN.py:153-161: structure only, target link removed, no self-loops added
   int edges_local = 0;
@@ -486,6 +472,7 @@ __global__ __launch_bounds__(T) void link_kernel(
   }
   __syncthreads();
 
+  if (debug_stop == 3) return;  // + degrees on P
   // ---- per row pair: K pull steps --------------------------------------------------------
   // State s_i[u] = dinv[u]·r_i[u] for u ∈ P (float2: rows a and b of the pair):
   //   r_i[w] = dinv[w] · Σ_{u ∈ N_S(w)} s_{i-1}[u]            (Â symmetric: pull == r_{i-1}·Â)
@@ -566,6 +553,7 @@ __global__ __launch_bounds__(T) void link_kernel(
       s_in = s_out;
       s_out = tmp;
     }
+    if (debug_stop == 4) return;  // + operators 1..K-1
     {  // last operator: degree and sum of every reachable row in one pass over its CSR row
       const int i = K - 1;
       int edges_pass = 0;
@@ -636,7 +624,11 @@ __global__ __launch_bounds__(T) void link_kernel(
   // edges of the masked induced subgraph: exact when the last pass of pair 0 covered all of S
   // (always with full_stats; otherwise whenever K >= num_hops), else the edges of P's rows
   edges_local = block_sum<T>(edges_local, sh);
-  if (tid == 0) atomicAdd(tot_edges, (unsigned long long)edges_local * (mirror >= 0 ? 2ull : 1ull));
+  vol_local = block_sum<T>(vol_local, sh);
+  if (tid == 0) {
+    atomicAdd(tot_edges, (unsigned long long)edges_local * (mirror >= 0 ? 2ull : 1ull));
+    atomicAdd(tot_vol, (unsigned long long)vol_local * (mirror >= 0 ? 2ull : 1ull));
+  }
 }
 
 // hop distance of every exported node from the per-link level ends
@@ -694,7 +686,7 @@ s3grl_status launch_mirror_rows(s3grl_context* ctx, const int32_t* partner, int6
 s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                           int hops, int plus, int K, const int32_t* partner,
                           const int32_t* mirror_of, int32_t* n_nodes, int32_t* p_nodes,
-                          int32_t* n_rows, int32_t* n_jobs, int32_t* err_flag, int64_t* tot_vol,
+                          int32_t* n_rows, int32_t* n_jobs, int32_t* err_flag,
                           int64_t* tot_nodes_alg) {
   if (L == 0) return S3GRL_OK;
   const int W = words_for(g->num_nodes);
@@ -705,7 +697,7 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)L), dim3(kBlock), lds, ctx->stream, g->indptr,
                      g->indices, (int)g->num_nodes, W, links, hops, plus, K, partner, mirror_of, n_nodes,
-                     p_nodes, n_rows, n_jobs, err_flag, reinterpret_cast<unsigned long long*>(tot_vol),
+                     p_nodes, n_rows, n_jobs, err_flag,
                      reinterpret_cast<unsigned long long*>(tot_nodes_alg));
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
@@ -767,7 +759,7 @@ struct LinkArgs {
   const s3grl_graph* g;
   const int64_t* links;
   const int32_t* class_list;
-  int hops, plus, cn_cap, full_stats;
+  int hops, plus, cn_cap, full_stats, debug_stop;
   const int32_t* p_nodes;
   const int64_t *node_off, *row_ptr, *job_off, *coef_off;
   const int32_t* mirror_of;
@@ -777,7 +769,7 @@ struct LinkArgs {
   float* job_z;
   int64_t* row_nodes;
   int32_t* lvl;
-  int64_t *tot_edges, *tot_support;
+  int64_t *tot_edges, *tot_support, *tot_vol;
 };
 
 template <int T, int K, int G>
@@ -790,10 +782,11 @@ s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(T), lds, ctx->stream, a.g->indptr,
                      a.g->indices, W, a.links, a.class_list + (int64_t)cls * L, a.hops, a.plus,
-                     a.cn_cap, a.full_stats, a.p_nodes, a.node_off, a.row_ptr, a.job_off, a.coef_off,
+                     a.cn_cap, a.full_stats, a.debug_stop, a.p_nodes, a.node_off, a.row_ptr, a.job_off, a.coef_off,
                      a.mirror_of, a.c_ids, a.c_coef, a.jobs, a.job_z, a.row_nodes, a.lvl,
                      reinterpret_cast<unsigned long long*>(a.tot_edges),
-                     reinterpret_cast<unsigned long long*>(a.tot_support));
+                     reinterpret_cast<unsigned long long*>(a.tot_support),
+                     reinterpret_cast<unsigned long long*>(a.tot_vol));
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -829,7 +822,7 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           const int64_t* node_off, const int64_t* row_ptr, const int64_t* job_off,
                           const int64_t* coef_off, const int32_t* mirror_of, int32_t* c_ids,
                           float* c_coef, Job* jobs, float* job_z, int64_t* row_nodes, int32_t* lvl,
-                          int64_t* tot_edges, int64_t* tot_support) {
+                          int64_t* tot_edges, int64_t* tot_support, int64_t* tot_vol) {
   if (L == 0) return S3GRL_OK;
   if (class_count_host[kNumClasses] > 0) {
     set_last_error(std::to_string(class_count_host[kNumClasses]) +
@@ -837,9 +830,10 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                    "build");
     return S3GRL_ERR_GRAPH_TOO_LARGE;
   }
-  LinkArgs a{g, links, class_list, hops, plus, cn_cap, full_stats, p_nodes, node_off, row_ptr,
+  static const int debug_stop = getenv("S3GRL_DEBUG_STOP") ? atoi(getenv("S3GRL_DEBUG_STOP")) : 0;
+  LinkArgs a{g, links, class_list, hops, plus, cn_cap, full_stats, debug_stop, p_nodes, node_off, row_ptr,
              job_off, coef_off, mirror_of, c_ids, c_coef, jobs, job_z, row_nodes, lvl, tot_edges,
-             tot_support};
+             tot_support, tot_vol};
   switch (K) {
     case 1: return launch_links_k<1>(ctx, a, L, class_count_host);
     case 2: return launch_links_k<2>(ctx, a, L, class_count_host);
