@@ -68,6 +68,55 @@ __device__ __forceinline__ bool sorted_contains(const int32_t* a, int n, int x) 
   return lo < n && a[lo] == x;
 }
 
+// Walks the CSR rows of list[r0..r1) with G lanes per row.  The passes built on this are bound
+// by dependent-load latency (list -> indptr -> indices -> LDS), not by lanes or bandwidth, so
+// UN row groups are in flight per wave: their id, row-bounds and first-neighbour loads are
+// issued back to back before anything is consumed.  visit(acc, v, u) is called for every stored
+// neighbour u of row v in stored order (lane g sees entries g, g+G, ...), finish(acc, t, v) once
+// per lane afterwards (all G lanes of the row; reduce across them there).
+struct RowAcc {
+  float x, y;
+  int n;
+};
+
+template <int T, int G, int UN, typename Visit, typename Finish>
+__device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
+                                          const int32_t* __restrict__ indptr,
+                                          const int32_t* __restrict__ indices, Visit visit,
+                                          Finish finish) {
+  const int tid = threadIdx.x;
+  const int g = tid & (G - 1);
+  constexpr int RPI = T / G;  // rows per wave-iteration slice
+  for (int base = r0; base < r1; base += UN * RPI) {
+    int t[UN], v[UN], c0[UN], e1[UN], first[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      t[u] = base + u * RPI + tid / G;
+      v[u] = t[u] < r1 ? list[t[u]] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      c0[u] = 0;
+      e1[u] = 0;
+      if (v[u] >= 0) {
+        c0[u] = indptr[v[u]] + g;
+        e1[u] = indptr[v[u] + 1];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) first[u] = c0[u] < e1[u] ? indices[c0[u]] : -1;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (v[u] >= 0) {
+        RowAcc acc{0.f, 0.f, 0};
+        if (first[u] >= 0) visit(acc, v[u], first[u]);
+        for (int c = c0[u] + G; c < e1[u]; c += G) visit(acc, v[u], indices[c]);
+        finish(acc, t[u], v[u]);
+      }
+    }
+  }
+}
+
 // Word-level popcount prefix of a bitmap (local id = rank): thread-contiguous runs, one block scan.
 template <int T>
 __device__ __forceinline__ void rank_prefix(const uint32_t* bm, uint32_t* wpre, int W, int* sh) {
@@ -96,7 +145,6 @@ __device__ __forceinline__ int bfs_list(const int32_t* __restrict__ indptr,
                                         int dst, int hops, uint32_t* vis, uint32_t* nxt,
                                         int32_t* list, int* lvl_end, int* sh, int& nlev_out) {
   const int tid = threadIdx.x;
-  const int g = tid & (G - 1);
   for (int t = tid; t < W; t += T) {
     vis[t] = 0;
     nxt[t] = 0;
@@ -113,19 +161,14 @@ __device__ __forceinline__ int bfs_list(const int32_t* __restrict__ indptr,
   int n = 2, nlev = 1;  // levels 0..nlev-1 are complete
   for (int d = 1; d <= hops; ++d) {
     const int f0 = d >= 2 ? lvl_end[d - 2] : 0, f1 = n;
-    for (int base = f0; base < f1; base += T / G) {
-      const int t = base + tid / G;
-      if (t < f1) {
-        const int v = list[t];
-        const int e1 = indptr[v + 1];
-        for (int c = indptr[v] + g; c < e1; c += G) {
-          const int u = indices[c];
+    walk_rows<T, G, 4>(
+        f0, f1, list, indptr, indices,
+        [&](RowAcc&, int, int u) {
           const uint32_t m = 1u << (u & 31);
           const uint32_t old = atomicOr(&vis[u >> 5], m);
           if (!(old & m)) atomicOr(&nxt[u >> 5], m);
-        }
-      }
-    }
+        },
+        [](RowAcc&, int, int) {});
     __syncthreads();
     // append the new level in ascending id order: every thread owns a contiguous run of
     // bitmap words, one block scan over the per-thread popcounts (2 barriers per level)

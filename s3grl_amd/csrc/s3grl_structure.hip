@@ -451,25 +451,20 @@ __global__ __launch_bounds__(T) void link_kernel(
   // ---- D^-1/2 on P (inf -> 0) -------------------------------------------------------------
   // reference tuned_SIGN.py:153-161: structure only, target link removed, no self-loops added
   int edges_local = 0;
-  for (int base = 0; base < p; base += T / G) {
-    const int t = base + tid / G;
-    if (t < p) {
-      const int v = list[t];
-      const int e1 = indptr[v + 1];
-      const bool is_src = v == src, is_dst = v == dst;
-      int cnt = 0;
-      for (int c = indptr[v] + g; c < e1; c += G) {
-        const int u = indices[c];
-        cnt += (test_bit(vis, u) && !((is_src && u == dst) || (is_dst && u == src))) ? 1 : 0;
-      }
+  walk_rows<T, G, 4>(
+      0, p, list, indptr, indices,
+      [&](RowAcc& a, int v, int u) {
+        a.n += (test_bit(vis, u) && !((v == src && u == dst) || (v == dst && u == src))) ? 1 : 0;
+      },
+      [&](RowAcc& a, int, int v) {
+        int cnt = a.n;
 #pragma unroll
-      for (int o = G / 2; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-      if (g == 0) {
-        dinvP[rank_of(inP, wpreP, v)] = cnt > 0 ? 1.0f / sqrtf((float)cnt) : 0.0f;
-        edges_local += cnt;
-      }
-    }
-  }
+        for (int o = G / 2; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (g == 0) {
+          dinvP[rank_of(inP, wpreP, v)] = cnt > 0 ? 1.0f / sqrtf((float)cnt) : 0.0f;
+          edges_local += cnt;
+        }
+      });
   __syncthreads();
 
   if (debug_stop == 3) return;  // + degrees on P
@@ -514,40 +509,34 @@ __global__ __launch_bounds__(T) void link_kernel(
 #pragma unroll 1
     for (int i = 0; i < K - 1; ++i) {
       const int limit = lvl_end[min(i + 1 + row_hop, nlev - 1)];  // <= p
-      for (int base = 0; base < support; base += T / G) {
-        const int t = base + tid / G;
-        if (t < limit) {
-          const int v = list[t];
-          const int e1 = indptr[v + 1];
-          const bool is_src = v == src, is_dst = v == dst;
-          float sx = 0.f, sy = 0.f;
-          for (int c = indptr[v] + g; c < e1; c += G) {
-            const int u = indices[c];
-            if (test_bit(inP, u) && !((is_src && u == dst) || (is_dst && u == src))) {
+      walk_rows<T, G, 4>(
+          0, limit, list, indptr, indices,
+          [&](RowAcc& a, int v, int u) {
+            if (test_bit(inP, u) && !((v == src && u == dst) || (v == dst && u == src))) {
               const float2 sv = s_in[rank_of(inP, wpreP, u)];
-              sx += sv.x;
-              sy += sv.y;
+              a.x += sv.x;
+              a.y += sv.y;
             }
-          }
+          },
+          [&](RowAcc& a, int t, int v) {
+            float sx = a.x, sy = a.y;
 #pragma unroll
-          for (int o = G / 2; o > 0; o >>= 1) {
-            sx += __shfl_xor(sx, o);
-            sy += __shfl_xor(sy, o);
-          }
-          if (g == 0) {
-            const int w = rank_of(inP, wpreP, v);
-            const float dw = dinvP[w];
-            const float rx = dw * sx, ry = dw * sy;
-            s_out[w] = make_float2(dw * rx, dw * ry);
-            coef[(int64_t)i * support + t] = make_float2(rx, ry);
-            // label column of operator i+1: Σ_w r[w] z_w = r[src] + r[dst]  (tuned_SIGN.py:177-185)
-            if (is_src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
-            if (is_dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
-          }
-        } else if (t < support && g == 0) {
-          coef[(int64_t)i * support + t] = make_float2(0.f, 0.f);
-        }
-      }
+            for (int o = G / 2; o > 0; o >>= 1) {
+              sx += __shfl_xor(sx, o);
+              sy += __shfl_xor(sy, o);
+            }
+            if (g == 0) {
+              const int w = rank_of(inP, wpreP, v);
+              const float dw = dinvP[w];
+              const float rx = dw * sx, ry = dw * sy;
+              s_out[w] = make_float2(dw * rx, dw * ry);
+              coef[(int64_t)i * support + t] = make_float2(rx, ry);
+              // label column of operator i+1: Σ_w r[w] z_w = r[src] + r[dst]  (tuned_SIGN.py:177-185)
+              if (v == src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
+              if (v == dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
+            }
+          });
+      for (int t = limit + tid; t < support; t += T) coef[(int64_t)i * support + t] = make_float2(0.f, 0.f);
       __syncthreads();
       float2* tmp = s_in;
       s_in = s_out;
@@ -557,44 +546,39 @@ __global__ __launch_bounds__(T) void link_kernel(
     {  // last operator: degree and sum of every reachable row in one pass over its CSR row
       const int i = K - 1;
       int edges_pass = 0;
-      for (int base = 0; base < last_rows; base += T / G) {
-        const int t = base + tid / G;
-        if (t < last_rows) {
-          const int v = list[t];
-          const int e1 = indptr[v + 1];
-          const bool is_src = v == src, is_dst = v == dst;
-          float sx = 0.f, sy = 0.f;
-          int cnt = 0;
-          for (int c = indptr[v] + g; c < e1; c += G) {
-            const int u = indices[c];
+      walk_rows<T, G, 4>(
+          0, last_rows, list, indptr, indices,
+          [&](RowAcc& a, int v, int u) {
             const uint32_t bit = 1u << (u & 31);
-            if ((vis[u >> 5] & bit) && !((is_src && u == dst) || (is_dst && u == src))) {
-              ++cnt;
+            if ((vis[u >> 5] & bit) && !((v == src && u == dst) || (v == dst && u == src))) {
+              ++a.n;
               if (inP[u >> 5] & bit) {
                 const float2 sv = s_in[rank_of(inP, wpreP, u)];
-                sx += sv.x;
-                sy += sv.y;
+                a.x += sv.x;
+                a.y += sv.y;
               }
             }
-          }
+          },
+          [&](RowAcc& a, int t, int v) {
+            int cnt = a.n;
+            float sx = a.x, sy = a.y;
 #pragma unroll
-          for (int o = G / 2; o > 0; o >>= 1) {
-            cnt += __shfl_xor(cnt, o);
-            sx += __shfl_xor(sx, o);
-            sy += __shfl_xor(sy, o);
-          }
-          if (g == 0) {
-            edges_pass += cnt;
-            if (t < support) {
-              const float dw = cnt > 0 ? 1.0f / sqrtf((float)cnt) : 0.0f;
-              const float rx = dw * sx, ry = dw * sy;
-              coef[(int64_t)i * support + t] = make_float2(rx, ry);
-              if (is_src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
-              if (is_dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
+            for (int o = G / 2; o > 0; o >>= 1) {
+              cnt += __shfl_xor(cnt, o);
+              sx += __shfl_xor(sx, o);
+              sy += __shfl_xor(sy, o);
             }
-          }
-        }
-      }
+            if (g == 0) {
+              edges_pass += cnt;
+              if (t < support) {
+                const float dw = cnt > 0 ? 1.0f / sqrtf((float)cnt) : 0.0f;
+                const float rx = dw * sx, ry = dw * sy;
+                coef[(int64_t)i * support + t] = make_float2(rx, ry);
+                if (v == src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
+                if (v == dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
+              }
+            }
+          });
       if (pr == 0) edges_local = (last_rows == n) ? edges_pass : edges_local;
       __syncthreads();
     }
@@ -795,7 +779,10 @@ s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t 
 template <int T, int K>
 s3grl_status launch_link_class(s3grl_context* ctx, const LinkArgs& a, int64_t L, int cls, int count) {
   const double mean_deg = (double)a.g->nnz / (double)std::max<int64_t>(a.g->num_nodes, 1);
-  if (mean_deg <= 6.0) return launch_link_class_g<T, K, 4>(ctx, a, L, cls, count);
+  static const int force_g = getenv("S3GRL_LANES_PER_ROW") ? atoi(getenv("S3GRL_LANES_PER_ROW")) : 0;
+  const int gsel = force_g ? force_g : (mean_deg <= 6.0 ? 4 : 8);
+  if (gsel == 2) return launch_link_class_g<T, K, 2>(ctx, a, L, cls, count);
+  if (gsel == 4) return launch_link_class_g<T, K, 4>(ctx, a, L, cls, count);
   return launch_link_class_g<T, K, 8>(ctx, a, L, cls, count);
 }
 
