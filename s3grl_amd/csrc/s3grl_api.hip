@@ -93,14 +93,6 @@ s3grl_status arena_alloc(s3grl_context* ctx, size_t count, T** out, std::vector<
   return S3GRL_OK;
 }
 
-struct Transient {  // released on scope exit (stream-ordered reuse is safe: one stream per context)
-  s3grl_context* ctx;
-  std::vector<void*> ptrs;
-  ~Transient() {
-    for (void* p : ptrs) ctx->arena.release(p);
-  }
-};
-
 s3grl_status record(s3grl_context* ctx, int idx) {
   if (!ctx->profiling) return S3GRL_OK;
   S3GRL_HIP_TRY(hipEventRecord(ctx->ev[idx], ctx->stream));
@@ -262,7 +254,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
                    std::to_string(kMaxNodesLds));
     return S3GRL_ERR_GRAPH_TOO_LARGE;
   }
-  if (L >= (int64_t)INT32_MAX / kNumClasses) return S3GRL_ERR_INVALID_ARGUMENT;
+  if (L >= (int64_t)INT32_MAX / (kNumClasses + 1)) return S3GRL_ERR_INVALID_ARGUMENT;
   S3GRL_HIP_TRY(hipSetDevice(ctx->device));
   const int K = cfg->sign_k;
 
@@ -298,7 +290,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   S3GRL_TRY(arena_alloc(ctx, (size_t)L, &n_rows, tr));
   S3GRL_TRY(arena_alloc(ctx, (size_t)L, &p_nodes, tr));
   S3GRL_TRY(arena_alloc(ctx, (size_t)L, &n_jobs, tr));
-  S3GRL_TRY(arena_alloc(ctx, (size_t)L * kNumClasses, &class_list, tr));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)L * (kNumClasses + 1), &class_list, tr));
   S3GRL_TRY(arena_alloc(ctx, (size_t)scan_workspace_elems(L), &scan_ws, tr));
 
   // d_scalars (int64 x 32): [0] err flag, [1] max n, [2] Σ edges, [3] Σ support, [4] Σ vol,
@@ -355,11 +347,11 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
     S3GRL_HIP_TRY(hipMemcpyAsync(hs + 8, ds + 8, 8 * 8, hipMemcpyDeviceToHost, ctx->stream));
     S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
-  int32_t class_count_host[kNumClasses + 1];
+  int32_t class_count_host[kNumClasses + 2];   // [kNumClasses] = HBM-scratch class, [+1] its max need
   std::memcpy(class_count_host, hs + 8, sizeof(class_count_host));
   if (getenv("S3GRL_DEBUG")) {
     fprintf(stderr, "[s3grl] L=%lld max_n=%lld classes:", (long long)L, (long long)max_n);
-    for (int c = 0; c <= kNumClasses; ++c) fprintf(stderr, " %d", class_count_host[c]);
+    for (int c = 0; c <= kNumClasses + 1; ++c) fprintf(stderr, " %d", class_count_host[c]);
     fprintf(stderr, "\n");
   }
   plan->stats.total_nodes = hs[6];          // algorithmic: a folded link counts like any other

@@ -88,29 +88,51 @@ __device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
   const int g = tid & (G - 1);
   constexpr int RPI = T / G;  // rows per wave-iteration slice
   for (int base = r0; base < r1; base += UN * RPI) {
+    // all loads of a stage are unconditional (clamped to a valid location, results selected
+    // afterwards): predicated loads make hipcc wait after each one
     int t[UN], v[UN], c0[UN], e1[UN], first[UN];
+    int2 be[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       t[u] = base + u * RPI + tid / G;
-      v[u] = t[u] < r1 ? list[t[u]] : -1;
+      v[u] = list[min(t[u], r1 - 1)];
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      c0[u] = 0;
-      e1[u] = 0;
-      if (v[u] >= 0) {
-        c0[u] = indptr[v[u]] + g;
-        e1[u] = indptr[v[u] + 1];
-      }
+      be[u].x = indptr[v[u]];
+      be[u].y = indptr[v[u] + 1];
     }
 #pragma unroll
-    for (int u = 0; u < UN; ++u) first[u] = c0[u] < e1[u] ? indices[c0[u]] : -1;
+    for (int u = 0; u < UN; ++u) {
+      const bool ok = t[u] < r1;
+      c0[u] = ok ? be[u].x + g : 0;
+      e1[u] = ok ? be[u].y : 0;
+      if (!ok) v[u] = -1;
+    }
+    int second[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      first[u] = indices[c0[u] < e1[u] ? c0[u] : 0];
+      second[u] = indices[c0[u] + G < e1[u] ? c0[u] + G : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (c0[u] >= e1[u]) first[u] = -1;
+      if (c0[u] + G >= e1[u]) second[u] = -1;
+    }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       if (v[u] >= 0) {
         RowAcc acc{0.f, 0.f, 0};
         if (first[u] >= 0) visit(acc, v[u], first[u]);
-        for (int c = c0[u] + G; c < e1[u]; c += G) visit(acc, v[u], indices[c]);
+        if (second[u] >= 0) visit(acc, v[u], second[u]);
+        // longer rows: two neighbours per lane in flight per trip
+        for (int c = c0[u] + 2 * G; c < e1[u]; c += 2 * G) {
+          const int ua = indices[c];
+          const int ub = indices[c + G < e1[u] ? c + G : c];
+          visit(acc, v[u], ua);
+          if (c + G < e1[u]) visit(acc, v[u], ub);
+        }
         finish(acc, t[u], v[u]);
       }
     }

@@ -143,6 +143,14 @@ struct s3grl_sop {
 
 namespace s3grl {
 
+struct Transient {  // released on scope exit (stream-ordered reuse is safe: one stream per context)
+  s3grl_context* ctx;
+  std::vector<void*> ptrs;
+  ~Transient() {
+    for (void* p : ptrs) ctx->arena.release(p);
+  }
+};
+
 // structure.hip
 s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                           int hops, int plus, int K, const int32_t* partner,

@@ -361,9 +361,10 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
     int base = 0;
     if (lane == leader) base = atomicAdd(&class_count[k], __popcll(m));
     base = __shfl(base, leader);
-    if (c == k && k < kNumClasses)
-      class_list[(int64_t)k * L + base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)l;
+    if (c == k) class_list[(int64_t)k * L + base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)l;
   }
+  // class kNumClasses = links that do not fit LDS: they run with their lists in HBM scratch
+  if (c == kNumClasses) atomicMax(&class_count[kNumClasses + 1], need);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -377,7 +378,9 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
 //   cur[p], nxs[p]         float2 propagation state s_i = dinv·r_i (rows a, b of the pair)
 // P = the hop-major prefix of S that r_{K-1} can reach; only the LAST operator touches the
 // rest of S, and it needs no state there: its degree and its sum come out of the same pass.
-template <int T, int K, int G>
+// GS = true: list / dinvP / state live in a per-workgroup HBM scratch slice instead of LDS (links
+// whose subgraph does not fit what the bitmaps leave of 160 KiB); same code, slower memory.
+template <int T, int K, int G, bool GS>
 __global__ __launch_bounds__(T) void link_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int W,
     const int64_t* __restrict__ links, const int32_t* __restrict__ class_list, int hops, int plus,
@@ -387,7 +390,8 @@ __global__ __launch_bounds__(T) void link_kernel(
     const int32_t* __restrict__ mirror_of, int32_t* __restrict__ c_ids, float* __restrict__ c_coef,
     Job* __restrict__ jobs, float* __restrict__ job_z, int64_t* __restrict__ row_nodes,
     int32_t* __restrict__ lvl_out, unsigned long long* __restrict__ tot_edges,
-    unsigned long long* __restrict__ tot_support, unsigned long long* __restrict__ tot_vol) {
+    unsigned long long* __restrict__ tot_support, unsigned long long* __restrict__ tot_vol,
+    char* __restrict__ scratch, int64_t scratch_stride) {
   extern __shared__ uint32_t smem[];
   const int tid = threadIdx.x;
   const int l = class_list[blockIdx.x];
@@ -404,10 +408,20 @@ __global__ __launch_bounds__(T) void link_kernel(
   int* lvl_end = cn + cn_cap;
   float* zbuf = reinterpret_cast<float*>(lvl_end + kMaxLevels);  // [2 (src,dst)][K][2 (rows)]
   int* sh = reinterpret_cast<int*>(zbuf + 4 * K);
-  int32_t* list = sh + 32;
-  float* dinvP = reinterpret_cast<float*>(list + n_alloc);
-  const int fixed_words = 3 * W + cn_cap + kMaxLevels + 4 * K + 32;
-  float2* cur = reinterpret_cast<float2*>(smem + ((fixed_words + n_alloc + p_alloc + 1) & ~1));
+  int32_t* list;
+  float* dinvP;
+  float2* cur;
+  if constexpr (GS) {
+    char* base = scratch + (int64_t)blockIdx.x * scratch_stride;   // 256-byte aligned slices
+    list = reinterpret_cast<int32_t*>(base);
+    dinvP = reinterpret_cast<float*>(list + n_alloc);
+    cur = reinterpret_cast<float2*>(base + (((size_t)(n_alloc + p_alloc) * 4 + 7) & ~(size_t)7));
+  } else {
+    list = sh + 32;
+    dinvP = reinterpret_cast<float*>(list + n_alloc);
+    const int fixed_words = 3 * W + cn_cap + kMaxLevels + 4 * K + 32;
+    cur = reinterpret_cast<float2*>(smem + ((fixed_words + n_alloc + p_alloc + 1) & ~1));
+  }
   float2* nxs = cur + p_alloc;
 
   const int src = (int)links[2 * (int64_t)l], dst = (int)links[2 * (int64_t)l + 1];
@@ -714,7 +728,8 @@ static inline int link_fixed_words(int64_t num_nodes, int cn_cap, int K) {
 // whatever the 160 KiB of a CU leave after the fixed part
 static ClassBounds class_bounds(int64_t num_nodes, int cn_cap, int K) {
   static const int nominal[kNumClasses] = S3GRL_CLASS_BOUNDS;
-  const int avail = 163840 - 4 * link_fixed_words(num_nodes, cn_cap, K);
+  int avail = 163840 - 4 * link_fixed_words(num_nodes, cn_cap, K);
+  if (const char* e = getenv("S3GRL_LDS_BUDGET")) avail = std::min(avail, atoi(e));  // test hook
   ClassBounds cb;
   for (int c = 0; c < kNumClasses; ++c) cb.b[c] = std::min(nominal[c], avail);
   cb.b[kNumClasses - 1] = avail;
@@ -726,9 +741,9 @@ s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_ca
                              int32_t* class_count, int32_t* class_list) {
   if (L == 0) return S3GRL_OK;
   const ClassBounds cb = class_bounds(g->num_nodes, cn_cap, K);
-  if (cb.b[kNumClasses - 1] < 1024) {
+  if (cb.b[kNumClasses - 1] < 0) {
     set_last_error("num_nodes " + std::to_string(g->num_nodes) +
-                   ": the LDS bitmaps leave no room for a subgraph");
+                   ": the LDS bitmaps alone exceed 160 KiB");
     return S3GRL_ERR_GRAPH_TOO_LARGE;
   }
   hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -754,14 +769,17 @@ struct LinkArgs {
   int64_t* row_nodes;
   int32_t* lvl;
   int64_t *tot_edges, *tot_support, *tot_vol;
+  char* scratch;
+  int64_t scratch_stride;
 };
 
-template <int T, int K, int G>
+template <int T, int K, int G, bool GS>
 s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t L, int cls, int count) {
   const int W = words_for(a.g->num_nodes);
   const ClassBounds cb = class_bounds(a.g->num_nodes, a.cn_cap, K);
-  const size_t lds = (size_t)4 * link_fixed_words(a.g->num_nodes, a.cn_cap, K) + cb.b[cls];
-  auto kern = link_kernel<T, K, G>;
+  const size_t lds = (size_t)4 * link_fixed_words(a.g->num_nodes, a.cn_cap, K) +
+                     (GS ? 0 : (size_t)cb.b[cls]);
+  auto kern = link_kernel<T, K, G, GS>;
   S3GRL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(T), lds, ctx->stream, a.g->indptr,
@@ -770,7 +788,7 @@ s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t 
                      a.mirror_of, a.c_ids, a.c_coef, a.jobs, a.job_z, a.row_nodes, a.lvl,
                      reinterpret_cast<unsigned long long*>(a.tot_edges),
                      reinterpret_cast<unsigned long long*>(a.tot_support),
-                     reinterpret_cast<unsigned long long*>(a.tot_vol));
+                     reinterpret_cast<unsigned long long*>(a.tot_vol), a.scratch, a.scratch_stride);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -781,15 +799,21 @@ s3grl_status launch_link_class(s3grl_context* ctx, const LinkArgs& a, int64_t L,
   const double mean_deg = (double)a.g->nnz / (double)std::max<int64_t>(a.g->num_nodes, 1);
   static const int force_g = getenv("S3GRL_LANES_PER_ROW") ? atoi(getenv("S3GRL_LANES_PER_ROW")) : 0;
   const int gsel = force_g ? force_g : (mean_deg <= 6.0 ? 4 : 8);
-  if (gsel == 2) return launch_link_class_g<T, K, 2>(ctx, a, L, cls, count);
-  if (gsel == 4) return launch_link_class_g<T, K, 4>(ctx, a, L, cls, count);
-  return launch_link_class_g<T, K, 8>(ctx, a, L, cls, count);
+  if (cls == kNumClasses) {   // HBM-scratch overflow class
+    if (gsel <= 4) return launch_link_class_g<1024, K, 4, true>(ctx, a, L, cls, count);
+    return launch_link_class_g<1024, K, 8, true>(ctx, a, L, cls, count);
+  }
+  if (gsel == 2) return launch_link_class_g<T, K, 2, false>(ctx, a, L, cls, count);
+  if (gsel == 4) return launch_link_class_g<T, K, 4, false>(ctx, a, L, cls, count);
+  return launch_link_class_g<T, K, 8, false>(ctx, a, L, cls, count);
 }
 
 template <int K>
 s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
                             const int32_t* class_count_host) {
   // largest subgraphs first: they are the long poles of the tail
+  if (class_count_host[kNumClasses] > 0)
+    S3GRL_TRY((launch_link_class<1024, K>(ctx, a, L, kNumClasses, class_count_host[kNumClasses])));
   for (int c = kNumClasses - 1; c >= 0; --c) {
     const int count = class_count_host[c];
     if (count == 0) continue;
@@ -811,16 +835,21 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           float* c_coef, Job* jobs, float* job_z, int64_t* row_nodes, int32_t* lvl,
                           int64_t* tot_edges, int64_t* tot_support, int64_t* tot_vol) {
   if (L == 0) return S3GRL_OK;
+  // links too large for LDS keep their lists in HBM scratch: one 256-byte aligned slice each
+  Transient scratch_owner{ctx, {}};
+  char* scratch = nullptr;
+  int64_t scratch_stride = 0;
   if (class_count_host[kNumClasses] > 0) {
-    set_last_error(std::to_string(class_count_host[kNumClasses]) +
-                   " link(s) have subgraphs that do not fit the 160 KiB LDS-resident path of this "
-                   "build");
-    return S3GRL_ERR_GRAPH_TOO_LARGE;
+    scratch_stride = ((int64_t)class_count_host[kNumClasses + 1] + 255) / 256 * 256;
+    void* q = nullptr;
+    S3GRL_TRY(ctx->arena.alloc((size_t)scratch_stride * class_count_host[kNumClasses], &q));
+    scratch_owner.ptrs.push_back(q);
+    scratch = static_cast<char*>(q);
   }
   static const int debug_stop = getenv("S3GRL_DEBUG_STOP") ? atoi(getenv("S3GRL_DEBUG_STOP")) : 0;
   LinkArgs a{g, links, class_list, hops, plus, cn_cap, full_stats, debug_stop, p_nodes, node_off, row_ptr,
              job_off, coef_off, mirror_of, c_ids, c_coef, jobs, job_z, row_nodes, lvl, tot_edges,
-             tot_support, tot_vol};
+             tot_support, tot_vol, scratch, scratch_stride};
   switch (K) {
     case 1: return launch_links_k<1>(ctx, a, L, class_count_host);
     case 2: return launch_links_k<2>(ctx, a, L, class_count_host);

@@ -423,3 +423,24 @@ def test_reversed_duplicates_are_folded_bit_exactly(eng):
             assert s1[k] == s0[k], k                       # algorithmic totals do not change
         assert s1["extracted_nodes"] < s0["extracted_nodes"]
     G.close()
+
+
+def test_hbm_scratch_path_for_oversized_subgraphs(eng, monkeypatch):
+    """Links whose lists do not fit LDS run with them in HBM scratch (GS = true): same results.
+    The LDS budget is shrunk through the test hook so that most links take that path."""
+    import torch
+
+    g = load_extract("rand300")
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = np.random.default_rng(21).standard_normal((n, 19))
+    G = eng.graph(A)
+    f = eng.features(X)
+    L = eng.links(g["links"].T)
+    ref = eng.precompute(G, f, L, mode="pos_plus", num_hops=2, sign_k=3)
+    monkeypatch.setenv("S3GRL_LDS_BUDGET", "600")
+    alt = eng.precompute(G, f, L, mode="pos_plus", num_hops=2, sign_k=3)
+    monkeypatch.delenv("S3GRL_LDS_BUDGET")
+    assert torch.equal(ref.row_ptr, alt.row_ptr) and torch.equal(ref.rows, alt.rows)
+    assert ref.stats == {**alt.stats, "workspace_bytes": ref.stats["workspace_bytes"]}
+    G.close()
