@@ -187,7 +187,11 @@ def main():
                              "propagate": tm["propagate_ms"] / max(tm["plans"], 1.0),
                              "gather": gather_ms},
                 "mean_subgraph_nodes": stats["total_nodes"] / max(L, 1),
-                "mean_support": stats["total_support"] / max(stats["num_row_pairs"], 1),
+                "folded_links": stats.get("folded_links", 0),
+                "note": "algorithmic bytes count every link (SURVEY 8d); links that are the reversed "
+                        "duplicate of an earlier link (both directions of a train edge) are served "
+                        "by that link's extraction and move no feature bytes of their own; X sits in "
+                        "the 256 MB Infinity Cache, so achieved > HBM peak is cache-served traffic",
             }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w, link_index, y, args.cpu_seconds, args.cpu_links)
