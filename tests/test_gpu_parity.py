@@ -444,3 +444,59 @@ def test_hbm_scratch_path_for_oversized_subgraphs(eng, monkeypatch):
     assert torch.equal(ref.row_ptr, alt.row_ptr) and torch.equal(ref.rows, alt.rows)
     assert ref.stats == {**alt.stats, "workspace_bytes": ref.stats["workspace_bytes"]}
     G.close()
+
+
+# ------------------------------------------------------------------------------------------
+# corner cases of the reference's semantics (SURVEY §8c K2/K4 and friends)
+# ------------------------------------------------------------------------------------------
+def _csr_with_self_loops(n, edges, loops):
+    import scipy.sparse as ssp
+
+    A = csr_from_undirected(n, edges).tolil()
+    for v in loops:
+        A[v, v] = 1
+    return ssp.csr_matrix(A)
+
+
+@pytest.mark.parametrize("mode", ["pos", "pos_plus"])
+@pytest.mark.parametrize("hops,K", [(0, 2), (1, 1), (1, 4), (2, 5), (3, 2)])
+def test_corner_cases_vs_oracle(eng, mode, hops, K):
+    """self-loops (they put src/dst themselves among the 'common neighbours', K4), isolated and
+    cross-component endpoints, repeated and reversed links, num_hops = 0, sign_k > num_hops."""
+    n = 14
+    edges = [[0, 1], [0, 2], [1, 2], [2, 3], [3, 4], [4, 5], [5, 0], [6, 7], [7, 8], [2, 9], [9, 10]]
+    A = _csr_with_self_loops(n, edges, loops=[0, 3, 7, 9])         # 11, 12, 13 isolated
+    X = np.random.default_rng(hops * 10 + K).standard_normal((n, 6))
+    links = np.array([[0, 1], [1, 0], [0, 3], [3, 0], [0, 1], [6, 8], [7, 6], [0, 7], [11, 12],
+                      [13, 2], [9, 2], [2, 9], [9, 3], [4, 10]]).T
+    kw = {"sign_k": K, "k_node_set_strategy": "intersection"}
+    fn = oracle.get_PoS_prepped_ds if mode == "pos" else oracle.get_PoS_Plus_prepped_ds
+    lst = fn(links, hops, A, X.astype(np.float32).astype(np.float64), 1, kw, dtype=np.float64)
+    ref, ptr, _ = oracle.collate_rows(lst, K)
+    G = eng.graph(A)
+    for fold in (True, False):
+        plan = eng.plan(G, eng.links(links), mode=mode, num_hops=hops, sign_k=K, fold_reversed=fold)
+        rows = plan.run(eng.features(X)).cpu().numpy()
+        np.testing.assert_array_equal(plan.row_ptr().cpu().numpy(), ptr)
+        got_nodes = plan.row_nodes().cpu().numpy()
+        for l, d in enumerate(lst):                    # CCN rows as a multiset, centre rows in order
+            mine = got_nodes[ptr[l]:ptr[l + 1]]
+            assert list(mine[:2]) == list(d["rows_global"][:2])
+            assert sorted(mine[2:]) == sorted(d["rows_global"][2:])
+        assert rel_err(rows, ref) < TOL
+        plan.close()
+    G.close()
+
+
+def test_wrapper_rejects_what_the_engine_cannot_mirror(eng):
+    import scipy.sparse as ssp
+
+    A = ssp.csr_matrix(np.array([[0, 1, 0], [0, 0, 1], [0, 0, 0]]))     # not symmetric
+    with pytest.raises(NotImplementedError):
+        eng.graph(A)
+    B = csr_from_undirected(3, [[0, 1], [1, 2]]).astype(np.float64)
+    B.data[0] = 0.0                                                      # stored zero
+    with pytest.raises(ValueError):
+        eng.graph(B)
+    with pytest.raises(ValueError):
+        eng.links(np.zeros((3, 4), dtype=np.int64))
