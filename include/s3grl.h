@@ -162,6 +162,10 @@ s3grl_status s3grl_run_features(s3grl_context* ctx, const s3grl_plan* p, const s
 s3grl_status s3grl_sop_create(s3grl_context* ctx, const s3grl_graph* g, const float* X,
                               int64_t ldx, int64_t num_features, int32_t sign_k, s3grl_sop** out);
 s3grl_status s3grl_sop_destroy(s3grl_sop* s);
+/* the global SIGN features themselves, out fp32 [K, N, F]: out[i-1] = Â^i X.  This is what the
+ * reference's non-optimised twin `TunedSIGN.__call__` (tuned_SIGN.py:18-23, PyG SIGN(K)) computes
+ * for the graph it is handed. */
+s3grl_status s3grl_sop_features(s3grl_context* ctx, const s3grl_sop* s, float* out);
 /* rows fp32 [2L, K+1, 1+F]: x_i[src] = [Â^i[s,s] | Σ_{w != d} Â^i[s,w] X[w]] and the mirror
  * image for dst (reference tuned_SIGN.py:71-78,92-113,119-132). */
 s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t* links,

@@ -225,6 +225,17 @@ __global__ __launch_bounds__(256) void sop_rows_kernel(
   }
 }
 
+// Y (f64, padded ld) -> out fp32 [K, N, F]
+__global__ void export_y_kernel(const double* __restrict__ Y, int64_t N, int64_t ldy, int64_t F,
+                                int K, float* __restrict__ out) {
+  const int64_t total = (int64_t)K * N * F;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = i % F, r = (i / F) % N, k = i / (F * N);
+    out[i] = (float)Y[((k + 1) * N + r) * ldy + c];
+  }
+}
+
 static inline int words_for(int64_t N) { return (int)((N + 31) / 32); }
 
 // bins links by LDS need of sop_scalar_kernel (4 + 16·HB bytes per ball node)
@@ -303,6 +314,16 @@ s3grl_status s3grl_sop_create(s3grl_context* ctx, const s3grl_graph* g, const fl
     ctx->timings[3] += ms;
   }
   *out = s.release();
+  return S3GRL_OK;
+}
+
+s3grl_status s3grl_sop_features(s3grl_context* ctx, const s3grl_sop* s, float* out) {
+  if (!ctx || !s || !out) return S3GRL_ERR_INVALID_ARGUMENT;
+  S3GRL_HIP_TRY(hipSetDevice(ctx->device));
+  const int64_t N = s->graph->num_nodes, total = (int64_t)s->K * N * s->F;
+  hipLaunchKernelGGL(export_y_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 8192)),
+                     dim3(256), 0, ctx->stream, s->Y, N, s->ldy, s->F, s->K, out);
+  S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
 

@@ -186,6 +186,13 @@ class Sop:
         self._h = h
         engine._children.add(self)
 
+    def sign_features(self):
+        """[K, N, F] fp32: Â^1 X .. Â^K X of the whole graph (PyG SIGN(K) on it)."""
+        out = torch.empty((self.sign_k, self.graph.num_nodes, self.F), dtype=torch.float32,
+                          device=self.engine.device)
+        N.check(N.lib().s3grl_sop_features(self.engine._ctx, self._h, _ptr(out)), "s3grl_sop_features")
+        return out
+
     def run(self, links, out=None):
         eng = self.engine
         L = int(links.shape[0])
@@ -286,6 +293,14 @@ class Engine:
         """links: int64 [L,2] device tensor (see `links()`); x: fp32 [N,F] device tensor."""
         if x is None:
             N.check(N.ERR_NO_FEATURES, "precompute")
+        if mode == "hybrid":
+            # reference utils.py:454-480: PoS keys kept, SoP x2..xK appended as x{K+1}..x{2K-1}
+            pos = self.precompute(graph, x, links, mode="pos", num_hops=num_hops, sign_k=sign_k)
+            if sign_k == 1:
+                return pos
+            sop = self.precompute(graph, x, links, mode="sop", sign_k=sign_k)
+            rows = torch.cat([pos.rows, sop.rows[:, 2:, :]], dim=1)
+            return Precomputed(rows, pos.row_ptr, pos.row_nodes, dict(pos.stats))
         if mode == "sop":
             sop = Sop(self, graph, x, sign_k)
             try:

@@ -174,16 +174,37 @@ class OptimizedSignOperations:
 
 
 class TunedSIGN:
-    """Name kept for import compatibility (reference tuned_SIGN.py:13-44).  The non-optimised
-    flows it serves (`optimize_sign=False`, reference utils.py:497-550) are outside the hot path
-    (no paper config uses them for SIGN) and are not implemented."""
+    """Reference tuned_SIGN.py:13-44, the non-optimised twin (`optimize_sign=False`, reference
+    utils.py:497-550).  `__call__` is PyG's SIGN(K) on the graph it is handed — x_i = Â^i x for
+    ALL rows, Â = D^-1/2 A D^-1/2 from `data.edge_index` without weights or self-loops — followed
+    by the reference's `sign_k == -1` pruning.  It runs on the engine's global-operator path.
+    `SoP_data_creation` (per-operator weighted graphs, outside the hot path) is not implemented."""
 
     def __init__(self, K):
         self.K = K
 
     def __call__(self, data, sign_k):
-        raise NotImplementedError("non-optimised SIGN flow (optimize_sign=False) is not part of the "
-                                  "MI355X engine; use OptimizedSignOperations")
+        import numpy as np
+        import scipy.sparse as ssp
+
+        assert data.edge_index is not None and data.x is not None
+        eng = _engine.default_engine()
+        ei = data.edge_index.cpu().numpy()
+        n = int(data.num_nodes) if getattr(data, "num_nodes", None) is not None else int(data.x.shape[0])
+        A = ssp.csr_matrix((np.ones(ei.shape[1]), (ei[0], ei[1])), shape=(n, n))
+        x = data.x if data.x.dim() == 2 else data.x.view(-1, 1)
+        g = eng.graph(A)
+        sop = _engine.Sop(eng, g, eng.features(x.float()), self.K)
+        ys = sop.sign_features()
+        out_dev = data.x.device
+        for i in range(1, self.K + 1):
+            data[f'x{i}'] = ys[i - 1].to(out_dev)
+        sop.close()
+        g.close()
+        if sign_k == -1:                                   # tuned_SIGN.py:20-22
+            for idx in range(1, self.K):
+                data.pop(f'x{idx}')
+        return data
 
     def SoP_data_creation(self, sop_data_list):
         raise NotImplementedError("non-optimised SoP flow is not part of the MI355X engine")

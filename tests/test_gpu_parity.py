@@ -500,3 +500,39 @@ def test_wrapper_rejects_what_the_engine_cannot_mirror(eng):
         eng.graph(B)
     with pytest.raises(ValueError):
         eng.links(np.zeros((3, 4), dtype=np.int64))
+
+
+def test_hybrid_and_tuned_sign_twin(eng):
+    import torch
+    from s3grl_amd.tuned_SIGN import LinkData, TunedSIGN, clear_cache
+
+    g = load_extract("usair")
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = np.random.default_rng(8).random((n, 10))
+    links = g["links"][:12].T
+    K = 3
+    kw = {"sign_k": K, "k_node_set_strategy": "intersection"}
+    X64 = X.astype(np.float32).astype(np.float64)
+    pos = oracle.get_PoS_prepped_ds(links, 2, A, X64, 1, kw, dtype=np.float64)
+    sop = oracle.get_SoP_prepped_ds(oracle.global_normalized_powers(A, K, np.float64), links, A, X64, 1,
+                                    dtype=np.float64)
+    hyb = oracle.hybrid_combine(pos, sop, K)
+    ref = np.concatenate([np.stack([d[k] for k in ["x"] + [f"x{i}" for i in range(1, 2 * K)]], axis=1)
+                          for d in hyb])
+    G = eng.graph(A)
+    res = eng.precompute(G, eng.features(X), eng.links(links), mode="hybrid", num_hops=2, sign_k=K)
+    assert res.rows.shape == (24, 2 * K, 11) and rel_err(res.rows.cpu().numpy(), ref) < TOL
+    # TunedSIGN twin == PyG SIGN(K): x_i = Â^i x for all rows of the graph it is given
+    coo = A.tocoo()
+    data = LinkData(x=torch.from_numpy(X.astype(np.float32)),
+                    edge_index=torch.from_numpy(np.stack([coo.row, coo.col]).astype(np.int64)),
+                    num_nodes=n)
+    out = TunedSIGN(K)(data, K)
+    P = oracle.global_normalized_powers(A, K, np.float64)
+    for i in range(1, K + 1):
+        assert rel_err(out[f"x{i}"].numpy(), np.asarray(P[i - 1] @ X64)) < TOL
+    data2 = TunedSIGN(K)(LinkData(x=data.x, edge_index=data.edge_index, num_nodes=n), -1)
+    assert "x1" not in data2 and "x2" not in data2 and f"x{K}" in data2
+    G.close()
+    clear_cache()
