@@ -65,6 +65,15 @@ __global__ void indptr_to_i32_kernel(const int64_t* __restrict__ in, int64_t n,
   if (i < n) out[i] = (int32_t)in[i];
 }
 
+__global__ void max_degree_kernel(const int32_t* __restrict__ indptr, int64_t n, int64_t* out) {
+  int m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    m = max(m, indptr[i + 1] - indptr[i]);
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<long long*>(out), (long long)m);
+}
+
 __global__ void max_i32_kernel(const int32_t* __restrict__ in, int64_t n, int64_t* out) {
   int m = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -208,7 +217,13 @@ s3grl_status s3grl_graph_create(s3grl_context* ctx, int64_t num_nodes, const int
   if (nnz)
     S3GRL_HIP_TRY(hipMemcpyAsync(g->indices, indices, (size_t)nnz * 4, hipMemcpyDeviceToDevice,
                                  ctx->stream));
+  S3GRL_HIP_TRY(hipMemsetAsync(ctx->d_scalars, 0, 8, ctx->stream));
+  hipLaunchKernelGGL(max_degree_kernel, dim3(256), dim3(256), 0, ctx->stream, g->indptr, num_nodes,
+                     ctx->d_scalars);
+  S3GRL_HIP_TRY(hipGetLastError());
+  S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  g->max_degree = (int32_t)ctx->h_scalars[0];
   *out = g;
   return S3GRL_OK;
 }

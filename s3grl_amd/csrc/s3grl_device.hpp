@@ -72,18 +72,26 @@ __device__ __forceinline__ bool sorted_contains(const int32_t* a, int n, int x) 
 // by dependent-load latency (list -> indptr -> indices -> LDS), not by lanes or bandwidth, so
 // UN row groups are in flight per wave: their id, row-bounds and first-neighbour loads are
 // issued back to back before anything is consumed.  visit(acc, v, u) is called for every stored
-// neighbour u of row v in stored order (lane g sees entries g, g+G, ...), finish(acc, t, v) once
-// per lane afterwards (all G lanes of the row; reduce across them there).
+// neighbour u of row v; commit(acc, t, v) once per row, by one lane, with acc summed over the
+// row (fixed reduction trees: bit-reproducible).
+// Hub rows (more than kHubFactor·G stored neighbours: a power-law hub would pin its G lanes for
+// hundreds of trips while the rest of the workgroup waits at the next barrier) are deferred to
+// `hub` = {count, row positions…} in LDS and then walked one at a time by the WHOLE workgroup.
+// Must be called by every thread of the workgroup (contains barriers).
 struct RowAcc {
   float x, y;
   int n;
 };
 
-template <int T, int G, int UN, typename Visit, typename Finish>
+constexpr int kHubFactor = 64;
+constexpr int kHubCap = 255;     // deferred hub rows per call; further ones are walked in place
+constexpr int kHubWords = kHubCap + 1 + 64;   // hub list + block-reduction scratch
+
+template <int T, int G, int UN, typename Visit, typename Commit>
 __device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
                                           const int32_t* __restrict__ indptr,
-                                          const int32_t* __restrict__ indices, Visit visit,
-                                          Finish finish) {
+                                          const int32_t* __restrict__ indices, int* hub,
+                                          Visit visit, Commit commit) {
   const int tid = threadIdx.x;
   const int g = tid & (G - 1);
   constexpr int RPI = T / G;  // rows per wave-iteration slice
@@ -104,7 +112,16 @@ __device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const bool ok = t[u] < r1;
+      bool ok = t[u] < r1;
+      if (hub && ok && be[u].y - be[u].x > kHubFactor * G) {   // uniform over the row's G lanes
+        int slot = kHubCap;
+        if (g == 0) slot = atomicAdd(&hub[0], 1);
+        slot = __shfl(slot, (tid & 63) & ~(G - 1));
+        if (slot < kHubCap) {
+          if (g == 0) hub[1 + slot] = t[u];
+          ok = false;
+        }
+      }
       c0[u] = ok ? be[u].x + g : 0;
       e1[u] = ok ? be[u].y : 0;
       if (!ok) v[u] = -1;
@@ -133,10 +150,53 @@ __device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
           visit(acc, v[u], ua);
           if (c + G < e1[u]) visit(acc, v[u], ub);
         }
-        finish(acc, t[u], v[u]);
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) {
+          acc.x += __shfl_xor(acc.x, o);
+          acc.y += __shfl_xor(acc.y, o);
+          acc.n += __shfl_xor(acc.n, o);
+        }
+        if (g == 0) commit(acc, t[u], v[u]);
       }
     }
   }
+  // deferred hub rows: the whole workgroup walks one row at a time.  hub == nullptr (uniform:
+  // the graph's maximum degree is below the hub threshold) skips the phase and its barriers.
+  if (!hub) return;
+  __syncthreads();
+  const int nh = min(hub[0], kHubCap);
+  float* red = reinterpret_cast<float*>(hub + 1 + kHubCap);   // [T/64][3] <= 48 words
+  for (int h = 0; h < nh; ++h) {
+    const int tt = hub[1 + h];
+    const int v = list[tt];
+    const int e1 = indptr[v + 1];
+    RowAcc acc{0.f, 0.f, 0};
+    for (int c = indptr[v] + tid; c < e1; c += T) visit(acc, v, indices[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      acc.x += __shfl_xor(acc.x, o);
+      acc.y += __shfl_xor(acc.y, o);
+      acc.n += __shfl_xor(acc.n, o);
+    }
+    if ((tid & 63) == 0) {
+      red[(tid >> 6) * 3 + 0] = acc.x;
+      red[(tid >> 6) * 3 + 1] = acc.y;
+      red[(tid >> 6) * 3 + 2] = __int_as_float(acc.n);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      RowAcc tot{0.f, 0.f, 0};
+      for (int w = 0; w < T / 64; ++w) {   // fixed order
+        tot.x += red[w * 3 + 0];
+        tot.y += red[w * 3 + 1];
+        tot.n += __float_as_int(red[w * 3 + 2]);
+      }
+      commit(tot, tt, v);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) hub[0] = 0;
+  __syncthreads();
 }
 
 // Word-level popcount prefix of a bitmap (local id = rank): thread-contiguous runs, one block scan.
@@ -165,7 +225,8 @@ template <int T, int G>
 __device__ __forceinline__ int bfs_list(const int32_t* __restrict__ indptr,
                                         const int32_t* __restrict__ indices, int W, int src,
                                         int dst, int hops, uint32_t* vis, uint32_t* nxt,
-                                        int32_t* list, int* lvl_end, int* sh, int& nlev_out) {
+                                        int32_t* list, int* lvl_end, int* sh, int* hub,
+                                        int& nlev_out) {
   const int tid = threadIdx.x;
   for (int t = tid; t < W; t += T) {
     vis[t] = 0;
@@ -178,13 +239,14 @@ __device__ __forceinline__ int bfs_list(const int32_t* __restrict__ indptr,
     list[0] = min(src, dst);
     list[1] = max(src, dst);
     lvl_end[0] = 2;
+    if (hub) hub[0] = 0;
   }
   __syncthreads();
   int n = 2, nlev = 1;  // levels 0..nlev-1 are complete
   for (int d = 1; d <= hops; ++d) {
     const int f0 = d >= 2 ? lvl_end[d - 2] : 0, f1 = n;
     walk_rows<T, G, 4>(
-        f0, f1, list, indptr, indices,
+        f0, f1, list, indptr, indices, hub,
         [&](RowAcc&, int, int u) {
           const uint32_t m = 1u << (u & 31);
           const uint32_t old = atomicOr(&vis[u >> 5], m);

@@ -90,6 +90,7 @@ struct s3grl_graph {
   s3grl_context* ctx = nullptr;
   int64_t num_nodes = 0;
   int64_t nnz = 0;
+  int32_t max_degree = 0;      // decides whether the hub-row path of the row walker is armed
   int32_t* indptr = nullptr;   // [N+1] device, int32 (nnz < 2^31)
   int32_t* indices = nullptr;  // [nnz] device
 };

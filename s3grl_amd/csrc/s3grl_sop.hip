@@ -85,7 +85,7 @@ __global__ __launch_bounds__(T) void sop_scalar_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int W,
     const double* __restrict__ gdinv, const int64_t* __restrict__ links,
     const int32_t* __restrict__ class_list, const int64_t* __restrict__ node_off, int K, int HB,
-    double* __restrict__ scal /* [L][K][3] = sd, ss, dd */) {
+    int hubs, double* __restrict__ scal /* [L][K][3] = sd, ss, dd */) {
   extern __shared__ uint32_t smem[];
   const int tid = threadIdx.x;
   const int l = class_list[blockIdx.x];
@@ -95,7 +95,8 @@ __global__ __launch_bounds__(T) void sop_scalar_kernel(
   uint32_t* wpre = smem + 2 * W;
   int* lvl_end = reinterpret_cast<int*>(smem + 3 * W);
   int* sh = lvl_end + kMaxLevels;
-  const int red_off = (3 * W + kMaxLevels + 32 + 1) & ~1;           // doubles: 8-byte aligned
+  int* hub = hubs ? sh + 32 : nullptr;
+  const int red_off = (3 * W + kMaxLevels + 32 + kHubWords + 1) & ~1;   // doubles: 8-byte aligned
   double* red = reinterpret_cast<double*>(smem + red_off);           // [16 waves][3]
   int32_t* list = reinterpret_cast<int32_t*>(smem + red_off + 96);
   double2* r = reinterpret_cast<double2*>(smem + ((red_off + 96 + n_alloc + 3) & ~3));  // [HB][n]
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(T) void sop_scalar_kernel(
   const int src = (int)links[2 * (int64_t)l], dst = (int)links[2 * (int64_t)l + 1];
   const int g = tid & (G - 1);
   int nlev;
-  const int n = bfs_list<T, G>(indptr, indices, W, src, dst, HB, vis, nxt, list, lvl_end, sh, nlev);
+  const int n = bfs_list<T, G>(indptr, indices, W, src, dst, HB, vis, nxt, list, lvl_end, sh, hub, nlev);
   rank_prefix<T>(vis, wpre, W, sh);
   for (int w = tid; w < n * HB; w += T) r[w] = make_double2(0.0, 0.0);
   __syncthreads();
@@ -371,7 +372,7 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
   S3GRL_TRY(launch_count(ctx, g, links, L, HB, 0, 1, nullptr, nullptr, n_nodes, p_nodes, n_rows,
                          n_jobs, reinterpret_cast<int32_t*>(ds), ds + 6));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_nodes, L, node_off, scan_ws));
-  const int fixed = 4 * (3 * W + kMaxLevels + 32 + 6 * 16) + 64;
+  const int fixed = 4 * (3 * W + kMaxLevels + 32 + kHubWords + 6 * 16) + 64;
   const int per_node = 4 + 16 * HB;
   const int b2 = 163840 - fixed, b1 = std::min(b2, 49152), b0 = std::min(b2, 12288);
   hipLaunchKernelGGL(sop_classify_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -407,7 +408,7 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
     hipLaunchKernelGGL(kern, dim3((unsigned)cc[c]), dim3(TT), lds, ctx->stream, g->indptr,         \
                        g->indices, W, s->dinv, links, class_list + (int64_t)c * L, node_off, K,    \
-                       HB, scal);                                                                  \
+                       HB, g->max_degree > kHubFactor * GG ? 1 : 0, scal);                                                                  \
   } while (0)
     if (c == 0) {
       if (sparse) S3GRL_SOP_LAUNCH(256, 4); else S3GRL_SOP_LAUNCH(256, 8);

@@ -69,7 +69,7 @@ constexpr int kCountList = 3072;
 template <int G>
 __global__ __launch_bounds__(kBlock) void count_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int N, int W,
-    const int64_t* __restrict__ links, int hops, int plus, int K,
+    const int64_t* __restrict__ links, int hops, int plus, int K, int hubs,
     const int32_t* __restrict__ partner, const int32_t* __restrict__ mirror_of,
     int32_t* __restrict__ n_nodes, int32_t* __restrict__ p_nodes, int32_t* __restrict__ n_rows,
     int32_t* __restrict__ n_jobs, int32_t* __restrict__ err_flag,
@@ -102,7 +102,8 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
     return;
   }
   const int src = (int)s64, dst = (int)d64;
-  int32_t* list = reinterpret_cast<int32_t*>(sh + 8);   // frontier nodes of the levels < hops
+  int* hub = hubs ? sh + 8 : nullptr;
+  int32_t* list = reinterpret_cast<int32_t*>(sh + 8 + kHubWords);   // frontier nodes of the levels < hops
   for (int t = tid; t < W; t += kBlock) {
     vis[t] = 0;
     cur[t] = 0;
@@ -114,29 +115,24 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
     atomicOr(&vis[dst >> 5], 1u << (dst & 31));
     list[0] = src;
     list[1] = dst;
+    if (hub) hub[0] = 0;
   }
   __syncthreads();
   // The frontier is a node list (G lanes per node: no serial row walks) as long as the levels
   // below `hops` fit kCountList entries; beyond that it degrades to a bitmap walked one thread
   // per word.  cum_a / cum_b: nodes within K-1 / K hops (P for a row at hop 0 / hop 1).
-  const int g = tid & (G - 1);
   int n = 2, cum_a = 2, cum_b = 2, f0 = 0, f1 = 2;
   bool use_list = true;
   for (int d = 1; d <= hops; ++d) {
     if (use_list) {
-      for (int base = f0; base < f1; base += kBlock / G) {
-        const int t = base + tid / G;
-        if (t < f1) {
-          const int v = list[t];
-          const int e1 = indptr[v + 1];
-          for (int c = indptr[v] + g; c < e1; c += G) {
-            const int u = indices[c];
+      walk_rows<kBlock, G, 4>(
+          f0, f1, list, indptr, indices, hub,
+          [&](RowAcc&, int, int u) {
             const uint32_t m = 1u << (u & 31);
             const uint32_t old = atomicOr(&vis[u >> 5], m);
             if (!(old & m)) atomicOr(&nxt[u >> 5], m);
-          }
-        }
-      }
+          },
+          [](RowAcc&, int, int) {});
     } else {
       for (int t = tid; t < W; t += kBlock) {
         uint32_t w = cur[t];
@@ -384,7 +380,7 @@ template <int T, int K, int G, bool GS>
 __global__ __launch_bounds__(T) void link_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int W,
     const int64_t* __restrict__ links, const int32_t* __restrict__ class_list, int hops, int plus,
-    int cn_cap, int full_stats, int debug_stop, const int32_t* __restrict__ p_nodes,
+    int cn_cap, int full_stats, int debug_stop, int hubs, const int32_t* __restrict__ p_nodes,
     const int64_t* __restrict__ node_off, const int64_t* __restrict__ row_ptr,
     const int64_t* __restrict__ job_off, const int64_t* __restrict__ coef_off,
     const int32_t* __restrict__ mirror_of, int32_t* __restrict__ c_ids, float* __restrict__ c_coef,
@@ -408,6 +404,7 @@ __global__ __launch_bounds__(T) void link_kernel(
   int* lvl_end = cn + cn_cap;
   float* zbuf = reinterpret_cast<float*>(lvl_end + kMaxLevels);  // [2 (src,dst)][K][2 (rows)]
   int* sh = reinterpret_cast<int*>(zbuf + 4 * K);
+  int* hub = hubs ? sh + 32 : nullptr;
   int32_t* list;
   float* dinvP;
   float2* cur;
@@ -417,19 +414,18 @@ __global__ __launch_bounds__(T) void link_kernel(
     dinvP = reinterpret_cast<float*>(list + n_alloc);
     cur = reinterpret_cast<float2*>(base + (((size_t)(n_alloc + p_alloc) * 4 + 7) & ~(size_t)7));
   } else {
-    list = sh + 32;
+    list = sh + 32 + kHubWords;
     dinvP = reinterpret_cast<float*>(list + n_alloc);
-    const int fixed_words = 3 * W + cn_cap + kMaxLevels + 4 * K + 32;
+    const int fixed_words = 3 * W + cn_cap + kMaxLevels + 4 * K + 32 + kHubWords;
     cur = reinterpret_cast<float2*>(smem + ((fixed_words + n_alloc + p_alloc + 1) & ~1));
   }
   float2* nxs = cur + p_alloc;
 
   const int src = (int)links[2 * (int64_t)l], dst = (int)links[2 * (int64_t)l + 1];
-  const int g = tid & (G - 1);
 
   // ---- BFS on the unmasked graph (reference utils.py:53-74) --------------------------------
   int nlev;
-  const int n = bfs_list<T, G>(indptr, indices, W, src, dst, hops, vis, inP, list, lvl_end, sh, nlev);
+  const int n = bfs_list<T, G>(indptr, indices, W, src, dst, hops, vis, inP, list, lvl_end, sh, hub, nlev);
 
   if (debug_stop == 1) return;  // profiling aid: BFS only
   // ---- rows of this link ----------------------------------------------------------------
@@ -466,18 +462,13 @@ __global__ __launch_bounds__(T) void link_kernel(
   // reference tuned_SIGN.py:153-161: structure only, target link removed, no self-loops added
   int edges_local = 0;
   walk_rows<T, G, 4>(
-      0, p, list, indptr, indices,
+      0, p, list, indptr, indices, hub,
       [&](RowAcc& a, int v, int u) {
         a.n += (test_bit(vis, u) && !((v == src && u == dst) || (v == dst && u == src))) ? 1 : 0;
       },
       [&](RowAcc& a, int, int v) {
-        int cnt = a.n;
-#pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-        if (g == 0) {
-          dinvP[rank_of(inP, wpreP, v)] = cnt > 0 ? 1.0f / sqrtf((float)cnt) : 0.0f;
-          edges_local += cnt;
-        }
+        dinvP[rank_of(inP, wpreP, v)] = a.n > 0 ? 1.0f / sqrtf((float)a.n) : 0.0f;
+        edges_local += a.n;
       });
   __syncthreads();
 
@@ -524,7 +515,7 @@ __global__ __launch_bounds__(T) void link_kernel(
     for (int i = 0; i < K - 1; ++i) {
       const int limit = lvl_end[min(i + 1 + row_hop, nlev - 1)];  // <= p
       walk_rows<T, G, 4>(
-          0, limit, list, indptr, indices,
+          0, limit, list, indptr, indices, hub,
           [&](RowAcc& a, int v, int u) {
             if (test_bit(inP, u) && !((v == src && u == dst) || (v == dst && u == src))) {
               const float2 sv = s_in[rank_of(inP, wpreP, u)];
@@ -533,22 +524,14 @@ __global__ __launch_bounds__(T) void link_kernel(
             }
           },
           [&](RowAcc& a, int t, int v) {
-            float sx = a.x, sy = a.y;
-#pragma unroll
-            for (int o = G / 2; o > 0; o >>= 1) {
-              sx += __shfl_xor(sx, o);
-              sy += __shfl_xor(sy, o);
-            }
-            if (g == 0) {
-              const int w = rank_of(inP, wpreP, v);
-              const float dw = dinvP[w];
-              const float rx = dw * sx, ry = dw * sy;
-              s_out[w] = make_float2(dw * rx, dw * ry);
-              coef[(int64_t)i * support + t] = make_float2(rx, ry);
-              // label column of operator i+1: Σ_w r[w] z_w = r[src] + r[dst]  (tuned_SIGN.py:177-185)
-              if (v == src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
-              if (v == dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
-            }
+            const int w = rank_of(inP, wpreP, v);
+            const float dw = dinvP[w];
+            const float rx = dw * a.x, ry = dw * a.y;
+            s_out[w] = make_float2(dw * rx, dw * ry);
+            coef[(int64_t)i * support + t] = make_float2(rx, ry);
+            // label column of operator i+1: Σ_w r[w] z_w = r[src] + r[dst]  (tuned_SIGN.py:177-185)
+            if (v == src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
+            if (v == dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
           });
       for (int t = limit + tid; t < support; t += T) coef[(int64_t)i * support + t] = make_float2(0.f, 0.f);
       __syncthreads();
@@ -561,7 +544,7 @@ __global__ __launch_bounds__(T) void link_kernel(
       const int i = K - 1;
       int edges_pass = 0;
       walk_rows<T, G, 4>(
-          0, last_rows, list, indptr, indices,
+          0, last_rows, list, indptr, indices, hub,
           [&](RowAcc& a, int v, int u) {
             const uint32_t bit = 1u << (u & 31);
             if ((vis[u >> 5] & bit) && !((v == src && u == dst) || (v == dst && u == src))) {
@@ -574,23 +557,13 @@ __global__ __launch_bounds__(T) void link_kernel(
             }
           },
           [&](RowAcc& a, int t, int v) {
-            int cnt = a.n;
-            float sx = a.x, sy = a.y;
-#pragma unroll
-            for (int o = G / 2; o > 0; o >>= 1) {
-              cnt += __shfl_xor(cnt, o);
-              sx += __shfl_xor(sx, o);
-              sy += __shfl_xor(sy, o);
-            }
-            if (g == 0) {
-              edges_pass += cnt;
-              if (t < support) {
-                const float dw = cnt > 0 ? 1.0f / sqrtf((float)cnt) : 0.0f;
-                const float rx = dw * sx, ry = dw * sy;
-                coef[(int64_t)i * support + t] = make_float2(rx, ry);
-                if (v == src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
-                if (v == dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
-              }
+            edges_pass += a.n;
+            if (t < support) {
+              const float dw = a.n > 0 ? 1.0f / sqrtf((float)a.n) : 0.0f;
+              const float rx = dw * a.x, ry = dw * a.y;
+              coef[(int64_t)i * support + t] = make_float2(rx, ry);
+              if (v == src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
+              if (v == dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
             }
           });
       if (pr == 0) edges_local = (last_rows == n) ? edges_pass : edges_local;
@@ -688,13 +661,14 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           int64_t* tot_nodes_alg) {
   if (L == 0) return S3GRL_OK;
   const int W = words_for(g->num_nodes);
-  const size_t lds = (size_t)(3 * W + 8 + kCountList) * 4;
+  const size_t lds = (size_t)(3 * W + 8 + kHubWords + kCountList) * 4;
   const bool sparse = (double)g->nnz / (double)std::max<int64_t>(g->num_nodes, 1) <= 6.0;
   auto kern = sparse ? count_kernel<4> : count_kernel<8>;
   S3GRL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)L), dim3(kBlock), lds, ctx->stream, g->indptr,
-                     g->indices, (int)g->num_nodes, W, links, hops, plus, K, partner, mirror_of, n_nodes,
+                     g->indices, (int)g->num_nodes, W, links, hops, plus, K,
+                     g->max_degree > kHubFactor * (sparse ? 4 : 8) ? 1 : 0, partner, mirror_of, n_nodes,
                      p_nodes, n_rows, n_jobs, err_flag,
                      reinterpret_cast<unsigned long long*>(tot_nodes_alg));
   S3GRL_HIP_TRY(hipGetLastError());
@@ -721,7 +695,7 @@ s3grl_status launch_scan_i32_to_i64(s3grl_context* ctx, const int32_t* in, int64
 
 // fixed part of link_kernel's LDS: 3 bitmaps + cn + lvl_end + zbuf + scan scratch
 static inline int link_fixed_words(int64_t num_nodes, int cn_cap, int K) {
-  return 3 * words_for(num_nodes) + cn_cap + kMaxLevels + 4 * K + 32;
+  return 3 * words_for(num_nodes) + cn_cap + kMaxLevels + 4 * K + 32 + kHubWords;
 }
 
 // class c holds the links whose variable LDS need is <= bound[c] bytes; the last bound is
@@ -784,7 +758,8 @@ s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(T), lds, ctx->stream, a.g->indptr,
                      a.g->indices, W, a.links, a.class_list + (int64_t)cls * L, a.hops, a.plus,
-                     a.cn_cap, a.full_stats, a.debug_stop, a.p_nodes, a.node_off, a.row_ptr, a.job_off, a.coef_off,
+                     a.cn_cap, a.full_stats, a.debug_stop, a.g->max_degree > kHubFactor * G ? 1 : 0,
+                     a.p_nodes, a.node_off, a.row_ptr, a.job_off, a.coef_off,
                      a.mirror_of, a.c_ids, a.c_coef, a.jobs, a.job_z, a.row_nodes, a.lvl,
                      reinterpret_cast<unsigned long long*>(a.tot_edges),
                      reinterpret_cast<unsigned long long*>(a.tot_support),
@@ -817,9 +792,12 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
   for (int c = kNumClasses - 1; c >= 0; --c) {
     const int count = class_count_host[c];
     if (count == 0) continue;
-    // larger subgraphs leave room for fewer workgroups per CU: give them more waves each
-    if (c <= 2) S3GRL_TRY((launch_link_class<256, K>(ctx, a, L, c, count)));
-    else if (c == 3) S3GRL_TRY((launch_link_class<512, K>(ctx, a, L, c, count)));
+    // Fewer workgroups fit a CU as the LDS per workgroup grows (bigger subgraph class, or a big
+    // graph whose three N-bit bitmaps alone take tens of KB): give each more waves then.
+    const size_t lds = (size_t)4 * link_fixed_words(a.g->num_nodes, a.cn_cap, K) +
+                       class_bounds(a.g->num_nodes, a.cn_cap, K).b[c];
+    if (lds <= 40 * 1024) S3GRL_TRY((launch_link_class<256, K>(ctx, a, L, c, count)));
+    else if (lds <= 80 * 1024) S3GRL_TRY((launch_link_class<512, K>(ctx, a, L, c, count)));
     else S3GRL_TRY((launch_link_class<1024, K>(ctx, a, L, c, count)));
   }
   return S3GRL_OK;
