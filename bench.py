@@ -28,10 +28,15 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MI
 
 def algorithmic_bytes(stats, F, K):
     """B_link = 8n + 4 vol(S) + 4 n F + 4 R (K+1)(1+F), summed exactly from the plan.
-    Returned as (whole path, gather-kernel share = feature rows read once + output written once)."""
+    Returns (whole path over ALL links, gather share over all links, gather share over the links
+    the gather launch actually processes).  The last one is what `roofline.achieved` uses: a link
+    that is the reversed duplicate of an earlier one is served by that link's extraction — its
+    output rows are written (counted) but no feature rows are fetched for it (not counted)."""
     n, vol, R = stats["total_nodes"], stats["total_volume"], stats["total_rows"]
-    gather = 4 * n * F + 4 * R * (K + 1) * (1 + F)
-    return 8 * n + 4 * vol + gather, gather
+    out_bytes = 4 * R * (K + 1) * (1 + F)
+    gather_all = 4 * n * F + out_bytes
+    gather_launch = 4 * stats.get("extracted_nodes", n) * F + out_bytes
+    return 8 * n + 4 * vol + gather_all, gather_all, gather_launch
 
 
 def cpu_baseline(w, link_index, y, budget_s, max_links):
@@ -164,7 +169,7 @@ def main():
                        "features": F, "graph": "real topology, synthetic features (BASELINE.md §3)"},
         }
         if w.mode != "sop" and stats:
-            path_bytes, gather_bytes = algorithmic_bytes(stats, F, K)
+            path_bytes, gather_all, gather_bytes = algorithmic_bytes(stats, F, K)
             launches = max(tm["gather_launches"], 1.0)
             gather_ms = tm["gather_ms"] / launches
             achieved = gather_bytes / (gather_ms * 1e-3) / 1e9 if gather_ms > 0 else 0.0
@@ -181,6 +186,7 @@ def main():
                 "bound": "hbm", "kernel": "gather_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": gather_bytes, "kernel_ms": gather_ms,
+                "algorithmic_bytes_all_links": gather_all,
                 "path_algorithmic_bytes_per_step": path_bytes,
                 "path_achieved_GBps": path_bytes / (ms_per_step * 1e-3) / 1e9,
                 "phase_ms": {"structure": tm["structure_ms"] / max(tm["plans"], 1.0),
@@ -188,9 +194,10 @@ def main():
                              "gather": gather_ms},
                 "mean_subgraph_nodes": stats["total_nodes"] / max(L, 1),
                 "folded_links": stats.get("folded_links", 0),
-                "note": "algorithmic bytes count every link (SURVEY 8d); links that are the reversed "
-                        "duplicate of an earlier link (both directions of a train edge) are served "
-                        "by that link's extraction and move no feature bytes of their own; X sits in "
+                "note": "achieved = algorithmic bytes of the links the gather launch processes / its "
+                        "HIP-event duration; links that are the reversed duplicate of an earlier link "
+                        "(both directions of a train edge) are served by that link's extraction and "
+                        "are NOT counted here (path_* figures count every link, SURVEY 8d). X sits in "
                         "the 256 MB Infinity Cache, so achieved > HBM peak is cache-served traffic",
             }
         if not args.no_cpu_baseline:

@@ -413,6 +413,13 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   plan->stats.total_sub_edges = hs[2];
   plan->stats.total_support = hs[3];
   plan->stats.total_volume = hs[4];
+  if (getenv("S3GRL_DEBUG_STAMPS")) {   // diagnostic build aid: cycles per link_kernel phase
+    S3GRL_HIP_TRY(hipMemcpy(hs + 16, ds + 16, 8 * 8, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[s3grl] link_kernel phase cycles (sum over workgroups): bfs %lld  P/rank %lld  "
+                    "deg %lld  ops<K %lld  last op %lld  tail %lld\n",
+            (long long)hs[16], (long long)hs[17], (long long)hs[18], (long long)hs[19],
+            (long long)hs[20], (long long)hs[21]);
+  }
   plan->stats.workspace_bytes = (int64_t)ctx->arena.bytes_held();
   if (ctx->profiling) {
     float ms = 0;

@@ -71,8 +71,8 @@ __device__ __forceinline__ bool sorted_contains(const int32_t* a, int n, int x) 
 // Walks the CSR rows of list[r0..r1) with G lanes per row.  The passes built on this are bound
 // by dependent-load latency (list -> indptr -> indices -> LDS), not by lanes or bandwidth, so
 // UN row groups are in flight per wave: their id, row-bounds and first-neighbour loads are
-// issued back to back before anything is consumed.  visit(acc, v, u) is called for every stored
-// neighbour u of row v; commit(acc, t, v) once per row, by one lane, with acc summed over the
+// issued back to back before anything is consumed.  visit(acc, v, u, valid) is called for every
+// stored neighbour u of row v (and with valid = false for padding slots); commit(acc, t, v) once per row, by one lane, with acc summed over the
 // row (fixed reduction trees: bit-reproducible).
 // Hub rows (more than kHubFactor·G stored neighbours: a power-law hub would pin its G lanes for
 // hundreds of trips while the rest of the workgroup waits at the next barrier) are deferred to
@@ -137,26 +137,38 @@ __device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
       if (c0[u] >= e1[u]) first[u] = -1;
       if (c0[u] + G >= e1[u]) second[u] = -1;
     }
+    // visits are branch-free (a `valid` flag instead of a skipped call) and the first two
+    // neighbours of all UN rows are visited in one straight-line block, so that their LDS reads
+    // interleave instead of forming one long dependent chain per row
+    RowAcc acc[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      acc[u] = RowAcc{0.f, 0.f, 0};
+      const int vv = max(v[u], 0);
+      visit(acc[u], vv, max(first[u], 0), first[u] >= 0);
+      visit(acc[u], vv, max(second[u], 0), second[u] >= 0);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      // longer rows: two neighbours per lane in flight per trip
+      for (int c = c0[u] + 2 * G; c < e1[u]; c += 2 * G) {
+        const bool vb = c + G < e1[u];
+        const int ua = indices[c];
+        const int ub = indices[vb ? c + G : c];
+        visit(acc[u], v[u], ua, true);
+        visit(acc[u], v[u], ub, vb);
+      }
+    }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       if (v[u] >= 0) {
-        RowAcc acc{0.f, 0.f, 0};
-        if (first[u] >= 0) visit(acc, v[u], first[u]);
-        if (second[u] >= 0) visit(acc, v[u], second[u]);
-        // longer rows: two neighbours per lane in flight per trip
-        for (int c = c0[u] + 2 * G; c < e1[u]; c += 2 * G) {
-          const int ua = indices[c];
-          const int ub = indices[c + G < e1[u] ? c + G : c];
-          visit(acc, v[u], ua);
-          if (c + G < e1[u]) visit(acc, v[u], ub);
-        }
 #pragma unroll
         for (int o = G / 2; o > 0; o >>= 1) {
-          acc.x += __shfl_xor(acc.x, o);
-          acc.y += __shfl_xor(acc.y, o);
-          acc.n += __shfl_xor(acc.n, o);
+          acc[u].x += __shfl_xor(acc[u].x, o);
+          acc[u].y += __shfl_xor(acc[u].y, o);
+          acc[u].n += __shfl_xor(acc[u].n, o);
         }
-        if (g == 0) commit(acc, t[u], v[u]);
+        if (g == 0) commit(acc[u], t[u], v[u]);
       }
     }
   }
@@ -171,7 +183,7 @@ __device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
     const int v = list[tt];
     const int e1 = indptr[v + 1];
     RowAcc acc{0.f, 0.f, 0};
-    for (int c = indptr[v] + tid; c < e1; c += T) visit(acc, v, indices[c]);
+    for (int c = indptr[v] + tid; c < e1; c += T) visit(acc, v, indices[c], true);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       acc.x += __shfl_xor(acc.x, o);
@@ -245,12 +257,14 @@ __device__ __forceinline__ int bfs_list(const int32_t* __restrict__ indptr,
   int n = 2, nlev = 1;  // levels 0..nlev-1 are complete
   for (int d = 1; d <= hops; ++d) {
     const int f0 = d >= 2 ? lvl_end[d - 2] : 0, f1 = n;
-    walk_rows<T, G, 4>(
+    walk_rows<T, G, 2>(
         f0, f1, list, indptr, indices, hub,
-        [&](RowAcc&, int, int u) {
-          const uint32_t m = 1u << (u & 31);
-          const uint32_t old = atomicOr(&vis[u >> 5], m);
-          if (!(old & m)) atomicOr(&nxt[u >> 5], m);
+        [&](RowAcc&, int, int u, bool valid) {
+          if (valid) {
+            const uint32_t m = 1u << (u & 31);
+            const uint32_t old = atomicOr(&vis[u >> 5], m);
+            if (!(old & m)) atomicOr(&nxt[u >> 5], m);
+          }
         },
         [](RowAcc&, int, int) {});
     __syncthreads();

@@ -125,12 +125,14 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
   bool use_list = true;
   for (int d = 1; d <= hops; ++d) {
     if (use_list) {
-      walk_rows<kBlock, G, 4>(
+      walk_rows<kBlock, G, 2>(
           f0, f1, list, indptr, indices, hub,
-          [&](RowAcc&, int, int u) {
-            const uint32_t m = 1u << (u & 31);
-            const uint32_t old = atomicOr(&vis[u >> 5], m);
-            if (!(old & m)) atomicOr(&nxt[u >> 5], m);
+          [&](RowAcc&, int, int u, bool valid) {
+            if (valid) {
+              const uint32_t m = 1u << (u & 31);
+              const uint32_t old = atomicOr(&vis[u >> 5], m);
+              if (!(old & m)) atomicOr(&nxt[u >> 5], m);
+            }
           },
           [](RowAcc&, int, int) {});
     } else {
@@ -387,8 +389,16 @@ __global__ __launch_bounds__(T) void link_kernel(
     Job* __restrict__ jobs, float* __restrict__ job_z, int64_t* __restrict__ row_nodes,
     int32_t* __restrict__ lvl_out, unsigned long long* __restrict__ tot_edges,
     unsigned long long* __restrict__ tot_support, unsigned long long* __restrict__ tot_vol,
-    char* __restrict__ scratch, int64_t scratch_stride) {
+    char* __restrict__ scratch, int64_t scratch_stride, unsigned long long* __restrict__ dbg) {
   extern __shared__ uint32_t smem[];
+  unsigned long long t_prev = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+#define S3GRL_STAMP(idx)                                                              \
+  if (dbg) {                                                                          \
+    __syncthreads();                                                                  \
+    const unsigned long long t_now = __builtin_amdgcn_s_memtime();                    \
+    if (threadIdx.x == 0) atomicAdd(&dbg[idx], t_now - t_prev);                       \
+    t_prev = t_now;                                                                   \
+  }
   const int tid = threadIdx.x;
   const int l = class_list[blockIdx.x];
   const int64_t noff = node_off[l];
@@ -427,6 +437,7 @@ __global__ __launch_bounds__(T) void link_kernel(
   int nlev;
   const int n = bfs_list<T, G>(indptr, indices, W, src, dst, hops, vis, inP, list, lvl_end, sh, hub, nlev);
 
+  S3GRL_STAMP(0)
   if (debug_stop == 1) return;  // profiling aid: BFS only
   // ---- rows of this link ----------------------------------------------------------------
   const int64_t rp = row_ptr[l];
@@ -457,14 +468,15 @@ __global__ __launch_bounds__(T) void link_kernel(
     if (mirror >= 0) row_nodes[mrp + r] = r == 0 ? dst : (r == 1 ? src : cn[r - 2]);
   }
 
+  S3GRL_STAMP(1)
   if (debug_stop == 2) return;  // + P bitmap / ranks / lists
   // ---- D^-1/2 on P (inf -> 0) -------------------------------------------------------------
   // reference tuned_SIGN.py:153-161: structure only, target link removed, no self-loops added
   int edges_local = 0;
-  walk_rows<T, G, 4>(
+  walk_rows<T, G, 2>(
       0, p, list, indptr, indices, hub,
-      [&](RowAcc& a, int v, int u) {
-        a.n += (test_bit(vis, u) && !((v == src && u == dst) || (v == dst && u == src))) ? 1 : 0;
+      [&](RowAcc& a, int v, int u, bool valid) {
+        a.n += (valid && test_bit(vis, u) && !((v == src && u == dst) || (v == dst && u == src))) ? 1 : 0;
       },
       [&](RowAcc& a, int, int v) {
         dinvP[rank_of(inP, wpreP, v)] = a.n > 0 ? 1.0f / sqrtf((float)a.n) : 0.0f;
@@ -472,6 +484,7 @@ __global__ __launch_bounds__(T) void link_kernel(
       });
   __syncthreads();
 
+  S3GRL_STAMP(2)
   if (debug_stop == 3) return;  // + degrees on P
   // ---- per row pair: K pull steps --------------------------------------------------------
   // State s_i[u] = dinv[u]·r_i[u] for u ∈ P (float2: rows a and b of the pair):
@@ -514,14 +527,17 @@ __global__ __launch_bounds__(T) void link_kernel(
 #pragma unroll 1
     for (int i = 0; i < K - 1; ++i) {
       const int limit = lvl_end[min(i + 1 + row_hop, nlev - 1)];  // <= p
-      walk_rows<T, G, 4>(
+      walk_rows<T, G, 2>(
           0, limit, list, indptr, indices, hub,
-          [&](RowAcc& a, int v, int u) {
-            if (test_bit(inP, u) && !((v == src && u == dst) || (v == dst && u == src))) {
-              const float2 sv = s_in[rank_of(inP, wpreP, u)];
-              a.x += sv.x;
-              a.y += sv.y;
-            }
+          [&](RowAcc& a, int v, int u, bool valid) {
+            // all LDS reads unconditional, the contribution selected afterwards
+            const uint32_t wp = inP[u >> 5];
+            const int r = (int)wpreP[u >> 5] + __popc(wp & ((1u << (u & 31)) - 1u));
+            const float2 sv = s_in[min(r, p - 1)];
+            const bool on = valid && ((wp >> (u & 31)) & 1u) &&
+                            !((v == src && u == dst) || (v == dst && u == src));
+            a.x += on ? sv.x : 0.f;
+            a.y += on ? sv.y : 0.f;
           },
           [&](RowAcc& a, int t, int v) {
             const int w = rank_of(inP, wpreP, v);
@@ -539,22 +555,25 @@ __global__ __launch_bounds__(T) void link_kernel(
       s_in = s_out;
       s_out = tmp;
     }
+    S3GRL_STAMP(3)
     if (debug_stop == 4) return;  // + operators 1..K-1
     {  // last operator: degree and sum of every reachable row in one pass over its CSR row
       const int i = K - 1;
       int edges_pass = 0;
-      walk_rows<T, G, 4>(
+      walk_rows<T, G, 2>(
           0, last_rows, list, indptr, indices, hub,
-          [&](RowAcc& a, int v, int u) {
+          [&](RowAcc& a, int v, int u, bool valid) {
+            // all LDS reads unconditional, count and contribution selected afterwards
             const uint32_t bit = 1u << (u & 31);
-            if ((vis[u >> 5] & bit) && !((v == src && u == dst) || (v == dst && u == src))) {
-              ++a.n;
-              if (inP[u >> 5] & bit) {
-                const float2 sv = s_in[rank_of(inP, wpreP, u)];
-                a.x += sv.x;
-                a.y += sv.y;
-              }
-            }
+            const uint32_t wv = vis[u >> 5], wp = inP[u >> 5];
+            const int r = (int)wpreP[u >> 5] + __popc(wp & (bit - 1u));
+            const float2 sv = s_in[min(r, p - 1)];
+            const bool in_s = valid && (wv & bit) &&
+                              !((v == src && u == dst) || (v == dst && u == src));
+            const bool on = in_s && (wp & bit);
+            a.n += in_s ? 1 : 0;
+            a.x += on ? sv.x : 0.f;
+            a.y += on ? sv.y : 0.f;
           },
           [&](RowAcc& a, int t, int v) {
             edges_pass += a.n;
@@ -569,6 +588,7 @@ __global__ __launch_bounds__(T) void link_kernel(
       if (pr == 0) edges_local = (last_rows == n) ? edges_pass : edges_local;
       __syncthreads();
     }
+    S3GRL_STAMP(4)
     if (tid < 2 * K) {
       const int i = tid >> 1, r = tid & 1;
       job_z[(jid * K + i) * 2 + r] = zbuf[(0 * K + i) * 2 + r] + zbuf[(1 * K + i) * 2 + r];
@@ -594,6 +614,7 @@ __global__ __launch_bounds__(T) void link_kernel(
   }
   // edges of the masked induced subgraph: exact when the last pass of pair 0 covered all of S
   // (always with full_stats; otherwise whenever K >= num_hops), else the edges of P's rows
+  S3GRL_STAMP(5)
   edges_local = block_sum<T>(edges_local, sh);
   vol_local = block_sum<T>(vol_local, sh);
   if (tid == 0) {
@@ -745,6 +766,7 @@ struct LinkArgs {
   int64_t *tot_edges, *tot_support, *tot_vol;
   char* scratch;
   int64_t scratch_stride;
+  unsigned long long* dbg;
 };
 
 template <int T, int K, int G, bool GS>
@@ -763,7 +785,8 @@ s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t 
                      a.mirror_of, a.c_ids, a.c_coef, a.jobs, a.job_z, a.row_nodes, a.lvl,
                      reinterpret_cast<unsigned long long*>(a.tot_edges),
                      reinterpret_cast<unsigned long long*>(a.tot_support),
-                     reinterpret_cast<unsigned long long*>(a.tot_vol), a.scratch, a.scratch_stride);
+                     reinterpret_cast<unsigned long long*>(a.tot_vol), a.scratch, a.scratch_stride,
+                     a.dbg);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -827,7 +850,8 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
   static const int debug_stop = getenv("S3GRL_DEBUG_STOP") ? atoi(getenv("S3GRL_DEBUG_STOP")) : 0;
   LinkArgs a{g, links, class_list, hops, plus, cn_cap, full_stats, debug_stop, p_nodes, node_off, row_ptr,
              job_off, coef_off, mirror_of, c_ids, c_coef, jobs, job_z, row_nodes, lvl, tot_edges,
-             tot_support, tot_vol, scratch, scratch_stride};
+             tot_support, tot_vol, scratch, scratch_stride,
+             getenv("S3GRL_DEBUG_STAMPS") ? reinterpret_cast<unsigned long long*>(ctx->d_scalars + 16) : nullptr};
   switch (K) {
     case 1: return launch_links_k<1>(ctx, a, L, class_count_host);
     case 2: return launch_links_k<2>(ctx, a, L, class_count_host);
