@@ -382,7 +382,7 @@ template <int T, int K, int G, bool GS>
 __global__ __launch_bounds__(T) void link_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int W,
     const int64_t* __restrict__ links, const int32_t* __restrict__ class_list, int hops, int plus,
-    int cn_cap, int full_stats, int debug_stop, int hubs, const int32_t* __restrict__ p_nodes,
+    int cn_cap, int full_stats, int hubs, const int32_t* __restrict__ p_nodes,
     const int64_t* __restrict__ node_off, const int64_t* __restrict__ row_ptr,
     const int64_t* __restrict__ job_off, const int64_t* __restrict__ coef_off,
     const int32_t* __restrict__ mirror_of, int32_t* __restrict__ c_ids, float* __restrict__ c_coef,
@@ -391,6 +391,8 @@ __global__ __launch_bounds__(T) void link_kernel(
     unsigned long long* __restrict__ tot_support, unsigned long long* __restrict__ tot_vol,
     char* __restrict__ scratch, int64_t scratch_stride, unsigned long long* __restrict__ dbg) {
   extern __shared__ uint32_t smem[];
+  // diagnostic only (S3GRL_DEBUG_STAMPS): cycles per phase, summed over workgroups; the extra
+  // barriers change the timing of the build they run in — read shares, not totals
   unsigned long long t_prev = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
 #define S3GRL_STAMP(idx)                                                              \
   if (dbg) {                                                                          \
@@ -438,7 +440,6 @@ __global__ __launch_bounds__(T) void link_kernel(
   const int n = bfs_list<T, G>(indptr, indices, W, src, dst, hops, vis, inP, list, lvl_end, sh, hub, nlev);
 
   S3GRL_STAMP(0)
-  if (debug_stop == 1) return;  // profiling aid: BFS only
   // ---- rows of this link ----------------------------------------------------------------
   const int64_t rp = row_ptr[l];
   const int R = (int)(row_ptr[l + 1] - rp);
@@ -469,7 +470,6 @@ __global__ __launch_bounds__(T) void link_kernel(
   }
 
   S3GRL_STAMP(1)
-  if (debug_stop == 2) return;  // + P bitmap / ranks / lists
   // ---- D^-1/2 on P (inf -> 0) -------------------------------------------------------------
   // reference tuned_SIGN.py:153-161: structure only, target link removed, no self-loops added
   int edges_local = 0;
@@ -485,7 +485,6 @@ __global__ __launch_bounds__(T) void link_kernel(
   __syncthreads();
 
   S3GRL_STAMP(2)
-  if (debug_stop == 3) return;  // + degrees on P
   // ---- per row pair: K pull steps --------------------------------------------------------
   // State s_i[u] = dinv[u]·r_i[u] for u ∈ P (float2: rows a and b of the pair):
   //   r_i[w] = dinv[w] · Σ_{u ∈ N_S(w)} s_{i-1}[u]            (Â symmetric: pull == r_{i-1}·Â)
@@ -556,7 +555,6 @@ __global__ __launch_bounds__(T) void link_kernel(
       s_out = tmp;
     }
     S3GRL_STAMP(3)
-    if (debug_stop == 4) return;  // + operators 1..K-1
     {  // last operator: degree and sum of every reachable row in one pass over its CSR row
       const int i = K - 1;
       int edges_pass = 0;
@@ -753,7 +751,7 @@ struct LinkArgs {
   const s3grl_graph* g;
   const int64_t* links;
   const int32_t* class_list;
-  int hops, plus, cn_cap, full_stats, debug_stop;
+  int hops, plus, cn_cap, full_stats;
   const int32_t* p_nodes;
   const int64_t *node_off, *row_ptr, *job_off, *coef_off;
   const int32_t* mirror_of;
@@ -780,7 +778,7 @@ s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(T), lds, ctx->stream, a.g->indptr,
                      a.g->indices, W, a.links, a.class_list + (int64_t)cls * L, a.hops, a.plus,
-                     a.cn_cap, a.full_stats, a.debug_stop, a.g->max_degree > kHubFactor * G ? 1 : 0,
+                     a.cn_cap, a.full_stats, a.g->max_degree > kHubFactor * G ? 1 : 0,
                      a.p_nodes, a.node_off, a.row_ptr, a.job_off, a.coef_off,
                      a.mirror_of, a.c_ids, a.c_coef, a.jobs, a.job_z, a.row_nodes, a.lvl,
                      reinterpret_cast<unsigned long long*>(a.tot_edges),
@@ -847,8 +845,7 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
     scratch_owner.ptrs.push_back(q);
     scratch = static_cast<char*>(q);
   }
-  static const int debug_stop = getenv("S3GRL_DEBUG_STOP") ? atoi(getenv("S3GRL_DEBUG_STOP")) : 0;
-  LinkArgs a{g, links, class_list, hops, plus, cn_cap, full_stats, debug_stop, p_nodes, node_off, row_ptr,
+  LinkArgs a{g, links, class_list, hops, plus, cn_cap, full_stats, p_nodes, node_off, row_ptr,
              job_off, coef_off, mirror_of, c_ids, c_coef, jobs, job_z, row_nodes, lvl, tot_edges,
              tot_support, tot_vol, scratch, scratch_stride,
              getenv("S3GRL_DEBUG_STAMPS") ? reinterpret_cast<unsigned long long*>(ctx->d_scalars + 16) : nullptr};
