@@ -15,11 +15,10 @@
 // 16-byte loads (64 lanes × 16 B = one 1 KiB wave-instruction per 256 columns), UNROLL rows
 // in flight per wave.  No LDS, no MFMA: 2·2K flop per 4 B of X.
 #include "s3grl_internal.hpp"
+#include "s3grl_gather_common.hpp"
 
 namespace s3grl {
 namespace {
-
-typedef float float4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kWavesPerBlock = 4;
 constexpr int kUnroll = 4;
@@ -96,45 +95,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_kernel(
     }
   }
 
-  // epilogue: rows are [K+1][1+F] fp32; the +1 label column makes them 4-byte aligned only.
-  // A folded reversed duplicate gets the same values with the two rows swapped.
-  const int Fp = F + 1;
-  const int64_t rstride = (int64_t)(K + 1) * Fp;
-  const int nrow = job.node_b >= 0 ? 2 : 1;
-  const int ncopy = job.mirror_row >= 0 ? 2 : 1;
-  for (int r = 0; r < nrow; ++r) {
-    const int node = r == 0 ? job.node_a : job.node_b;
-    const float* __restrict__ xr = X + (int64_t)node * ldx;
-    for (int m = 0; m < ncopy; ++m) {
-      const int64_t orow = m == 0 ? job.out_row + r
-                                  : job.mirror_row + (job.mirror_swap ? 1 - r : r);
-      float* __restrict__ out = rows + orow * rstride;
-#pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        if (cok[c]) {
-          const float4_t x0 = *reinterpret_cast<const float4_t*>(xr + coff[c]);
-          const int nv = min(4, F - coff[c]);  // F need not be a multiple of 4 (X is padded)
-          float* o = out + 1 + coff[c];
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (e < nv) o[e] = x0[e];
-#pragma unroll
-          for (int i = 0; i < K; ++i) {
-            const float4_t a = acc[i][r][c];
-            float* oi = out + (int64_t)(i + 1) * Fp + 1 + coff[c];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (e < nv) oi[e] = a[e];
-          }
-        }
-      }
-      if (blockIdx.y == 0 && lane <= K) {
-        const float z = lane == 0 ? (float)(r == 0 ? job.z_a : job.z_b)
-                                  : job_z[((int64_t)jid * K + (lane - 1)) * 2 + r];
-        out[(int64_t)lane * Fp] = z;
-      }
-    }
-  }
+  write_pair_rows<K, CH>(job, jid, acc, coff, cok, job_z, X, ldx, F, rows, blockIdx.y == 0);
 }
 
 template <int K>
