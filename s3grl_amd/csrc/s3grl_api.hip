@@ -269,7 +269,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
                    std::to_string(kMaxNodesLds));
     return S3GRL_ERR_GRAPH_TOO_LARGE;
   }
-  if (L >= (int64_t)INT32_MAX / (kNumClasses + 1)) return S3GRL_ERR_INVALID_ARGUMENT;
+  if (L >= (int64_t)INT32_MAX / 16) return S3GRL_ERR_INVALID_ARGUMENT;
   S3GRL_HIP_TRY(hipSetDevice(ctx->device));
   const int K = cfg->sign_k;
 
@@ -299,13 +299,14 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   S3GRL_TRY(arena_alloc(ctx, (size_t)L * 2, &plan->links, own));
   S3GRL_HIP_TRY(hipMemcpyAsync(plan->links, links, (size_t)L * 16, hipMemcpyDeviceToDevice,
                                ctx->stream));
-  int32_t *n_rows, *n_jobs, *p_nodes, *class_list, *class_count;
+  int32_t *n_rows, *n_jobs, *p_nodes, *lvl_max, *class_list, *class_count;
   int64_t* scan_ws;
   S3GRL_TRY(arena_alloc(ctx, (size_t)L, &plan->n_nodes, own));
   S3GRL_TRY(arena_alloc(ctx, (size_t)L, &n_rows, tr));
   S3GRL_TRY(arena_alloc(ctx, (size_t)L, &p_nodes, tr));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)L, &lvl_max, tr));
   S3GRL_TRY(arena_alloc(ctx, (size_t)L, &n_jobs, tr));
-  S3GRL_TRY(arena_alloc(ctx, (size_t)L * (kNumClasses + 1), &class_list, tr));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)L * num_class_lists(), &class_list, tr));
   S3GRL_TRY(arena_alloc(ctx, (size_t)scan_workspace_elems(L), &scan_ws, tr));
 
   // d_scalars (int64 x 32): [0] err flag, [1] max n, [2] Σ edges, [3] Σ support, [4] Σ vol,
@@ -329,8 +330,8 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
                                   mirror_of, ds + 7));
   }
   S3GRL_TRY(launch_count(ctx, g, plan->links, L, cfg->num_hops, plus ? 1 : 0, K, partner, mirror_of,
-                         plan->n_nodes, p_nodes, n_rows, n_jobs, reinterpret_cast<int32_t*>(ds),
-                         ds + 6));
+                         plan->n_nodes, p_nodes, n_rows, n_jobs, lvl_max,
+                         reinterpret_cast<int32_t*>(ds), ds + 6));
   if (fold) S3GRL_TRY(launch_mirror_rows(ctx, partner, L, n_rows));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, plan->n_nodes, L, plan->node_off, scan_ws));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_rows, L, plan->row_ptr, scan_ws));
@@ -339,7 +340,8 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   hipLaunchKernelGGL(max_i32_kernel, dim3(256), dim3(256), 0, ctx->stream, n_rows, L, ds + 5);
   S3GRL_HIP_TRY(hipGetLastError());
   // PoS has no common-neighbour rows: the LDS classes are known without a round trip
-  if (!plus) S3GRL_TRY(launch_classify(ctx, g, 1, K, plan->n_nodes, p_nodes, L, class_count, class_list));
+  if (!plus)
+    S3GRL_TRY(launch_classify(ctx, g, 1, K, plan->n_nodes, p_nodes, lvl_max, L, class_count, class_list));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs, ds, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs + 16, plan->node_off + L, 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs + 17, plan->row_ptr + L, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -358,15 +360,17 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   const int64_t tot_n = hs[16], tot_rows = hs[17], njobs = hs[18];
   const int cn_cap = (int)std::max<int64_t>(max_R - 2, 0) + 1;
   if (plus) {
-    S3GRL_TRY(launch_classify(ctx, g, cn_cap, K, plan->n_nodes, p_nodes, L, class_count, class_list));
+    S3GRL_TRY(launch_classify(ctx, g, cn_cap, K, plan->n_nodes, p_nodes, lvl_max, L, class_count,
+                              class_list));
     S3GRL_HIP_TRY(hipMemcpyAsync(hs + 8, ds + 8, 8 * 8, hipMemcpyDeviceToHost, ctx->stream));
     S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
-  int32_t class_count_host[kNumClasses + 2];   // [kNumClasses] = HBM-scratch class, [+1] its max need
+  int32_t class_count_host[16];   // [0..5] bitmap classes, [6] HBM-scratch class, [7] its max need,
+                                  // [8..13] hash classes (see classify_kernel)
   std::memcpy(class_count_host, hs + 8, sizeof(class_count_host));
   if (getenv("S3GRL_DEBUG")) {
     fprintf(stderr, "[s3grl] L=%lld max_n=%lld classes:", (long long)L, (long long)max_n);
-    for (int c = 0; c <= kNumClasses + 1; ++c) fprintf(stderr, " %d", class_count_host[c]);
+    for (int c = 0; c < 14; ++c) fprintf(stderr, " %d", class_count_host[c]);
     fprintf(stderr, "\n");
   }
   plan->stats.total_nodes = hs[6];          // algorithmic: a folded link counts like any other

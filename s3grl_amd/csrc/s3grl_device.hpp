@@ -74,18 +74,21 @@ __device__ __forceinline__ bool sorted_contains(const int32_t* a, int n, int x) 
 // issued back to back before anything is consumed.  visit(acc, v, u, valid) is called for every
 // stored neighbour u of row v (and with valid = false for padding slots); commit(acc, t, v) once per row, by one lane, with acc summed over the
 // row (fixed reduction trees: bit-reproducible).
-// Hub rows (more than kHubFactor·G stored neighbours: a power-law hub would pin its G lanes for
-// hundreds of trips while the rest of the workgroup waits at the next barrier) are deferred to
-// `hub` = {count, row positions…} in LDS and then walked one at a time by the WHOLE workgroup.
+// Hub rows (more than kHubFactor·G stored neighbours: a long row would pin its G lanes for dozens
+// of trips while the other rows of the wavefront idle) are deferred to `hub` = {count, row
+// positions…} in LDS and then walked by one whole wavefront each.
 // Must be called by every thread of the workgroup (contains barriers).
 struct RowAcc {
   float x, y;
   int n;
 };
 
-constexpr int kHubFactor = 64;
+constexpr int kHubFactor = 8;
+// the hub path (one extra barrier per walk) is armed only for graphs that have real hubs:
+// PubMed (max degree 171) runs 5 % faster without it, a power-law graph 20 % faster with it
+constexpr int kHubArmDegree = 256;
 constexpr int kHubCap = 255;     // deferred hub rows per call; further ones are walked in place
-constexpr int kHubWords = kHubCap + 1 + 64;   // hub list + block-reduction scratch
+constexpr int kHubWords = kHubCap + 1;   // {count, row positions...}
 
 template <int T, int G, int UN, typename Visit, typename Commit>
 __device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
@@ -172,41 +175,34 @@ __device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
       }
     }
   }
-  // deferred hub rows: the whole workgroup walks one row at a time.  hub == nullptr (uniform:
-  // the graph's maximum degree is below the hub threshold) skips the phase and its barriers.
+  // deferred hub rows: one WAVEFRONT per row (64 lanes stride it), several rows in parallel per
+  // workgroup, xor-tree reduction: no barrier per row.  hub == nullptr (uniform: the graph's
+  // maximum degree is below the hub threshold) skips the phase and its barriers.
   if (!hub) return;
   __syncthreads();
   const int nh = min(hub[0], kHubCap);
-  float* red = reinterpret_cast<float*>(hub + 1 + kHubCap);   // [T/64][3] <= 48 words
-  for (int h = 0; h < nh; ++h) {
+  const int lane = tid & 63;
+  for (int h = tid >> 6; h < nh; h += T / 64) {
     const int tt = hub[1 + h];
     const int v = list[tt];
     const int e1 = indptr[v + 1];
     RowAcc acc{0.f, 0.f, 0};
-    for (int c = indptr[v] + tid; c < e1; c += T) visit(acc, v, indices[c], true);
+    for (int c = indptr[v] + lane; c < e1; c += 128) {   // two neighbours per lane in flight
+      const bool vb = c + 64 < e1;
+      const int ua = indices[c];
+      const int ub = indices[vb ? c + 64 : c];
+      visit(acc, v, ua, true);
+      visit(acc, v, ub, vb);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       acc.x += __shfl_xor(acc.x, o);
       acc.y += __shfl_xor(acc.y, o);
       acc.n += __shfl_xor(acc.n, o);
     }
-    if ((tid & 63) == 0) {
-      red[(tid >> 6) * 3 + 0] = acc.x;
-      red[(tid >> 6) * 3 + 1] = acc.y;
-      red[(tid >> 6) * 3 + 2] = __int_as_float(acc.n);
-    }
-    __syncthreads();
-    if (tid == 0) {
-      RowAcc tot{0.f, 0.f, 0};
-      for (int w = 0; w < T / 64; ++w) {   // fixed order
-        tot.x += red[w * 3 + 0];
-        tot.y += red[w * 3 + 1];
-        tot.n += __float_as_int(red[w * 3 + 2]);
-      }
-      commit(tot, tt, v);
-    }
-    __syncthreads();
+    if (lane == 0) commit(acc, tt, v);
   }
+  __syncthreads();
   if (tid == 0) hub[0] = 0;
   __syncthreads();
 }
@@ -287,6 +283,109 @@ __device__ __forceinline__ int bfs_list(const int32_t* __restrict__ indptr,
     }
     if (added == 0) break;  // uniform: `added` is a block-wide total
     n += added;
+    if (tid == 0) lvl_end[d] = n;
+    nlev = d + 1;
+    __syncthreads();
+  }
+  __syncthreads();
+  nlev_out = nlev;
+  return n;
+}
+
+// ---------------------------------------------------------------------------------------
+// Hash-set flavour of the visited set, for graphs whose N-bit bitmaps would eat the LDS (a
+// 235 000-node graph needs 88 KB for three bitmaps, leaving one workgroup per CU for subgraphs
+// of ~100 nodes).  Open addressing over C = pow2 >= 2n slots: keys = global node ids, vals =
+// position of the node in the hop-major list (its local id).
+constexpr int kSparseLevelMax = 1024;   // nodes a BFS level may add in the hash flavour
+
+__device__ __forceinline__ uint32_t hs_home(int v, uint32_t mask) {
+  return ((uint32_t)v * 2654435761u >> 7) & mask;
+}
+
+__device__ __forceinline__ bool hs_insert(int32_t* keys, uint32_t mask, int v) {
+  uint32_t s = hs_home(v, mask);
+  for (;;) {
+    const int old = atomicCAS(&keys[s], -1, v);
+    if (old == -1) return true;
+    if (old == v) return false;
+    s = (s + 1) & mask;
+  }
+}
+
+// slot of v, or -1
+__device__ __forceinline__ int hs_find(const int32_t* keys, uint32_t mask, int v) {
+  uint32_t s = hs_home(v, mask);
+  for (;;) {
+    const int k = keys[s];
+    if (k == v) return (int)s;
+    if (k == -1) return -1;
+    s = (s + 1) & mask;
+  }
+}
+
+// Same contract as bfs_list (hop-major list, ascending id inside a hop, lvl_end), visited set =
+// hash.  New nodes are appended in discovery order and every finished level is rank-sorted
+// (each thread counts the smaller elements of the level: no barriers inside, levels are capped
+// at kSparseLevelMax by the caller's choice of links).  `cnt` is one LDS int.
+template <int T, int G>
+__device__ __forceinline__ int bfs_hash(const int32_t* __restrict__ indptr,
+                                        const int32_t* __restrict__ indices, int src, int dst,
+                                        int hops, int32_t* keys, int32_t* vals, uint32_t mask,
+                                        int32_t* list, int* lvl_end, int* cnt, int* hub,
+                                        int& nlev_out) {
+  const int tid = threadIdx.x;
+  for (uint32_t t = tid; t <= mask; t += T) keys[t] = -1;
+  __syncthreads();
+  if (tid == 0) {
+    const int a = min(src, dst), b = max(src, dst);
+    hs_insert(keys, mask, a);
+    hs_insert(keys, mask, b);
+    vals[hs_find(keys, mask, a)] = 0;
+    vals[hs_find(keys, mask, b)] = 1;
+    list[0] = a;
+    list[1] = b;
+    lvl_end[0] = 2;
+    *cnt = 2;
+    if (hub) hub[0] = 0;
+  }
+  __syncthreads();
+  int n = 2, nlev = 1;
+  for (int d = 1; d <= hops; ++d) {
+    const int f0 = d >= 2 ? lvl_end[d - 2] : 0, f1 = n;
+    walk_rows<T, G, 2>(
+        f0, f1, list, indptr, indices, hub,
+        [&](RowAcc&, int, int u, bool valid) {
+          if (valid && hs_insert(keys, mask, u)) list[atomicAdd(cnt, 1)] = u;
+        },
+        [](RowAcc&, int, int) {});
+    __syncthreads();
+    const int n_new = *cnt;
+    const int added = n_new - n;
+    if (added == 0) break;
+    // rank sort of list[n .. n_new): up to kSparseLevelMax / T elements per thread
+    constexpr int PER = (kSparseLevelMax + T - 1) / T;
+    int x[PER], r[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int t = tid + k * T;
+      x[k] = t < added ? list[n + t] : 0x7fffffff;
+      r[k] = 0;
+    }
+    for (int j = 0; j < added; ++j) {
+      const int y = list[n + j];   // same address in every lane: LDS broadcast
+#pragma unroll
+      for (int k = 0; k < PER; ++k) r[k] += y < x[k] ? 1 : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      if (tid + k * T < added) {
+        list[n + r[k]] = x[k];
+        vals[hs_find(keys, mask, x[k])] = n + r[k];
+      }
+    }
+    n = n_new;
     if (tid == 0) lvl_end[d] = n;
     nlev = d + 1;
     __syncthreads();

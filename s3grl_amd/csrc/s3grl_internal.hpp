@@ -156,8 +156,9 @@ struct Transient {  // released on scope exit (stream-ordered reuse is safe: one
 s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                           int hops, int plus, int K, const int32_t* partner,
                           const int32_t* mirror_of, int32_t* n_nodes, int32_t* p_nodes,
-                          int32_t* n_rows, int32_t* n_jobs, int32_t* err_flag,
+                          int32_t* n_rows, int32_t* n_jobs, int32_t* lvl_max, int32_t* err_flag,
                           int64_t* tot_nodes_alg);
+int num_class_lists();
 // folds a reversed duplicate (dst,src) of a link (src,dst) into it: partner[l] = primary of a
 // folded link (else -1), mirror_of[l] = the link folded into l (else -1)
 int64_t mirror_table_slots(int64_t L);
@@ -170,8 +171,9 @@ int64_t scan_workspace_elems(int64_t n);
 s3grl_status launch_scan_i32_to_i64(s3grl_context* ctx, const int32_t* in, int64_t n, int64_t* out,
                                     int64_t* workspace);
 s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_cap, int K,
-                             const int32_t* n_nodes, const int32_t* p_nodes, int64_t L,
-                             int32_t* class_count, int32_t* class_list);
+                             const int32_t* n_nodes, const int32_t* p_nodes,
+                             const int32_t* lvl_max, int64_t L, int32_t* class_count,
+                             int32_t* class_list);
 s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                           const int32_t* class_list, const int32_t* class_count_host, int hops,
                           int plus, int cn_cap, int full_stats, int K, const int32_t* p_nodes,

@@ -350,7 +350,7 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
     tmp.push_back(*q);
     return S3GRL_OK;
   };
-  int32_t *n_nodes, *p_nodes, *n_rows, *n_jobs, *class_list;
+  int32_t *n_nodes, *p_nodes, *n_rows, *n_jobs, *lvl_max, *class_list;
   int64_t *node_off, *scan_ws;
   double* scal;
   void* q;
@@ -358,6 +358,7 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
   S3GRL_TRY(alloc((size_t)L * 4, &q)); p_nodes = (int32_t*)q;
   S3GRL_TRY(alloc((size_t)L * 4, &q)); n_rows = (int32_t*)q;
   S3GRL_TRY(alloc((size_t)L * 4, &q)); n_jobs = (int32_t*)q;
+  S3GRL_TRY(alloc((size_t)L * 4, &q)); lvl_max = (int32_t*)q;
   S3GRL_TRY(alloc((size_t)L * 3 * 4, &q)); class_list = (int32_t*)q;
   S3GRL_TRY(alloc((size_t)(L + 1) * 8, &q)); node_off = (int64_t*)q;
   S3GRL_TRY(alloc((size_t)scan_workspace_elems(L) * 8, &q)); scan_ws = (int64_t*)q;
@@ -370,7 +371,7 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
   S3GRL_HIP_TRY(hipMemsetAsync(ds, 0, 32 * sizeof(int64_t), ctx->stream));
   // the ⌈K/2⌉-hop ball of {s,d}: same BFS as PoS, no row selection
   S3GRL_TRY(launch_count(ctx, g, links, L, HB, 0, 1, nullptr, nullptr, n_nodes, p_nodes, n_rows,
-                         n_jobs, reinterpret_cast<int32_t*>(ds), ds + 6));
+                         n_jobs, lvl_max, reinterpret_cast<int32_t*>(ds), ds + 6));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_nodes, L, node_off, scan_ws));
   const int fixed = 4 * (3 * W + kMaxLevels + 32 + kHubWords + 6 * 16) + 64;
   const int per_node = 4 + 16 * HB;
@@ -408,7 +409,7 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
     hipLaunchKernelGGL(kern, dim3((unsigned)cc[c]), dim3(TT), lds, ctx->stream, g->indptr,         \
                        g->indices, W, s->dinv, links, class_list + (int64_t)c * L, node_off, K,    \
-                       HB, g->max_degree > kHubFactor * GG ? 1 : 0, scal);                                                                  \
+                       HB, g->max_degree > kHubArmDegree ? 1 : 0, scal);                                                                  \
   } while (0)
     if (c == 0) {
       if (sparse) S3GRL_SOP_LAUNCH(256, 4); else S3GRL_SOP_LAUNCH(256, 8);

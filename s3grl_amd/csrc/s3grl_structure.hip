@@ -27,10 +27,10 @@ namespace {
 // For x ∉ {src,dst}: x ∈ N(src) ∩ N(dst) ∩ S.  src itself is selected iff src has a self-loop,
 // dst iff dst has one.  One wave walks row(src) (ascending) and emits global ids in ascending
 // order into out[] (may be null: count only).  Returns |CN|.
+template <typename Member>
 __device__ __forceinline__ int common_neighbours(const int32_t* __restrict__ indptr,
                                                  const int32_t* __restrict__ indices,
-                                                 const uint32_t* vis, int src, int dst,
-                                                 int32_t* out) {
+                                                 Member in_s, int src, int dst, int32_t* out) {
   const int lane = lane_id();
   const int32_t* row_s = indices + indptr[src];
   const int32_t* row_d = indices + indptr[dst];
@@ -43,7 +43,7 @@ __device__ __forceinline__ int common_neighbours(const int32_t* __restrict__ ind
     bool sel = false;
     if (c < cs) {
       x = row_s[c];
-      sel = x != dst && test_bit(vis, x) && (x == src || sorted_contains(row_d, cd, x));
+      sel = x != dst && in_s(x) && (x == src || sorted_contains(row_d, cd, x));
     }
     const unsigned long long bal = __ballot(sel);
     const unsigned long long below = __ballot(sel && x < dst);
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
     const int64_t* __restrict__ links, int hops, int plus, int K, int hubs,
     const int32_t* __restrict__ partner, const int32_t* __restrict__ mirror_of,
     int32_t* __restrict__ n_nodes, int32_t* __restrict__ p_nodes, int32_t* __restrict__ n_rows,
-    int32_t* __restrict__ n_jobs, int32_t* __restrict__ err_flag,
+    int32_t* __restrict__ n_jobs, int32_t* __restrict__ lvl_max, int32_t* __restrict__ err_flag,
     unsigned long long* __restrict__ tot_nodes_alg) {
   extern __shared__ uint32_t smem[];
   uint32_t* vis = smem;
@@ -89,6 +89,7 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
       p_nodes[l] = 0;
       n_rows[l] = 0;
       n_jobs[l] = 0;
+      lvl_max[l] = 0;
     }
     return;
   }
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
       p_nodes[l] = 0;
       n_rows[l] = 0;  // copied from the primary by mirror_rows_kernel
       n_jobs[l] = 0;
+      lvl_max[l] = 0;
     }
     return;
   }
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
   // The frontier is a node list (G lanes per node: no serial row walks) as long as the levels
   // below `hops` fit kCountList entries; beyond that it degrades to a bitmap walked one thread
   // per word.  cum_a / cum_b: nodes within K-1 / K hops (P for a row at hop 0 / hop 1).
-  int n = 2, cum_a = 2, cum_b = 2, f0 = 0, f1 = 2;
+  int n = 2, cum_a = 2, cum_b = 2, f0 = 0, f1 = 2, biggest = 2;
   bool use_list = true;
   for (int d = 1; d <= hops; ++d) {
     if (use_list) {
@@ -184,16 +186,19 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
       __syncthreads();
     }
     n += added;
+    biggest = max(biggest, added);
     if (d <= K - 1) cum_a = n;
     if (d <= K) cum_b = n;
   }
   int R = 2;
-  if (plus && wave_id() == 0) R = 2 + common_neighbours(indptr, indices, vis, src, dst, nullptr);
+  if (plus && wave_id() == 0)
+    R = 2 + common_neighbours(indptr, indices, [&](int x) { return test_bit(vis, x); }, src, dst, nullptr);
   if (tid == 0) {
     n_nodes[l] = n;
     p_nodes[l] = R > 2 ? cum_b : cum_a;
     n_rows[l] = R;
     n_jobs[l] = (R + 1) / 2;
+    lvl_max[l] = biggest;
     // algorithmic totals count a folded link as if it had been extracted on its own
     const unsigned long long mult = (mirror_of && mirror_of[l] >= 0) ? 2ull : 1ull;
     atomicAdd(tot_nodes_alg, mult * (unsigned long long)n);
@@ -332,27 +337,53 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restri
 
 // ---------------------------------------------------------------------------------------
 // LDS bytes link_kernel needs beyond its fixed part: list[n] + dinvP[p] + two float2 state
-// arrays [p] (+ alignment slack).
+// arrays [p] (+ alignment slack); the hash flavour adds its keys/vals tables.
 __host__ __device__ __forceinline__ int link_lds_need(int n, int p) { return 4 * n + 20 * p + 16; }
+__host__ __device__ __forceinline__ int link_lds_need_sparse(int n, int p) {
+  int C = 64;
+  while (C < 2 * n) C <<= 1;
+  return 8 * C + link_lds_need(n, p);
+}
 
 struct ClassBounds {
   int b[kNumClasses];
 };
 
+// class ids: 0..kNumClasses-1 bitmap flavour by LDS need, kNumClasses = HBM-scratch flavour,
+// kSparseBase.. = hash flavour by LDS need.  class_count[kNumClasses + 1] = max need of the
+// HBM-scratch class.
+constexpr int kSparseBase = kNumClasses + 2;
+constexpr int kNumLists = kSparseBase + kNumClasses;
+
 __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
-                                const int32_t* __restrict__ p_nodes, int64_t L, ClassBounds bound,
+                                const int32_t* __restrict__ p_nodes,
+                                const int32_t* __restrict__ lvl_max, int64_t L, ClassBounds bound,
+                                int sparse_mode, ClassBounds sbound,
                                 int32_t* __restrict__ class_count, int32_t* __restrict__ class_list) {
   const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int n = l < L ? n_nodes[l] : 0;
-  const int need = l < L ? link_lds_need(n, p_nodes[l]) : 0;
+  const int p = l < L ? p_nodes[l] : 0;
+  int need = link_lds_need(n, p);
   int c = 0;
+  bool sparse = false;
+  if (sparse_mode && n > 0 && lvl_max[l] <= kSparseLevelMax) {
+    const int sneed = link_lds_need_sparse(n, p);
+    if (sneed <= sbound.b[kNumClasses - 1]) {
+      sparse = true;
 #pragma unroll
-  for (int k = 0; k < kNumClasses; ++k) c += need > bound.b[k] ? 1 : 0;
+      for (int k = 0; k < kNumClasses; ++k) c += sneed > sbound.b[k] ? 1 : 0;
+      c += kSparseBase;
+    }
+  }
+  if (!sparse) {
+#pragma unroll
+    for (int k = 0; k < kNumClasses; ++k) c += need > bound.b[k] ? 1 : 0;
+  }
   if (n == 0) c = -1;
   // one atomic per (wave, class) instead of one per link
   const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int k = 0; k <= kNumClasses; ++k) {
+  for (int k = 0; k < kNumLists; ++k) {
+    if (k == kNumClasses + 1) continue;
     const unsigned long long m = __ballot(c == k);
     if (m == 0) continue;
     const int leader = __ffsll((long long)m) - 1;
@@ -378,7 +409,10 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
 // rest of S, and it needs no state there: its degree and its sum come out of the same pass.
 // GS = true: list / dinvP / state live in a per-workgroup HBM scratch slice instead of LDS (links
 // whose subgraph does not fit what the bitmaps leave of 160 KiB); same code, slower memory.
-template <int T, int K, int G, bool GS>
+// HS = true: the visited set is a hash table sized by the subgraph (keys/vals of C = pow2 >= 2n
+// slots) instead of three N-bit bitmaps, local id = position in the hop-major list: for graphs
+// whose bitmaps alone would take tens of KB of LDS per workgroup.  Same results bit for bit.
+template <int T, int K, int G, bool GS, bool HS>
 __global__ __launch_bounds__(T) void link_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int W,
     const int64_t* __restrict__ links, const int32_t* __restrict__ class_list, int hops, int plus,
@@ -409,10 +443,21 @@ __global__ __launch_bounds__(T) void link_kernel(
   const int mirror = mirror_of ? mirror_of[l] : -1;          // reversed duplicate folded into l
   const int64_t mrp = mirror >= 0 ? row_ptr[mirror] : -1;
 
+  // visited set: three bitmaps of W words, or (HS) keys + vals of C words each
+  uint32_t hmask = 0;
+  int set_words = 3 * W;
+  if constexpr (HS) {
+    int C = 64;
+    while (C < 2 * n_alloc) C <<= 1;
+    hmask = (uint32_t)(C - 1);
+    set_words = 2 * C;
+  }
   uint32_t* vis = smem;
   uint32_t* inP = smem + W;
   uint32_t* wpreP = smem + 2 * W;
-  int32_t* cn = reinterpret_cast<int32_t*>(smem + 3 * W);
+  int32_t* hkeys = reinterpret_cast<int32_t*>(smem);
+  int32_t* hvals = hkeys + (hmask + 1);
+  int32_t* cn = reinterpret_cast<int32_t*>(smem + set_words);
   int* lvl_end = cn + cn_cap;
   float* zbuf = reinterpret_cast<float*>(lvl_end + kMaxLevels);  // [2 (src,dst)][K][2 (rows)]
   int* sh = reinterpret_cast<int*>(zbuf + 4 * K);
@@ -428,7 +473,7 @@ __global__ __launch_bounds__(T) void link_kernel(
   } else {
     list = sh + 32 + kHubWords;
     dinvP = reinterpret_cast<float*>(list + n_alloc);
-    const int fixed_words = 3 * W + cn_cap + kMaxLevels + 4 * K + 32 + kHubWords;
+    const int fixed_words = set_words + cn_cap + kMaxLevels + 4 * K + 32 + kHubWords;
     cur = reinterpret_cast<float2*>(smem + ((fixed_words + n_alloc + p_alloc + 1) & ~1));
   }
   float2* nxs = cur + p_alloc;
@@ -437,7 +482,22 @@ __global__ __launch_bounds__(T) void link_kernel(
 
   // ---- BFS on the unmasked graph (reference utils.py:53-74) --------------------------------
   int nlev;
-  const int n = bfs_list<T, G>(indptr, indices, W, src, dst, hops, vis, inP, list, lvl_end, sh, hub, nlev);
+  int n;
+  if constexpr (HS)
+    n = bfs_hash<T, G>(indptr, indices, src, dst, hops, hkeys, hvals, hmask, list, lvl_end, sh + 31,
+                       hub, nlev);
+  else
+    n = bfs_list<T, G>(indptr, indices, W, src, dst, hops, vis, inP, list, lvl_end, sh, hub, nlev);
+  // set queries of the passes below: membership in S; index into the P-state arrays (+ is it in P);
+  // the P-state index of list entry t (= node v)
+  auto in_s = [&](int u) -> bool {
+    if constexpr (HS) return hs_find(hkeys, hmask, u) >= 0;
+    else return test_bit(vis, u);
+  };
+  auto p_index_of_row = [&](int t, int v) -> int {
+    if constexpr (HS) { (void)v; return t; }
+    else { (void)t; return rank_of(inP, wpreP, v); }
+  };
 
   S3GRL_STAMP(0)
   // ---- rows of this link ----------------------------------------------------------------
@@ -447,9 +507,11 @@ __global__ __launch_bounds__(T) void link_kernel(
   const int p = lvl_end[min(K - 1 + max_row_hop, nlev - 1)];
 
   // ---- P as bitmap + rank prefix; node list out -------------------------------------------
-  for (int t = tid; t < p; t += T) {
-    const int v = list[t];
-    atomicOr(&inP[v >> 5], 1u << (v & 31));
+  if constexpr (!HS) {
+    for (int t = tid; t < p; t += T) {
+      const int v = list[t];
+      atomicOr(&inP[v >> 5], 1u << (v & 31));
+    }
   }
   int vol_local = 0;   // vol(S) = Σ global degrees, the 4·vol(S) term of the algorithmic bytes
   for (int t = tid; t < n; t += T) {
@@ -457,9 +519,9 @@ __global__ __launch_bounds__(T) void link_kernel(
     c_ids[noff + t] = v;
     vol_local += indptr[v + 1] - indptr[v];
   }
-  if (plus && wave_id() == 0) common_neighbours(indptr, indices, vis, src, dst, cn);
+  if (plus && wave_id() == 0) common_neighbours(indptr, indices, in_s, src, dst, cn);
   __syncthreads();
-  rank_prefix<T>(inP, wpreP, W, sh);
+  if constexpr (!HS) rank_prefix<T>(inP, wpreP, W, sh);
   __syncthreads();
   if (tid == 0)
     for (int d = 0; d < kMaxLevels; ++d)
@@ -476,10 +538,10 @@ __global__ __launch_bounds__(T) void link_kernel(
   walk_rows<T, G, 2>(
       0, p, list, indptr, indices, hub,
       [&](RowAcc& a, int v, int u, bool valid) {
-        a.n += (valid && test_bit(vis, u) && !((v == src && u == dst) || (v == dst && u == src))) ? 1 : 0;
+        a.n += (valid && in_s(u) && !((v == src && u == dst) || (v == dst && u == src))) ? 1 : 0;
       },
-      [&](RowAcc& a, int, int v) {
-        dinvP[rank_of(inP, wpreP, v)] = a.n > 0 ? 1.0f / sqrtf((float)a.n) : 0.0f;
+      [&](RowAcc& a, int t, int v) {
+        dinvP[p_index_of_row(t, v)] = a.n > 0 ? 1.0f / sqrtf((float)a.n) : 0.0f;
         edges_local += a.n;
       });
   __syncthreads();
@@ -511,10 +573,14 @@ __global__ __launch_bounds__(T) void link_kernel(
     if (tid < 4 * K) zbuf[tid] = 0.f;
     __syncthreads();
     if (tid == 0) {
-      const int la = rank_of(inP, wpreP, node_a);
+      auto p_index = [&](int v) -> int {
+        if constexpr (HS) return hvals[hs_find(hkeys, hmask, v)];
+        else return rank_of(inP, wpreP, v);
+      };
+      const int la = p_index(node_a);
       cur[la].x = dinvP[la];
       if (node_b >= 0) {
-        const int lb = rank_of(inP, wpreP, node_b);
+        const int lb = p_index(node_b);
         cur[lb].y = dinvP[lb];
       }
     }
@@ -529,17 +595,26 @@ __global__ __launch_bounds__(T) void link_kernel(
       walk_rows<T, G, 2>(
           0, limit, list, indptr, indices, hub,
           [&](RowAcc& a, int v, int u, bool valid) {
-            // all LDS reads unconditional, the contribution selected afterwards
-            const uint32_t wp = inP[u >> 5];
-            const int r = (int)wpreP[u >> 5] + __popc(wp & ((1u << (u & 31)) - 1u));
-            const float2 sv = s_in[min(r, p - 1)];
-            const bool on = valid && ((wp >> (u & 31)) & 1u) &&
-                            !((v == src && u == dst) || (v == dst && u == src));
+            bool on;
+            float2 sv;
+            if constexpr (HS) {
+              const int slot = hs_find(hkeys, hmask, u);
+              const int r = hvals[max(slot, 0)];
+              sv = s_in[min(max(r, 0), p - 1)];
+              on = valid && slot >= 0 && r < p;
+            } else {
+              // all LDS reads unconditional, the contribution selected afterwards
+              const uint32_t wp = inP[u >> 5];
+              const int r = (int)wpreP[u >> 5] + __popc(wp & ((1u << (u & 31)) - 1u));
+              sv = s_in[min(r, p - 1)];
+              on = valid && ((wp >> (u & 31)) & 1u);
+            }
+            on = on && !((v == src && u == dst) || (v == dst && u == src));
             a.x += on ? sv.x : 0.f;
             a.y += on ? sv.y : 0.f;
           },
           [&](RowAcc& a, int t, int v) {
-            const int w = rank_of(inP, wpreP, v);
+            const int w = p_index_of_row(t, v);
             const float dw = dinvP[w];
             const float rx = dw * a.x, ry = dw * a.y;
             s_out[w] = make_float2(dw * rx, dw * ry);
@@ -561,15 +636,27 @@ __global__ __launch_bounds__(T) void link_kernel(
       walk_rows<T, G, 2>(
           0, last_rows, list, indptr, indices, hub,
           [&](RowAcc& a, int v, int u, bool valid) {
-            // all LDS reads unconditional, count and contribution selected afterwards
-            const uint32_t bit = 1u << (u & 31);
-            const uint32_t wv = vis[u >> 5], wp = inP[u >> 5];
-            const int r = (int)wpreP[u >> 5] + __popc(wp & (bit - 1u));
-            const float2 sv = s_in[min(r, p - 1)];
-            const bool in_s = valid && (wv & bit) &&
-                              !((v == src && u == dst) || (v == dst && u == src));
-            const bool on = in_s && (wp & bit);
-            a.n += in_s ? 1 : 0;
+            bool member, on;
+            float2 sv;
+            if constexpr (HS) {
+              const int slot = hs_find(hkeys, hmask, u);
+              const int r = hvals[max(slot, 0)];
+              sv = s_in[min(max(r, 0), p - 1)];
+              member = valid && slot >= 0;
+              on = member && r < p;
+            } else {
+              // all LDS reads unconditional, count and contribution selected afterwards
+              const uint32_t bit = 1u << (u & 31);
+              const uint32_t wv = vis[u >> 5], wp = inP[u >> 5];
+              const int r = (int)wpreP[u >> 5] + __popc(wp & (bit - 1u));
+              sv = s_in[min(r, p - 1)];
+              member = valid && (wv & bit);
+              on = member && (wp & bit);
+            }
+            const bool masked = (v == src && u == dst) || (v == dst && u == src);
+            member = member && !masked;
+            on = on && !masked;
+            a.n += member ? 1 : 0;
             a.x += on ? sv.x : 0.f;
             a.y += on ? sv.y : 0.f;
           },
@@ -676,7 +763,7 @@ s3grl_status launch_mirror_rows(s3grl_context* ctx, const int32_t* partner, int6
 s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                           int hops, int plus, int K, const int32_t* partner,
                           const int32_t* mirror_of, int32_t* n_nodes, int32_t* p_nodes,
-                          int32_t* n_rows, int32_t* n_jobs, int32_t* err_flag,
+                          int32_t* n_rows, int32_t* n_jobs, int32_t* lvl_max, int32_t* err_flag,
                           int64_t* tot_nodes_alg) {
   if (L == 0) return S3GRL_OK;
   const int W = words_for(g->num_nodes);
@@ -687,8 +774,8 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)L), dim3(kBlock), lds, ctx->stream, g->indptr,
                      g->indices, (int)g->num_nodes, W, links, hops, plus, K,
-                     g->max_degree > kHubFactor * (sparse ? 4 : 8) ? 1 : 0, partner, mirror_of, n_nodes,
-                     p_nodes, n_rows, n_jobs, err_flag,
+                     g->max_degree > kHubArmDegree ? 1 : 0, partner, mirror_of, n_nodes,
+                     p_nodes, n_rows, n_jobs, lvl_max, err_flag,
                      reinterpret_cast<unsigned long long*>(tot_nodes_alg));
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
@@ -712,9 +799,12 @@ s3grl_status launch_scan_i32_to_i64(s3grl_context* ctx, const int32_t* in, int64
   return S3GRL_OK;
 }
 
-// fixed part of link_kernel's LDS: 3 bitmaps + cn + lvl_end + zbuf + scan scratch
+// fixed part of link_kernel's LDS: 3 bitmaps + cn + lvl_end + zbuf + scan scratch + hub list
 static inline int link_fixed_words(int64_t num_nodes, int cn_cap, int K) {
   return 3 * words_for(num_nodes) + cn_cap + kMaxLevels + 4 * K + 32 + kHubWords;
+}
+static inline int link_fixed_words_sparse(int cn_cap, int K) {
+  return cn_cap + kMaxLevels + 4 * K + 32 + kHubWords;
 }
 
 // class c holds the links whose variable LDS need is <= bound[c] bytes; the last bound is
@@ -728,10 +818,27 @@ static ClassBounds class_bounds(int64_t num_nodes, int cn_cap, int K) {
   cb.b[kNumClasses - 1] = avail;
   return cb;
 }
+static ClassBounds class_bounds_sparse(int cn_cap, int K) {
+  static const int nominal[kNumClasses] = {4096, 8192, 16384, 32768, 65536, 131072};
+  const int avail = 163840 - 4 * link_fixed_words_sparse(cn_cap, K);
+  ClassBounds cb;
+  for (int c = 0; c < kNumClasses; ++c) cb.b[c] = std::min(nominal[c], avail);
+  return cb;
+}
+
+// The hash flavour pays off when the bitmaps alone would hold a CU to a few workgroups.
+bool sparse_mode_for(const s3grl_graph* g) {
+  if (getenv("S3GRL_FORCE_HASH")) return true;   // test hook
+  if (getenv("S3GRL_NO_HASH")) return false;
+  return 3 * (size_t)words_for(g->num_nodes) * 4 > 24 * 1024;
+}
+
+int num_class_lists() { return kNumLists; }
 
 s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_cap, int K,
-                             const int32_t* n_nodes, const int32_t* p_nodes, int64_t L,
-                             int32_t* class_count, int32_t* class_list) {
+                             const int32_t* n_nodes, const int32_t* p_nodes,
+                             const int32_t* lvl_max, int64_t L, int32_t* class_count,
+                             int32_t* class_list) {
   if (L == 0) return S3GRL_OK;
   const ClassBounds cb = class_bounds(g->num_nodes, cn_cap, K);
   if (cb.b[kNumClasses - 1] < 0) {
@@ -740,7 +847,8 @@ s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_ca
     return S3GRL_ERR_GRAPH_TOO_LARGE;
   }
   hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream,
-                     n_nodes, p_nodes, L, cb, class_count, class_list);
+                     n_nodes, p_nodes, lvl_max, L, cb, sparse_mode_for(g) ? 1 : 0,
+                     class_bounds_sparse(cn_cap, K), class_count, class_list);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -767,18 +875,22 @@ struct LinkArgs {
   unsigned long long* dbg;
 };
 
-template <int T, int K, int G, bool GS>
+template <int T, int K, int G, bool GS, bool HS>
 s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t L, int cls, int count) {
   const int W = words_for(a.g->num_nodes);
-  const ClassBounds cb = class_bounds(a.g->num_nodes, a.cn_cap, K);
-  const size_t lds = (size_t)4 * link_fixed_words(a.g->num_nodes, a.cn_cap, K) +
-                     (GS ? 0 : (size_t)cb.b[cls]);
-  auto kern = link_kernel<T, K, G, GS>;
+  size_t lds;
+  if (HS)
+    lds = (size_t)4 * link_fixed_words_sparse(a.cn_cap, K) +
+          class_bounds_sparse(a.cn_cap, K).b[cls - kSparseBase];
+  else
+    lds = (size_t)4 * link_fixed_words(a.g->num_nodes, a.cn_cap, K) +
+          (GS ? 0 : (size_t)class_bounds(a.g->num_nodes, a.cn_cap, K).b[cls]);
+  auto kern = link_kernel<T, K, G, GS, HS>;
   S3GRL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(T), lds, ctx->stream, a.g->indptr,
                      a.g->indices, W, a.links, a.class_list + (int64_t)cls * L, a.hops, a.plus,
-                     a.cn_cap, a.full_stats, a.g->max_degree > kHubFactor * G ? 1 : 0,
+                     a.cn_cap, a.full_stats, a.g->max_degree > kHubArmDegree ? 1 : 0,
                      a.p_nodes, a.node_off, a.row_ptr, a.job_off, a.coef_off,
                      a.mirror_of, a.c_ids, a.c_coef, a.jobs, a.job_z, a.row_nodes, a.lvl,
                      reinterpret_cast<unsigned long long*>(a.tot_edges),
@@ -796,12 +908,16 @@ s3grl_status launch_link_class(s3grl_context* ctx, const LinkArgs& a, int64_t L,
   static const int force_g = getenv("S3GRL_LANES_PER_ROW") ? atoi(getenv("S3GRL_LANES_PER_ROW")) : 0;
   const int gsel = force_g ? force_g : (mean_deg <= 6.0 ? 4 : 8);
   if (cls == kNumClasses) {   // HBM-scratch overflow class
-    if (gsel <= 4) return launch_link_class_g<1024, K, 4, true>(ctx, a, L, cls, count);
-    return launch_link_class_g<1024, K, 8, true>(ctx, a, L, cls, count);
+    if (gsel <= 4) return launch_link_class_g<1024, K, 4, true, false>(ctx, a, L, cls, count);
+    return launch_link_class_g<1024, K, 8, true, false>(ctx, a, L, cls, count);
   }
-  if (gsel == 2) return launch_link_class_g<T, K, 2, false>(ctx, a, L, cls, count);
-  if (gsel == 4) return launch_link_class_g<T, K, 4, false>(ctx, a, L, cls, count);
-  return launch_link_class_g<T, K, 8, false>(ctx, a, L, cls, count);
+  if (cls >= kSparseBase) {   // hash flavour
+    if (gsel <= 4) return launch_link_class_g<256, K, 4, false, true>(ctx, a, L, cls, count);
+    return launch_link_class_g<256, K, 8, false, true>(ctx, a, L, cls, count);
+  }
+  if (gsel == 2) return launch_link_class_g<T, K, 2, false, false>(ctx, a, L, cls, count);
+  if (gsel == 4) return launch_link_class_g<T, K, 4, false, false>(ctx, a, L, cls, count);
+  return launch_link_class_g<T, K, 8, false, false>(ctx, a, L, cls, count);
 }
 
 template <int K>
@@ -810,6 +926,9 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
   // largest subgraphs first: they are the long poles of the tail
   if (class_count_host[kNumClasses] > 0)
     S3GRL_TRY((launch_link_class<1024, K>(ctx, a, L, kNumClasses, class_count_host[kNumClasses])));
+  for (int c = kNumLists - 1; c >= kSparseBase; --c)
+    if (class_count_host[c] > 0)
+      S3GRL_TRY((launch_link_class<256, K>(ctx, a, L, c, class_count_host[c])));
   for (int c = kNumClasses - 1; c >= 0; --c) {
     const int count = class_count_host[c];
     if (count == 0) continue;

@@ -536,3 +536,35 @@ def test_hybrid_and_tuned_sign_twin(eng):
     assert "x1" not in data2 and "x2" not in data2 and f"x{K}" in data2
     G.close()
     clear_cache()
+
+
+@pytest.mark.parametrize("name,hops,K", [("rand300", 2, 3), ("usair", 2, 2), ("cora", 3, 3), ("probe5", 3, 5)])
+def test_hash_flavour_matches_bitmap_flavour(eng, monkeypatch, name, hops, K):
+    """Graphs whose bitmaps would hog the LDS use a hash table as visited set (HS = true); forced
+    here on small graphs: node lists, rows and statistics must be identical bit for bit."""
+    import torch
+
+    g = load_extract(name)
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = np.random.default_rng(31).standard_normal((n, 21))
+    G = eng.graph(A)
+    f = eng.features(X)
+    L = eng.links(g["links"].T)
+    for mode in ("pos", "pos_plus"):
+        monkeypatch.delenv("S3GRL_FORCE_HASH", raising=False)
+        p0 = eng.plan(G, L, mode=mode, num_hops=hops, sign_k=K, full_stats=True)
+        r0, e0 = p0.run(f), p0.export_subgraphs()
+        monkeypatch.setenv("S3GRL_FORCE_HASH", "1")
+        p1 = eng.plan(G, L, mode=mode, num_hops=hops, sign_k=K, full_stats=True)
+        r1, e1 = p1.run(f), p1.export_subgraphs()
+        monkeypatch.delenv("S3GRL_FORCE_HASH")
+        assert torch.equal(r0, r1) and torch.equal(p0.row_ptr(), p1.row_ptr())
+        assert torch.equal(p0.row_nodes(), p1.row_nodes())
+        for a, b in zip(e0, e1):
+            assert torch.equal(a, b)
+        s0, s1 = dict(p0.stats), dict(p1.stats)
+        s0.pop("workspace_bytes"), s1.pop("workspace_bytes")
+        assert s0 == s1
+        p0.close(), p1.close()
+    G.close()
