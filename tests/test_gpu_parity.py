@@ -568,3 +568,47 @@ def test_hash_flavour_matches_bitmap_flavour(eng, monkeypatch, name, hops, K):
         assert s0 == s1
         p0.close(), p1.close()
     G.close()
+
+
+def test_headline_workload_full_size(eng):
+    """BASELINE.json's headline config at full size (PubMed PoS sign_k=3, 3-hop, F=500, all
+    164 000 links of the three splits): size-independent properties on everything, and the fp64
+    oracle on a sample of links drawn from the full result."""
+    import torch
+    from s3grl_amd import workloads
+
+    w = workloads.make("pubmed_pos_k3")
+    link_index, y = w.split.all_links()
+    L = link_index.shape[1]
+    assert L == 164000
+    G = eng.graph(w.A)
+    f = eng.features(w.X)
+    res = eng.precompute(G, f, eng.links(link_index), mode="pos", num_hops=3, sign_k=3)
+    rows = res.rows
+    assert rows.shape == (2 * L, 4, 501) and res.stats["folded_links"] > 30000
+    X = torch.from_numpy(w.X).to(rows.device)
+    li = torch.from_numpy(link_index).to(rows.device)
+    # operator 0 is [1 | X[node]] for both centre rows of every link
+    assert torch.equal(rows[0::2, 0, 1:], X[li[0]]) and torch.equal(rows[1::2, 0, 1:], X[li[1]])
+    assert torch.all(rows[:, 0, 0] == 1)
+    # X >= 0 and every operator entry >= 0: nothing negative, nothing non-finite
+    assert torch.isfinite(rows).all() and (rows >= 0).all()
+    # both directions of a train edge: same rows, swapped
+    P = w.split.links["train"][0].shape[1]
+    key = {(int(a), int(b)): i for i, (a, b) in enumerate(link_index[:, :P].T)}
+    probe = np.random.default_rng(0).choice(P, 2000, replace=False)
+    fwd = torch.tensor(probe, device=rows.device)
+    rev = torch.tensor([key[(int(link_index[1, i]), int(link_index[0, i]))] for i in probe],
+                       device=rows.device)
+    assert torch.equal(rows[2 * fwd], rows[2 * rev + 1]) and torch.equal(rows[2 * fwd + 1], rows[2 * rev])
+    # sampled links against the fp64 oracle
+    rng = np.random.default_rng(1)
+    sample = np.concatenate([rng.choice(np.flatnonzero(y == 1), 40, replace=False),
+                             rng.choice(np.flatnonzero(y == 0), 40, replace=False)])
+    kw = {"sign_k": 3, "k_node_set_strategy": "intersection"}
+    ref, _, _ = oracle.collate_rows(
+        oracle.get_PoS_prepped_ds(link_index[:, sample], 3, w.A, w.X.astype(np.float64), 1, kw,
+                                  dtype=np.float64), 3)
+    idx = torch.tensor(np.stack([2 * sample, 2 * sample + 1], 1).reshape(-1), device=rows.device)
+    assert rel_err(rows[idx].cpu().numpy(), ref) < TOL
+    G.close()
