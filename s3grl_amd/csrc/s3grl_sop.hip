@@ -244,11 +244,21 @@ __global__ void sop_classify_kernel(const int32_t* __restrict__ n_nodes, int64_t
                                     int b0, int b1, int b2, int32_t* __restrict__ class_count,
                                     int32_t* __restrict__ class_list) {
   const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= L) return;
-  const int need = n_nodes[l] * per_node + 64;
-  const int c = need <= b0 ? 0 : (need <= b1 ? 1 : (need <= b2 ? 2 : 3));
-  const int slot = atomicAdd(&class_count[c], 1);
-  if (c < 3) class_list[(int64_t)c * L + slot] = (int32_t)l;
+  const int need = l < L ? n_nodes[l] * per_node + 64 : 0;
+  const int c = l >= L ? -1 : (need <= b0 ? 0 : (need <= b1 ? 1 : (need <= b2 ? 2 : 3)));
+  // one atomic per (wave, class) instead of one per link
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned long long m = __ballot(c == k);
+    if (m == 0) continue;
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&class_count[k], __popcll(m));
+    base = __shfl(base, leader);
+    if (c == k && k < 3)
+      class_list[(int64_t)k * L + base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)l;
+  }
 }
 
 }  // namespace
