@@ -40,7 +40,7 @@ typedef enum s3grl_status {
   S3GRL_ERR_NOT_IMPLEMENTED = 2,  /* maps to the reference's NotImplementedError:
                                      k_node_set_strategy other than "intersection"
                                      (tuned_SIGN.py:235; "union" is unusable as shipped),
-                                     directed graphs, per-hop sampling, random-walk subgraphs */
+                                     directed graphs, per-hop sampling */
   S3GRL_ERR_NO_FEATURES = 3,      /* X == NULL: the reference's `assert subgraph_features is not
                                      None` (tuned_SIGN.py:166,221) */
   S3GRL_ERR_OUT_OF_MEMORY = 4,
@@ -70,7 +70,11 @@ typedef struct s3grl_cfg {
   int32_t directed;  /* must be 0 (A_csc == None in every non-ogbl-citation2 run) */
   int32_t reserved[3]; /* [0] bit 0: per-link diagnostics — exact total_sub_edges even when
                           sign_k < num_hops, subgraph export for every link (turns folding of
-                          reversed duplicates off); bit 1: no folding; others must be 0 */
+                          reversed duplicates off); bit 1: no folding.
+                          [1] ScaLed subgraphs (reference utils.py:86-150, rw_kwargs): rw_m |
+                          rw_M << 16 — M random walks of length m per node replace the BFS,
+                          num_hops is ignored like in the reference; 0 = k-hop BFS.
+                          [2] seed of those walks */
 } s3grl_cfg;
 
 /* sizes a plan measured while extracting; the benchmark's algorithmic-bytes figure

@@ -53,7 +53,8 @@ def neighbors(fringe, A):
     return set(int(v) for v in A[fringe].indices)
 
 
-def k_hop_subgraph(src, dst, num_hops, A, node_features=None, y=1, order="canonical"):
+def k_hop_subgraph(src, dst, num_hops, A, node_features=None, y=1, order="canonical",
+                   rw_nodes=None):
     """k-hop enclosing subgraph of link (src, dst) — reference utils.py:47-85, non-rw branch
     with sample_ratio=1.0 / max_nodes_per_hop=None (every paper config), undirected.
 
@@ -64,6 +65,22 @@ def k_hop_subgraph(src, dst, num_hops, A, node_features=None, y=1, order="canoni
     Returns (nodes, sub_csr, dists, X_S, y) like the reference.
     """
     src, dst = int(src), int(dst)
+    if rw_nodes is not None:
+        # ScaLed branch with sign=True — reference utils.py:101-150: the node set is the union of
+        # the (cached) random-walk nodes of src and dst, made unique and sorted (torch.unique),
+        # then dst and src are moved to the front (:134-135); dists = [0, 0, 1, 1, ...] (:145-146);
+        # induced matrix and masking as in the BFS branch (:137-143).  num_hops plays no part.
+        rest = sorted(set(int(v) for v in rw_nodes) - {src, dst})
+        nodes = [src, dst] + rest
+        dists = [0, 0] + [1] * len(rest)
+        sub = A[nodes, :][:, nodes]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", ssp.SparseEfficiencyWarning)
+            sub[0, 1] = 0
+            sub[1, 0] = 0
+        if node_features is not None:
+            node_features = np.asarray(node_features)[nodes]
+        return nodes, sub, dists, node_features, y
     nodes = [src, dst]
     dists = [0, 0]
     visited = {src, dst}
@@ -116,12 +133,12 @@ def _powers(op, K):
 
 
 def pos_link(src, dst, num_hops, A, x, K, *, plus=False, strategy="intersection",
-             dtype=np.float32, order="canonical"):
+             dtype=np.float32, order="canonical", rw_nodes=None):
     """One iteration of the reference's PoS / PoS Plus hot loop — tuned_SIGN.py:147-187 and
     :202-260.  Returns a dict with x, x1..xK ([R, 1+F]), the selected local rows, the global
     ids of those rows, the node list and hop distances."""
     nodes, sub, dists, X_S, _ = k_hop_subgraph(src, dst, num_hops, A, node_features=x,
-                                                order=order)
+                                                order=order, rw_nodes=rw_nodes)
     n = sub.shape[0]
     op = normalized_subgraph_operator(sub, dtype)
     powers = _powers(op, K)
@@ -161,28 +178,30 @@ def _links(link_index):
 
 
 def get_PoS_prepped_ds(link_index, num_hops, A, x, y, sign_kwargs, *, dtype=np.float32,
-                       order="canonical"):
-    """Reference tuned_SIGN.py:137-189 (optimised PoS flow), one dict per link."""
+                       order="canonical", rw_node_sets=None):
+    """Reference tuned_SIGN.py:137-189 (optimised PoS flow), one dict per link.
+    `rw_node_sets[l]` = the random-walk node set of link l (ScaLed branch), else k-hop BFS."""
     assert x is not None
     K = sign_kwargs["sign_k"]
     out = []
-    for src, dst in _links(link_index):
-        d = pos_link(src, dst, num_hops, A, x, K, plus=False, dtype=dtype, order=order)
+    for l, (src, dst) in enumerate(_links(link_index)):
+        d = pos_link(src, dst, num_hops, A, x, K, plus=False, dtype=dtype, order=order,
+                     rw_nodes=None if rw_node_sets is None else rw_node_sets[l])
         d["y"] = y
         out.append(d)
     return out
 
 
 def get_PoS_Plus_prepped_ds(link_index, num_hops, A, x, y, sign_kwargs, *, dtype=np.float32,
-                            order="canonical"):
+                            order="canonical", rw_node_sets=None):
     """Reference tuned_SIGN.py:192-262 (optimised PoS Plus flow), one dict per link."""
     assert x is not None
     K = sign_kwargs["sign_k"]
     strat = sign_kwargs["k_node_set_strategy"]
     out = []
-    for src, dst in _links(link_index):
+    for l, (src, dst) in enumerate(_links(link_index)):
         d = pos_link(src, dst, num_hops, A, x, K, plus=True, strategy=strat, dtype=dtype,
-                     order=order)
+                     order=order, rw_nodes=None if rw_node_sets is None else rw_node_sets[l])
         d["y"] = y
         out.append(d)
     return out

@@ -315,6 +315,14 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   int64_t* hs = ctx->h_scalars;
   class_count = reinterpret_cast<int32_t*>(ds + 8);
   S3GRL_HIP_TRY(hipMemsetAsync(ds, 0, 32 * sizeof(int64_t), ctx->stream));
+  // ScaLed: per-node random walks replace the BFS (cfg.reserved[1] = m | M << 16, [2] = seed)
+  const int rw_m = cfg->reserved[1] & 0xffff, rw_M = (cfg->reserved[1] >> 16) & 0xffff;
+  int32_t* rw_raw = nullptr;
+  const int rw_len = rw_m * rw_M;
+  if (rw_len > 0) {
+    S3GRL_TRY(arena_alloc(ctx, (size_t)g->num_nodes * rw_len, &rw_raw, tr));
+    S3GRL_TRY(launch_random_walks(ctx, g, rw_m, rw_M, (uint32_t)cfg->reserved[2], rw_raw));
+  }
   // reversed duplicates (both directions of a train edge) are folded into one extraction
   int32_t *partner = nullptr, *mirror_of = nullptr;
   const bool fold = !(cfg->reserved[0] & 3) && !getenv("S3GRL_NO_MIRROR");
@@ -329,7 +337,8 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
     S3GRL_TRY(launch_find_mirrors(ctx, plan->links, L, g->num_nodes, keys, vals, slots, partner,
                                   mirror_of, ds + 7));
   }
-  S3GRL_TRY(launch_count(ctx, g, plan->links, L, cfg->num_hops, plus ? 1 : 0, K, partner, mirror_of,
+  S3GRL_TRY(launch_count(ctx, g, plan->links, L, cfg->num_hops, plus ? 1 : 0, K, rw_raw, rw_len,
+                         partner, mirror_of,
                          plan->n_nodes, p_nodes, n_rows, n_jobs, lvl_max,
                          reinterpret_cast<int32_t*>(ds), ds + 6));
   if (fold) S3GRL_TRY(launch_mirror_rows(ctx, partner, L, n_rows));
@@ -407,7 +416,8 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   S3GRL_TRY(arena_alloc(ctx, (size_t)L * kMaxLevels, &plan->lvl, own));
   S3GRL_TRY(record(ctx, 1));
   S3GRL_TRY(launch_links(ctx, g, plan->links, L, class_list, class_count_host, cfg->num_hops,
-                         plus ? 1 : 0, cn_cap, cfg->reserved[0] & 1, K, p_nodes, plan->node_off,
+                         plus ? 1 : 0, cn_cap, cfg->reserved[0] & 1, K, rw_raw, rw_len, p_nodes,
+                         plan->node_off,
                          plan->row_ptr, plan->job_off, coef_off, mirror_of, plan->c_ids,
                          plan->c_coef, plan->jobs, plan->job_z, plan->row_nodes, plan->lvl, ds + 2,
                          ds + 3, ds + 4));

@@ -233,8 +233,9 @@ template <int T, int G>
 __device__ __forceinline__ int bfs_list(const int32_t* __restrict__ indptr,
                                         const int32_t* __restrict__ indices, int W, int src,
                                         int dst, int hops, uint32_t* vis, uint32_t* nxt,
-                                        int32_t* list, int* lvl_end, int* sh, int* hub,
-                                        int& nlev_out) {
+                                        int32_t* list, int cap, int* lvl_end, int* sh, int* hub,
+                                        int& nlev_out, const int32_t* __restrict__ rw_raw = nullptr,
+                                        int rw_len = 0) {
   const int tid = threadIdx.x;
   for (int t = tid; t < W; t += T) {
     vis[t] = 0;
@@ -251,18 +252,28 @@ __device__ __forceinline__ int bfs_list(const int32_t* __restrict__ indptr,
   }
   __syncthreads();
   int n = 2, nlev = 1;  // levels 0..nlev-1 are complete
+  if (rw_raw) hops = 1;  // ScaLed: "level 1" = what the cached random walks of src and dst visited
   for (int d = 1; d <= hops; ++d) {
     const int f0 = d >= 2 ? lvl_end[d - 2] : 0, f1 = n;
-    walk_rows<T, G, 2>(
-        f0, f1, list, indptr, indices, hub,
-        [&](RowAcc&, int, int u, bool valid) {
-          if (valid) {
-            const uint32_t m = 1u << (u & 31);
-            const uint32_t old = atomicOr(&vis[u >> 5], m);
-            if (!(old & m)) atomicOr(&nxt[u >> 5], m);
-          }
-        },
-        [](RowAcc&, int, int) {});
+    if (rw_raw) {
+      for (int i = tid; i < 2 * rw_len; i += T) {
+        const int u = rw_raw[(int64_t)(i < rw_len ? src : dst) * rw_len + (i < rw_len ? i : i - rw_len)];
+        const uint32_t m = 1u << (u & 31);
+        const uint32_t old = atomicOr(&vis[u >> 5], m);
+        if (!(old & m)) atomicOr(&nxt[u >> 5], m);
+      }
+    } else {
+      walk_rows<T, G, 2>(
+          f0, f1, list, indptr, indices, hub,
+          [&](RowAcc&, int, int u, bool valid) {
+            if (valid) {
+              const uint32_t m = 1u << (u & 31);
+              const uint32_t old = atomicOr(&vis[u >> 5], m);
+              if (!(old & m)) atomicOr(&nxt[u >> 5], m);
+            }
+          },
+          [](RowAcc&, int, int) {});
+    }
     __syncthreads();
     // append the new level in ascending id order: every thread owns a contiguous run of
     // bitmap words, one block scan over the per-thread popcounts (2 barriers per level)
@@ -278,11 +289,12 @@ __device__ __forceinline__ int bfs_list(const int32_t* __restrict__ indptr,
       while (w) {
         const int b = __ffs(w) - 1;
         w &= w - 1;
-        list[pos++] = t * 32 + b;
+        if (pos < cap) list[pos] = t * 32 + b;   // cap = what the sizing pass counted: never exceeded
+        ++pos;                                   // unless the two passes disagree (then: no fault)
       }
     }
     if (added == 0) break;  // uniform: `added` is a block-wide total
-    n += added;
+    n = min(n + added, cap);
     if (tid == 0) lvl_end[d] = n;
     nlev = d + 1;
     __syncthreads();
@@ -332,8 +344,9 @@ template <int T, int G>
 __device__ __forceinline__ int bfs_hash(const int32_t* __restrict__ indptr,
                                         const int32_t* __restrict__ indices, int src, int dst,
                                         int hops, int32_t* keys, int32_t* vals, uint32_t mask,
-                                        int32_t* list, int* lvl_end, int* cnt, int* hub,
-                                        int& nlev_out) {
+                                        int32_t* list, int cap, int* lvl_end, int* cnt, int* hub,
+                                        int& nlev_out, const int32_t* __restrict__ rw_raw = nullptr,
+                                        int rw_len = 0) {
   const int tid = threadIdx.x;
   for (uint32_t t = tid; t <= mask; t += T) keys[t] = -1;
   __syncthreads();
@@ -351,16 +364,30 @@ __device__ __forceinline__ int bfs_hash(const int32_t* __restrict__ indptr,
   }
   __syncthreads();
   int n = 2, nlev = 1;
+  if (rw_raw) hops = 1;
   for (int d = 1; d <= hops; ++d) {
     const int f0 = d >= 2 ? lvl_end[d - 2] : 0, f1 = n;
-    walk_rows<T, G, 2>(
-        f0, f1, list, indptr, indices, hub,
-        [&](RowAcc&, int, int u, bool valid) {
-          if (valid && hs_insert(keys, mask, u)) list[atomicAdd(cnt, 1)] = u;
-        },
-        [](RowAcc&, int, int) {});
+    if (rw_raw) {
+      for (int i = tid; i < 2 * rw_len; i += T) {
+        const int u = rw_raw[(int64_t)(i < rw_len ? src : dst) * rw_len + (i < rw_len ? i : i - rw_len)];
+        if (hs_insert(keys, mask, u)) {
+          const int pos = atomicAdd(cnt, 1);
+          if (pos < cap) list[pos] = u;
+        }
+      }
+    } else {
+      walk_rows<T, G, 2>(
+          f0, f1, list, indptr, indices, hub,
+          [&](RowAcc&, int, int u, bool valid) {
+            if (valid && hs_insert(keys, mask, u)) {
+              const int pos = atomicAdd(cnt, 1);
+              if (pos < cap) list[pos] = u;
+            }
+          },
+          [](RowAcc&, int, int) {});
+    }
     __syncthreads();
-    const int n_new = *cnt;
+    const int n_new = min(*cnt, cap);
     const int added = n_new - n;
     if (added == 0) break;
     // rank sort of list[n .. n_new): up to kSparseLevelMax / T elements per thread

@@ -154,11 +154,13 @@ struct Transient {  // released on scope exit (stream-ordered reuse is safe: one
 
 // structure.hip
 s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
-                          int hops, int plus, int K, const int32_t* partner,
-                          const int32_t* mirror_of, int32_t* n_nodes, int32_t* p_nodes,
+                          int hops, int plus, int K, const int32_t* rw_raw, int rw_len,
+                          const int32_t* partner, const int32_t* mirror_of, int32_t* n_nodes, int32_t* p_nodes,
                           int32_t* n_rows, int32_t* n_jobs, int32_t* lvl_max, int32_t* err_flag,
                           int64_t* tot_nodes_alg);
 int num_class_lists();
+s3grl_status launch_random_walks(s3grl_context* ctx, const s3grl_graph* g, int m, int M,
+                                 uint32_t seed, int32_t* raw);
 // folds a reversed duplicate (dst,src) of a link (src,dst) into it: partner[l] = primary of a
 // folded link (else -1), mirror_of[l] = the link folded into l (else -1)
 int64_t mirror_table_slots(int64_t L);
@@ -176,7 +178,8 @@ s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_ca
                              int32_t* class_list);
 s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                           const int32_t* class_list, const int32_t* class_count_host, int hops,
-                          int plus, int cn_cap, int full_stats, int K, const int32_t* p_nodes,
+                          int plus, int cn_cap, int full_stats, int K, const int32_t* rw_raw,
+                          int rw_len, const int32_t* p_nodes,
                           const int64_t* node_off, const int64_t* row_ptr, const int64_t* job_off,
                           const int64_t* coef_off, const int32_t* mirror_of, int32_t* c_ids,
                           float* c_coef, Job* jobs, float* job_z, int64_t* row_nodes, int32_t* lvl,

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(T) void sop_scalar_kernel(
   const int src = (int)links[2 * (int64_t)l], dst = (int)links[2 * (int64_t)l + 1];
   const int g = tid & (G - 1);
   int nlev;
-  const int n = bfs_list<T, G>(indptr, indices, W, src, dst, HB, vis, nxt, list, lvl_end, sh, hub, nlev);
+  const int n = bfs_list<T, G>(indptr, indices, W, src, dst, HB, vis, nxt, list, n_alloc, lvl_end, sh, hub, nlev);
   rank_prefix<T>(vis, wpre, W, sh);
   for (int w = tid; w < n * HB; w += T) r[w] = make_double2(0.0, 0.0);
   __syncthreads();
@@ -380,7 +380,7 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
   if (ctx->profiling) S3GRL_HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
   S3GRL_HIP_TRY(hipMemsetAsync(ds, 0, 32 * sizeof(int64_t), ctx->stream));
   // the ⌈K/2⌉-hop ball of {s,d}: same BFS as PoS, no row selection
-  S3GRL_TRY(launch_count(ctx, g, links, L, HB, 0, 1, nullptr, nullptr, n_nodes, p_nodes, n_rows,
+  S3GRL_TRY(launch_count(ctx, g, links, L, HB, 0, 1, nullptr, 0, nullptr, nullptr, n_nodes, p_nodes, n_rows,
                          n_jobs, lvl_max, reinterpret_cast<int32_t*>(ds), ds + 6));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_nodes, L, node_off, scan_ws));
   const int fixed = 4 * (3 * W + kMaxLevels + 32 + kHubWords + 6 * 16) + 64;

@@ -70,7 +70,7 @@ template <int G>
 __global__ __launch_bounds__(kBlock) void count_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int N, int W,
     const int64_t* __restrict__ links, int hops, int plus, int K, int hubs,
-    const int32_t* __restrict__ partner, const int32_t* __restrict__ mirror_of,
+    const int32_t* __restrict__ rw_raw, int rw_len, const int32_t* __restrict__ partner, const int32_t* __restrict__ mirror_of,
     int32_t* __restrict__ n_nodes, int32_t* __restrict__ p_nodes, int32_t* __restrict__ n_rows,
     int32_t* __restrict__ n_jobs, int32_t* __restrict__ lvl_max, int32_t* __restrict__ err_flag,
     unsigned long long* __restrict__ tot_nodes_alg) {
@@ -125,8 +125,16 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
   // per word.  cum_a / cum_b: nodes within K-1 / K hops (P for a row at hop 0 / hop 1).
   int n = 2, cum_a = 2, cum_b = 2, f0 = 0, f1 = 2, biggest = 2;
   bool use_list = true;
+  if (rw_raw) hops = 1;  // ScaLed: the "hop" is what the cached random walks of src and dst visited
   for (int d = 1; d <= hops; ++d) {
-    if (use_list) {
+    if (rw_raw) {
+      for (int i = tid; i < 2 * rw_len; i += kBlock) {
+        const int u = rw_raw[(int64_t)(i < rw_len ? src : dst) * rw_len + (i < rw_len ? i : i - rw_len)];
+        const uint32_t m = 1u << (u & 31);
+        const uint32_t old = atomicOr(&vis[u >> 5], m);
+        if (!(old & m)) atomicOr(&nxt[u >> 5], m);
+      }
+    } else if (use_list) {
       walk_rows<kBlock, G, 2>(
           f0, f1, list, indptr, indices, hub,
           [&](RowAcc&, int, int u, bool valid) {
@@ -202,6 +210,39 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
     // algorithmic totals count a folded link as if it had been extracted on its own
     const unsigned long long mult = (mirror_of && mirror_of[l] >= 0) ? 2ull : 1ull;
     atomicAdd(tot_nodes_alg, mult * (unsigned long long)n);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// ScaLed subgraphs (reference utils.py:86-150 with sign=True, cache built by create_rw_cache
+// utils.py:425-443): M random walks of length m from every node, cached per NODE; the subgraph of
+// a link is {src,dst} plus everything the walks of src and of dst visited.  torch_cluster's
+// uniform walk is restated with a counter-based generator keyed by (seed, node, walk, step), so a
+// node's walks are the same in every link and every kernel that re-derives the subgraph.
+__device__ __forceinline__ uint32_t rw_random(uint32_t seed, uint32_t node, uint32_t walk,
+                                              uint32_t step) {
+  uint64_t x = ((uint64_t)seed << 32) ^ ((uint64_t)node * 0x9E3779B97F4A7C15ull) ^
+               ((uint64_t)walk << 20) ^ step;
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdull;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ull;
+  x ^= x >> 33;
+  return (uint32_t)(x >> 16);
+}
+
+__global__ void random_walks_kernel(const int32_t* __restrict__ indptr,
+                                    const int32_t* __restrict__ indices, int64_t N, int m, int M,
+                                    uint32_t seed, int32_t* __restrict__ raw /* [N, M*m] */) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * M) return;
+  const int64_t v = i / M;
+  const int w = (int)(i - v * M);
+  int cur = (int)v;
+  for (int s = 0; s < m; ++s) {
+    const int b = indptr[cur], deg = indptr[cur + 1] - b;
+    if (deg > 0) cur = indices[b + rw_random(seed, (uint32_t)v, (uint32_t)w, (uint32_t)s) % deg];
+    raw[(v * M + w) * m + s] = cur;   // an isolated node stays where it is
   }
 }
 
@@ -416,7 +457,8 @@ template <int T, int K, int G, bool GS, bool HS>
 __global__ __launch_bounds__(T) void link_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int W,
     const int64_t* __restrict__ links, const int32_t* __restrict__ class_list, int hops, int plus,
-    int cn_cap, int full_stats, int hubs, const int32_t* __restrict__ p_nodes,
+    int cn_cap, int full_stats, int hubs, const int32_t* __restrict__ rw_raw, int rw_len,
+    const int32_t* __restrict__ p_nodes,
     const int64_t* __restrict__ node_off, const int64_t* __restrict__ row_ptr,
     const int64_t* __restrict__ job_off, const int64_t* __restrict__ coef_off,
     const int32_t* __restrict__ mirror_of, int32_t* __restrict__ c_ids, float* __restrict__ c_coef,
@@ -484,10 +526,11 @@ __global__ __launch_bounds__(T) void link_kernel(
   int nlev;
   int n;
   if constexpr (HS)
-    n = bfs_hash<T, G>(indptr, indices, src, dst, hops, hkeys, hvals, hmask, list, lvl_end, sh + 31,
-                       hub, nlev);
+    n = bfs_hash<T, G>(indptr, indices, src, dst, hops, hkeys, hvals, hmask, list, n_alloc, lvl_end, sh + 31,
+                       hub, nlev, rw_raw, rw_len);
   else
-    n = bfs_list<T, G>(indptr, indices, W, src, dst, hops, vis, inP, list, lvl_end, sh, hub, nlev);
+    n = bfs_list<T, G>(indptr, indices, W, src, dst, hops, vis, inP, list, n_alloc, lvl_end, sh, hub, nlev,
+                       rw_raw, rw_len);
   // set queries of the passes below: membership in S; index into the P-state arrays (+ is it in P);
   // the P-state index of list entry t (= node v)
   auto in_s = [&](int u) -> bool {
@@ -751,6 +794,15 @@ s3grl_status launch_find_mirrors(s3grl_context* ctx, const int64_t* links, int64
   return S3GRL_OK;
 }
 
+s3grl_status launch_random_walks(s3grl_context* ctx, const s3grl_graph* g, int m, int M,
+                                 uint32_t seed, int32_t* raw) {
+  const int64_t total = g->num_nodes * M;
+  hipLaunchKernelGGL(random_walks_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     ctx->stream, g->indptr, g->indices, g->num_nodes, m, M, seed, raw);
+  S3GRL_HIP_TRY(hipGetLastError());
+  return S3GRL_OK;
+}
+
 s3grl_status launch_mirror_rows(s3grl_context* ctx, const int32_t* partner, int64_t L,
                                 int32_t* n_rows) {
   if (L == 0) return S3GRL_OK;
@@ -761,8 +813,8 @@ s3grl_status launch_mirror_rows(s3grl_context* ctx, const int32_t* partner, int6
 }
 
 s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
-                          int hops, int plus, int K, const int32_t* partner,
-                          const int32_t* mirror_of, int32_t* n_nodes, int32_t* p_nodes,
+                          int hops, int plus, int K, const int32_t* rw_raw, int rw_len,
+                          const int32_t* partner, const int32_t* mirror_of, int32_t* n_nodes, int32_t* p_nodes,
                           int32_t* n_rows, int32_t* n_jobs, int32_t* lvl_max, int32_t* err_flag,
                           int64_t* tot_nodes_alg) {
   if (L == 0) return S3GRL_OK;
@@ -774,7 +826,7 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)L), dim3(kBlock), lds, ctx->stream, g->indptr,
                      g->indices, (int)g->num_nodes, W, links, hops, plus, K,
-                     g->max_degree > kHubArmDegree ? 1 : 0, partner, mirror_of, n_nodes,
+                     g->max_degree > kHubArmDegree ? 1 : 0, rw_raw, rw_len, partner, mirror_of, n_nodes,
                      p_nodes, n_rows, n_jobs, lvl_max, err_flag,
                      reinterpret_cast<unsigned long long*>(tot_nodes_alg));
   S3GRL_HIP_TRY(hipGetLastError());
@@ -860,6 +912,8 @@ struct LinkArgs {
   const int64_t* links;
   const int32_t* class_list;
   int hops, plus, cn_cap, full_stats;
+  const int32_t* rw_raw;
+  int rw_len;
   const int32_t* p_nodes;
   const int64_t *node_off, *row_ptr, *job_off, *coef_off;
   const int32_t* mirror_of;
@@ -890,8 +944,8 @@ s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(T), lds, ctx->stream, a.g->indptr,
                      a.g->indices, W, a.links, a.class_list + (int64_t)cls * L, a.hops, a.plus,
-                     a.cn_cap, a.full_stats, a.g->max_degree > kHubArmDegree ? 1 : 0,
-                     a.p_nodes, a.node_off, a.row_ptr, a.job_off, a.coef_off,
+                     a.cn_cap, a.full_stats, a.g->max_degree > kHubArmDegree ? 1 : 0, a.rw_raw,
+                     a.rw_len, a.p_nodes, a.node_off, a.row_ptr, a.job_off, a.coef_off,
                      a.mirror_of, a.c_ids, a.c_coef, a.jobs, a.job_z, a.row_nodes, a.lvl,
                      reinterpret_cast<unsigned long long*>(a.tot_edges),
                      reinterpret_cast<unsigned long long*>(a.tot_support),
@@ -947,7 +1001,8 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
 
 s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                           const int32_t* class_list, const int32_t* class_count_host, int hops,
-                          int plus, int cn_cap, int full_stats, int K, const int32_t* p_nodes,
+                          int plus, int cn_cap, int full_stats, int K, const int32_t* rw_raw,
+                          int rw_len, const int32_t* p_nodes,
                           const int64_t* node_off, const int64_t* row_ptr, const int64_t* job_off,
                           const int64_t* coef_off, const int32_t* mirror_of, int32_t* c_ids,
                           float* c_coef, Job* jobs, float* job_z, int64_t* row_nodes, int32_t* lvl,
@@ -964,7 +1019,8 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
     scratch_owner.ptrs.push_back(q);
     scratch = static_cast<char*>(q);
   }
-  LinkArgs a{g, links, class_list, hops, plus, cn_cap, full_stats, p_nodes, node_off, row_ptr,
+  LinkArgs a{g, links, class_list, hops, plus, cn_cap, full_stats, rw_raw, rw_len, p_nodes, node_off,
+             row_ptr,
              job_off, coef_off, mirror_of, c_ids, c_coef, jobs, job_z, row_nodes, lvl, tot_edges,
              tot_support, tot_vol, scratch, scratch_stride,
              getenv("S3GRL_DEBUG_STAMPS") ? reinterpret_cast<unsigned long long*>(ctx->d_scalars + 16) : nullptr};

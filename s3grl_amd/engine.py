@@ -274,7 +274,7 @@ class Engine:
 
     # ---- the batched native entry ----------------------------------------------------------
     def plan(self, graph, links, *, mode="pos", num_hops=1, sign_k=3, strategy="intersection",
-             directed=False, full_stats=False, fold_reversed=True):
+             directed=False, full_stats=False, fold_reversed=True, rw=None):
         cfg = N.Cfg()
         cfg.mode = {"pos": N.MODE_POS, "pos_plus": N.MODE_POS_PLUS}[mode]
         cfg.num_hops = int(num_hops)
@@ -286,16 +286,24 @@ class Engine:
         # bit 0: per-link diagnostics (exact edge totals, export of every subgraph);
         # bit 1: do not fold reversed duplicates (d,s) into (s,d)
         cfg.reserved[0] = (1 if full_stats else 0) | (0 if fold_reversed else 2)
+        if rw is not None:
+            # ScaLed subgraphs (reference rw_kwargs): rw = (m, M[, seed]) — M walks of length m per
+            # node instead of the k-hop BFS
+            m, M = int(rw[0]), int(rw[1])
+            if not (0 < m < 65536 and 0 < M < 65536):
+                raise ValueError("rw = (m, M[, seed]) with 0 < m, M < 65536")
+            cfg.reserved[1] = m | (M << 16)
+            cfg.reserved[2] = int(rw[2]) & 0x7fffffff if len(rw) > 2 else 0
         return Plan(self, graph, links, cfg)
 
     def precompute(self, graph, x, links, *, mode="pos", num_hops=1, sign_k=3,
-                   strategy="intersection", directed=False, out=None):
+                   strategy="intersection", directed=False, out=None, rw=None):
         """links: int64 [L,2] device tensor (see `links()`); x: fp32 [N,F] device tensor."""
         if x is None:
             N.check(N.ERR_NO_FEATURES, "precompute")
         if mode == "hybrid":
             # reference utils.py:454-480: PoS keys kept, SoP x2..xK appended as x{K+1}..x{2K-1}
-            pos = self.precompute(graph, x, links, mode="pos", num_hops=num_hops, sign_k=sign_k)
+            pos = self.precompute(graph, x, links, mode="pos", num_hops=num_hops, sign_k=sign_k, rw=rw)
             if sign_k == 1:
                 return pos
             sop = self.precompute(graph, x, links, mode="sop", sign_k=sign_k)
@@ -312,7 +320,7 @@ class Engine:
             return Precomputed(rows, row_ptr, links.reshape(-1).clone(), {"num_links": L,
                                                                           "total_rows": 2 * L})
         plan = self.plan(graph, links, mode=mode, num_hops=num_hops, sign_k=sign_k,
-                         strategy=strategy, directed=directed)
+                         strategy=strategy, directed=directed, rw=rw)
         try:
             rows = plan.run(x, out)
             res = Precomputed(rows, plan.row_ptr(), plan.row_nodes(), dict(plan.stats))

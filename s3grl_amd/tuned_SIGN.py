@@ -7,9 +7,10 @@ static method uploads (and caches) A and x, runs the HIP engine once for the who
 returns a `list` of per-link `Data`-like objects that are views into one collated tensor.
 
 What is NOT mirrored (raises NotImplementedError, the reference's own convention for unsupported
-flows): random-walk / ScaLed subgraphs (`rw_kwargs`), per-hop sampling (`ratio_per_hop < 1`,
-`max_nodes_per_hop`), directed graphs (`A_csc`), and `k_node_set_strategy='union'`, which the
-reference itself cannot execute (tuned_SIGN.py:243 builds a ragged tensor).
+flows): per-hop sampling (`ratio_per_hop < 1`, `max_nodes_per_hop`), directed graphs (`A_csc`), and
+`k_node_set_strategy='union'`, which the reference itself cannot execute (tuned_SIGN.py:243
+builds a ragged tensor).  ScaLed random-walk subgraphs (`rw_kwargs`) are supported with the
+engine's own walks (same distribution, different random numbers than torch_cluster's).
 """
 from __future__ import annotations
 
@@ -115,10 +116,16 @@ def _as_data_list(res, K, y):
     return data_list
 
 
+def _rw_of(rw_kwargs):
+    """ScaLed settings of the reference's rw_kwargs (sgrl_link_pred.py:130-159): M walks of length
+    m per node.  The reference's cached walks (`cached_pos_rws`, torch_cluster RNG) cannot be
+    reproduced; the engine draws its own per-node walks from `rw_kwargs.get('seed', 0)`."""
+    if not rw_kwargs or not rw_kwargs.get('rw_m'):
+        return None
+    return (int(rw_kwargs['rw_m']), int(rw_kwargs['rw_M']), int(rw_kwargs.get('seed', 0)))
+
+
 def _check_unsupported(ratio_per_hop, max_nodes_per_hop, directed, A_csc, rw_kwargs):
-    if rw_kwargs:
-        raise NotImplementedError("random-walk (ScaLed) subgraphs are not implemented in the "
-                                  "MI355X engine yet")
     if ratio_per_hop is not None and ratio_per_hop < 1.0:
         raise NotImplementedError("ratio_per_hop < 1.0 (per-hop sampling) is not implemented")
     if max_nodes_per_hop is not None:
@@ -150,7 +157,8 @@ class OptimizedSignOperations:
         K = sign_kwargs['sign_k']
         assert x is not None                                  # tuned_SIGN.py:166
         eng, g, xd = _device_inputs(A, x)
-        res = eng.precompute(g, xd, eng.links(link_index), mode="pos", num_hops=num_hops, sign_k=K)
+        res = eng.precompute(g, xd, eng.links(link_index), mode="pos", num_hops=num_hops, sign_k=K,
+                             rw=_rw_of(rw_kwargs))
         return _as_data_list(res, K, y)
 
     @staticmethod
@@ -169,7 +177,7 @@ class OptimizedSignOperations:
         assert x is not None                                  # tuned_SIGN.py:221
         eng, g, xd = _device_inputs(A, x)
         res = eng.precompute(g, xd, eng.links(link_index), mode="pos_plus", num_hops=num_hops,
-                             sign_k=K, strategy=strat)
+                             sign_k=K, strategy=strat, rw=_rw_of(rw_kwargs))
         return _as_data_list(res, K, y)
 
 
