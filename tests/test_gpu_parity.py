@@ -687,3 +687,88 @@ def test_scaled_through_the_dropin_api(eng):
     lst = OptimizedSignOperations.get_PoS_prepped_ds(li, 3, A, 1.0, None, False, None, X, 1, kw, rw_kwargs)
     assert len(lst) == 6 and lst[0].x.shape == (2, 9) and lst[0]["x2"].shape == (2, 9)
     clear_cache()
+
+
+# ------------------------------------------------------------------------------------------
+# the other BASELINE.json configs at full size: sampled links against the fp64 oracle
+# ------------------------------------------------------------------------------------------
+def _sampled_check(eng, w, mode, n_sample, seed, **kw):
+    import torch
+
+    link_index, y = w.split.all_links()
+    G = eng.graph(w.A)
+    res = eng.precompute(G, eng.features(w.X), eng.links(link_index), mode=mode, sign_k=w.sign_k, **kw)
+    rng = np.random.default_rng(seed)
+    sample = np.sort(rng.choice(link_index.shape[1], n_sample, replace=False))
+    X64 = w.X.astype(np.float64)
+    skw = {"sign_k": w.sign_k, "k_node_set_strategy": "intersection"}
+    if mode == "sop":
+        lst = oracle.get_SoP_prepped_ds(oracle.global_normalized_powers(w.A, w.sign_k, np.float64),
+                                        link_index[:, sample], w.A, X64, 1, dtype=np.float64)
+    else:
+        fn = oracle.get_PoS_prepped_ds if mode == "pos" else oracle.get_PoS_Plus_prepped_ds
+        lst = fn(link_index[:, sample], w.num_hops, w.A, X64, 1, skw, dtype=np.float64)
+    row_ptr = res.row_ptr.cpu().numpy()
+    row_nodes = res.row_nodes.cpu().numpy()
+    worst = 0.0
+    for s, d in zip(sample, lst):
+        blk = res.rows[row_ptr[s]:row_ptr[s + 1]].cpu().numpy()
+        ref = np.stack([d[k] for k in ["x"] + [f"x{i}" for i in range(1, w.sign_k + 1)]], axis=1)
+        assert blk.shape == ref.shape
+        mine = row_nodes[row_ptr[s]:row_ptr[s + 1]]
+        assert list(mine[:2]) == list(d["rows_global"][:2]) and list(mine[2:]) == list(d["rows_global"][2:])
+        worst = max(worst, rel_err(blk, ref))
+    assert worst < TOL, worst
+    assert torch.isfinite(res.rows).all()
+    G.close()
+    return res
+
+
+def test_cora_pos_plus_full_size(eng):
+    """BASELINE config 2: Cora PoS Plus sign_k=3, 3-hop, F=1433, 19 532 links."""
+    from s3grl_amd import workloads
+
+    w = workloads.make("cora_posplus_k3")
+    res = _sampled_check(eng, w, "pos_plus", 60, 2, num_hops=3)
+    assert res.num_links == 19532 and res.rows.shape[0] == int(res.row_ptr[-1])
+
+
+def test_pubmed_sop_full_size(eng):
+    """BASELINE config 3: PubMed SoP sign_k=3 with one-hot degree features (F = 1525), 164 000 links."""
+    from s3grl_amd import workloads
+
+    w = workloads.make("pubmed_sop_k3")
+    res = _sampled_check(eng, w, "sop", 40, 3)
+    assert res.rows.shape == (328000, 4, 1526)
+
+
+def test_power_law_graph_hash_flavour_and_hubs(eng):
+    """A 70 000-node power-law graph: its bitmaps (26 KB) switch the engine to the hash flavour of
+    the visited set, its hubs (degree >> 256) arm the wave-per-row path; 1-hop subgraphs, sign_k=3."""
+    from s3grl_amd import workloads
+
+    n, e = workloads.chung_lu(70000, 300000, seed=9)
+    rng = np.random.default_rng(10)
+    X = rng.standard_normal((n, 24)).astype(np.float32)
+    pos = e[rng.choice(len(e), 3000, replace=False)]
+    neg = rng.integers(0, n, size=(3000, 2))
+    neg = neg[neg[:, 0] != neg[:, 1]]
+    deg = np.bincount(e.ravel(), minlength=n)
+    hubs = np.argsort(-deg)[:8]
+    extra = np.array([[hubs[0], hubs[1]], [hubs[2], int(pos[0, 0])], [hubs[3], hubs[4]]])
+    sp = workloads.Split(n, e, workloads.csr_from_undirected(n, e),
+                         {"train": (np.concatenate([pos, extra]).T.copy(), neg.T.copy()),
+                          "valid": (np.zeros((2, 0), np.int64),) * 2, "test": (np.zeros((2, 0), np.int64),) * 2})
+    w = workloads.Workload("powerlaw", sp, X, "pos_plus", 1, 3)
+    assert deg.max() > 256
+    # force the hub rows into the sample: the last 3 positives are hub-hub links
+    link_index, _ = sp.all_links()
+    res = _sampled_check(eng, w, "pos_plus", 50, 4, num_hops=1)
+    G = eng.graph(w.A)
+    hub_links = eng.links(np.concatenate([pos[:5], extra]).T.copy())
+    got = eng.precompute(G, eng.features(X), hub_links, mode="pos", num_hops=1, sign_k=3)
+    ref, _, _ = oracle.collate_rows(
+        oracle.get_PoS_prepped_ds(np.concatenate([pos[:5], extra]).T, 1, w.A, X.astype(np.float64), 1,
+                                  {"sign_k": 3}, dtype=np.float64), 3)
+    assert rel_err(got.rows.cpu().numpy(), ref) < TOL
+    G.close()
