@@ -6,3 +6,10 @@ interface (`s3grl_amd.tuned_SIGN`).  Importing the package does not touch the GP
 call into the engine loads libs3grl_hip.so and fails loudly if it is not built.
 """
 __version__ = "0.1.0"
+
+
+def precompute(*args, **kwargs):
+    """See `s3grl_amd.engine.precompute` (imported lazily: the engine imports torch)."""
+    from .engine import precompute as _p
+
+    return _p(*args, **kwargs)

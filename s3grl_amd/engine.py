@@ -361,3 +361,38 @@ def default_engine(device=None):
     if key not in _default:
         _default[key] = Engine(device)
     return _default[key]
+
+
+def precompute(indptr, indices, X, links, *, mode="pos", num_hops=1, sign_k=3,
+               strategy="intersection", rw=None, device=None):
+    """The native batched entry the `tuned_SIGN` wrappers delegate to, on the
+    current HIP device:
+
+        rows, row_ptr, node_count = precompute(indptr, indices, X, links, mode=..., ...)
+
+    `indptr`/`indices`: CSR structure of the (symmetric) train graph; `X`: fp32 [N, F];
+    `links`: int64 [2, L] as the reference passes them.  Returns `rows` fp32 [sum R, K+1, 1+F]
+    (the collated x, x1..xK of every link, label column first), `row_ptr` int64 [L+1] and
+    `node_count` int32 [L] (subgraph sizes; zeros for SoP, which extracts no subgraph)."""
+    eng = default_engine(device)
+    n = int(len(indptr) - 1)
+    g = eng.graph(indptr=indptr, indices=indices, num_nodes=n)
+    try:
+        lk = eng.links(links)
+        xd = eng.features(X)
+        if mode in ("pos", "pos_plus"):
+            plan = eng.plan(g, lk, mode=mode, num_hops=num_hops, sign_k=sign_k, strategy=strategy,
+                            full_stats=True, rw=rw)
+            try:
+                rows = plan.run(xd)
+                row_ptr = plan.row_ptr()
+                node_count = plan.export_subgraphs()[0].diff().to(torch.int32)
+            finally:
+                plan.close()
+        else:
+            res = eng.precompute(g, xd, lk, mode=mode, num_hops=num_hops, sign_k=sign_k, rw=rw)
+            rows, row_ptr = res.rows, res.row_ptr
+            node_count = torch.zeros(lk.shape[0], dtype=torch.int32, device=eng.device)
+    finally:
+        g.close()
+    return rows, row_ptr, node_count

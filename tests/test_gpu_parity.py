@@ -611,6 +611,18 @@ def test_headline_workload_full_size(eng):
                                   dtype=np.float64), 3)
     idx = torch.tensor(np.stack([2 * sample, 2 * sample + 1], 1).reshape(-1), device=rows.device)
     assert rel_err(rows[idx].cpu().numpy(), ref) < TOL
+    # EVERY link against the plain-C fp64 restatement (all host cores), streamed in chunks
+    from oracle import c_oracle
+
+    worst, chunk = 0.0, 8000
+    node_total = 0
+    for lo in range(0, L, chunk):
+        hi = min(lo + chunk, L)
+        cref, cptr, cnodes, ccount = c_oracle.pos_rows(link_index[:, lo:hi], 3, w.A, w.X, 3)
+        node_total += int(ccount.sum())
+        worst = max(worst, rel_err(rows[2 * lo:2 * hi].cpu().numpy(), cref))
+    assert worst < TOL, worst
+    assert node_total == res.stats["total_nodes"]          # subgraph sizes, summed over all links
     G.close()
 
 
@@ -772,3 +784,21 @@ def test_power_law_graph_hash_flavour_and_hubs(eng):
                                   {"sign_k": 3}, dtype=np.float64), 3)
     assert rel_err(got.rows.cpu().numpy(), ref) < TOL
     G.close()
+
+
+def test_module_level_precompute_entry(eng):
+    """precompute(indptr, indices, X, links, ...) -> (rows, row_ptr, node_count)."""
+    import s3grl_amd
+
+    fx = load_diffusion("usair")
+    A = csr_from_undirected(int(fx["num_nodes"]), fx["edges"])
+    X = fx["X"].astype(np.float32)
+    links = fx["links"]
+    rows, row_ptr, node_count = s3grl_amd.precompute(A.indptr, A.indices, X, links.T.copy(), mode="pos_plus",
+                                                     num_hops=1, sign_k=2)
+    lst = oracle.get_PoS_Plus_prepped_ds(links.T, 1, A, X.astype(np.float64), 1,
+                                         {"sign_k": 2, "k_node_set_strategy": "intersection"}, dtype=np.float64)
+    ref, ref_ptr, _ = oracle.collate_rows(lst, 2)
+    assert np.array_equal(row_ptr.cpu().numpy(), ref_ptr)
+    assert rel_err(rows.cpu().numpy(), ref) < TOL
+    assert list(node_count.cpu().numpy()) == [len(d["nodes"]) for d in lst]
