@@ -802,3 +802,62 @@ def test_module_level_precompute_entry(eng):
     assert np.array_equal(row_ptr.cpu().numpy(), ref_ptr)
     assert rel_err(rows.cpu().numpy(), ref) < TOL
     assert list(node_count.cpu().numpy()) == [len(d["nodes"]) for d in lst]
+
+
+# ------------------------------------------------------------------------------------------
+# every link of the remaining PoS configs against the plain-C fp64 restatement
+# ------------------------------------------------------------------------------------------
+def _all_links_vs_c(eng, w, mode, links_sel=None, chunk=8000):
+    from oracle import c_oracle
+
+    link_index, _ = w.split.all_links()
+    G = eng.graph(w.A)
+    res = eng.precompute(G, eng.features(w.X), eng.links(link_index), mode=mode, num_hops=w.num_hops,
+                         sign_k=w.sign_k)
+    row_ptr = res.row_ptr.cpu().numpy()
+    row_nodes = res.row_nodes.cpu().numpy()
+    L = link_index.shape[1]
+    sel = np.arange(L) if links_sel is None else np.sort(links_sel)
+    worst = 0.0
+    for lo in range(0, len(sel), chunk):
+        part = sel[lo:lo + chunk]
+        cref, cptr, cnodes, _ = c_oracle.pos_rows(link_index[:, part], w.num_hops, w.A, w.X, w.sign_k,
+                                                  plus=mode == "pos_plus")
+        assert np.array_equal(np.diff(cptr), np.diff(row_ptr)[part])         # rows per link: exact
+        take = np.concatenate([np.arange(row_ptr[l], row_ptr[l + 1]) for l in part]) if len(part) else part
+        assert np.array_equal(row_nodes[take], cnodes)                       # which rows: exact
+        import torch
+
+        got = res.rows[torch.from_numpy(take).to(res.rows.device)].cpu().numpy()
+        worst = max(worst, rel_err(got, cref))
+    G.close()
+    assert worst < TOL, worst
+    return res
+
+
+def test_cora_pos_plus_every_link(eng):
+    from s3grl_amd import workloads
+
+    _all_links_vs_c(eng, workloads.make("cora_posplus_k3"), "pos_plus", chunk=2000)
+
+
+def test_pubmed_pos_k5_every_link(eng):
+    """BASELINE config 4 (per-GPU share = the whole list when run on one GPU)."""
+    from s3grl_amd import workloads
+
+    res = _all_links_vs_c(eng, workloads.make("pubmed_pos_k5"), "pos")
+    assert res.rows.shape == (328000, 6, 501)
+
+
+def test_collab_scale_sampled_links(eng):
+    """BASELINE config 5: 235 000-node power-law graph, 1 M links, 1-hop, sign_k=3; 40 000 of the
+    links (plus the 200 with the largest endpoint degrees) against the C restatement."""
+    from s3grl_amd import workloads
+
+    w = workloads.make("collab_pos_k3")
+    link_index, _ = w.split.all_links()
+    deg = np.diff(w.A.indptr)
+    heavy = np.argsort(-(deg[link_index[0]] + deg[link_index[1]]))[:200]
+    sel = np.unique(np.concatenate([np.random.default_rng(5).choice(link_index.shape[1], 40000, replace=False),
+                                    heavy]))
+    _all_links_vs_c(eng, w, "pos", links_sel=sel, chunk=10000)
