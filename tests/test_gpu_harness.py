@@ -31,3 +31,40 @@ def test_usair_end_to_end_auc(mode, k_heuristic, strategy):
                                 k_pool_strategy=strategy, epochs=8, lr=2e-3, seed=1)
     assert auc > 0.85, auc
     eng.close()
+
+
+def test_split_bundle_cache_round_trip_on_device(tmp_path):
+    """a split's (rows, row_ptr, y) saved as a bundle and loaded back into HBM
+    is bit-identical; a bundle written for other operator settings is not reused."""
+    import torch
+    from s3grl_amd import cache, workloads
+    from s3grl_amd.engine import Engine
+
+    w = workloads.make("usair_pos_k2")
+    eng = Engine("cuda:0")
+    G = eng.graph(w.A)
+    f = eng.features(w.X)
+    pos, neg = w.split.links["valid"]
+    li = np.concatenate([pos, neg], axis=1)
+    y = np.concatenate([np.ones(pos.shape[1], np.int64), np.zeros(neg.shape[1], np.int64)])
+    calls = []
+
+    def compute(sign_k):
+        def fn():
+            calls.append(sign_k)
+            res = eng.precompute(G, f, eng.links(li), mode="pos_plus", num_hops=1, sign_k=sign_k)
+            return res.rows, res.row_ptr, y
+        return fn
+
+    app = cache.data_appendix(num_hops=1, node_label="zo", ratio_per_hop=1.0, seed=1)
+    d2 = cache.cache_dir(tmp_path / "USAir", app, mode="pos_plus", sign_k=2)
+    d3 = cache.cache_dir(tmp_path / "USAir", app, mode="pos_plus", sign_k=3)
+    assert d2 != d3
+    name = cache.bundle_name("valid")
+    a = cache.get_or_compute(d2 / name, compute(2), expect={"sign_k": 2, "mode": "pos_plus"}, device=eng.device)
+    b = cache.get_or_compute(d2 / name, compute(2), expect={"sign_k": 2, "mode": "pos_plus"}, device=eng.device)
+    assert calls == [2] and b[0].is_cuda
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    c = cache.get_or_compute(d3 / name, compute(3), expect={"sign_k": 3, "mode": "pos_plus"}, device=eng.device)
+    assert calls == [2, 3] and c[0].shape[1] == 4
+    eng.close()
