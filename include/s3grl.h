@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define S3GRL_ABI_VERSION 1
+#define S3GRL_ABI_VERSION 2
 
 typedef enum s3grl_status {
   S3GRL_OK = 0,
@@ -61,6 +61,12 @@ typedef enum s3grl_strategy {
   S3GRL_STRATEGY_UNION = 1         /* accepted by the reference's parser, broken in its code */
 } s3grl_strategy;
 
+/* s3grl_cfg.flags */
+#define S3GRL_FLAG_FULL_STATS 1u /* per-link diagnostics: exact total_sub_edges even when
+                                    sign_k < num_hops, subgraph export for every link (turns
+                                    the folding of reversed duplicates off) */
+#define S3GRL_FLAG_NO_FOLD 2u    /* do not serve (d,s) from the extraction of (s,d) */
+
 /* sign_kwargs / call arguments of the reference operators (tuned_SIGN.py:137-138,145,200,229) */
 typedef struct s3grl_cfg {
   int32_t mode;      /* s3grl_mode */
@@ -68,13 +74,18 @@ typedef struct s3grl_cfg {
   int32_t sign_k;    /* number of operators K >= 1 */
   int32_t strategy;  /* s3grl_strategy, PoS Plus only */
   int32_t directed;  /* must be 0 (A_csc == None in every non-ogbl-citation2 run) */
-  int32_t reserved[3]; /* [0] bit 0: per-link diagnostics — exact total_sub_edges even when
-                          sign_k < num_hops, subgraph export for every link (turns folding of
-                          reversed duplicates off); bit 1: no folding.
-                          [1] ScaLed subgraphs (reference utils.py:86-150, rw_kwargs): rw_m |
-                          rw_M << 16 — M random walks of length m per node replace the BFS,
-                          num_hops is ignored like in the reference; 0 = k-hop BFS.
-                          [2] seed of those walks */
+  uint32_t flags;    /* S3GRL_FLAG_* */
+  int32_t rw_m;      /* ScaLed subgraphs (reference utils.py:86-150, rw_kwargs): rw_M random walks */
+  int32_t rw_M;      /*   of length rw_m per node replace the BFS (num_hops is then ignored, like
+                          in the reference); 0 = k-hop BFS */
+  uint32_t seed;     /* seed of the engine's own counter-based generator (walks, hop sampling) */
+  int32_t max_nodes_per_hop; /* utils.py:68-70: keep at most this many nodes of every hop;
+                                0 = no cap (None) */
+  double ratio_per_hop;      /* utils.py:66-67: keep int(ratio * |fringe|) nodes of every hop
+                                (before the cap), uniformly; >= 1.0 = keep all (every paper
+                                config).  A double, like the Python float whose product is
+                                truncated.  Offset 40. */
+  int32_t reserved[4];       /* must be 0 */
 } s3grl_cfg;
 
 /* sizes a plan measured while extracting; the benchmark's algorithmic-bytes figure

@@ -25,4 +25,6 @@ from .s3grl_oracle import (  # noqa: F401
     hybrid_combine,
     centre_pool,
     collate_rows,
+    hash_sampler,
+    hop_sample_key,
 )

@@ -53,10 +53,41 @@ def neighbors(fringe, A):
     return set(int(v) for v in A[fringe].indices)
 
 
+_M64 = (1 << 64) - 1
+
+
+def hop_sample_key(seed, a, b, u):
+    """The engine's per-node sampling key (s3grl_device.hpp `hop_sample_key`), in Python ints:
+    a 64-bit mix of (seed, unordered endpoints a <= b, node) with the node id in the low half,
+    so keys of distinct nodes are distinct."""
+    x = (seed & 0xffffffff) << 32
+    x ^= ((a & 0xffffffff) * 0x9E3779B97F4A7C15) & _M64
+    x ^= ((b & 0xffffffff) * 0xC2B2AE3D27D4EB4F) & _M64
+    x = (x + (u & 0xffffffff) * 0x165667B19E3779F9) & _M64
+    x ^= x >> 33
+    x = (x * 0xff51afd7ed558ccd) & _M64
+    x ^= x >> 33
+    x = (x * 0xc4ceb9fe1a85ec53) & _M64
+    x ^= x >> 33
+    return (x & 0xffffffff00000000) | (u & 0xffffffff)
+
+
+def hash_sampler(seed, src, dst):
+    """`sampler` for k_hop_subgraph that makes the engine's draw: the k smallest keys of the hop.
+    (The reference draws with `random.sample`; any uniform k-subset is the same distribution.)"""
+    a, b = min(int(src), int(dst)), max(int(src), int(dst))
+
+    def pick(fringe, k, dist=None):
+        return sorted(fringe, key=lambda u: hop_sample_key(seed, a, b, int(u)))[:k]
+    return pick
+
+
 def k_hop_subgraph(src, dst, num_hops, A, node_features=None, y=1, order="canonical",
-                   rw_nodes=None):
-    """k-hop enclosing subgraph of link (src, dst) — reference utils.py:47-85, non-rw branch
-    with sample_ratio=1.0 / max_nodes_per_hop=None (every paper config), undirected.
+                   rw_nodes=None, sample_ratio=1.0, max_nodes_per_hop=None, sampler=None):
+    """k-hop enclosing subgraph of link (src, dst) — reference utils.py:47-85, non-rw branch,
+    undirected.  Every paper config runs it with sample_ratio=1.0 / max_nodes_per_hop=None; the
+    per-hop sampling of utils.py:66-70 is restated too, with the draw behind `sampler(fringe, k,
+    dist)` (default: `random.sample`, what the reference calls).
 
     BFS runs on the *unmasked* graph from both endpoints at once; the target link is removed
     afterwards from the induced matrix by assignment, which on scipy CSR inserts an explicit
@@ -85,9 +116,19 @@ def k_hop_subgraph(src, dst, num_hops, A, node_features=None, y=1, order="canoni
     dists = [0, 0]
     visited = {src, dst}
     fringe = {src, dst}
+    if sampler is None:
+        import random
+
+        def sampler(fr, k, dist):
+            return random.sample(sorted(fr), k)
     for dist in range(1, num_hops + 1):
         fringe = neighbors(fringe, A) - visited
-        visited |= fringe
+        visited |= fringe                                  # dropped nodes stay visited (utils.py:65)
+        if sample_ratio < 1.0:                             # utils.py:66-67
+            fringe = set(sampler(fringe, int(sample_ratio * len(fringe)), dist))
+        if max_nodes_per_hop is not None:                  # utils.py:68-70
+            if max_nodes_per_hop < len(fringe):
+                fringe = set(sampler(fringe, max_nodes_per_hop, dist))
         if not fringe:
             break
         hop = sorted(fringe) if order == "canonical" else list(fringe)
@@ -133,12 +174,15 @@ def _powers(op, K):
 
 
 def pos_link(src, dst, num_hops, A, x, K, *, plus=False, strategy="intersection",
-             dtype=np.float32, order="canonical", rw_nodes=None):
+             dtype=np.float32, order="canonical", rw_nodes=None, sample_ratio=1.0,
+             max_nodes_per_hop=None, sampler=None):
     """One iteration of the reference's PoS / PoS Plus hot loop — tuned_SIGN.py:147-187 and
     :202-260.  Returns a dict with x, x1..xK ([R, 1+F]), the selected local rows, the global
     ids of those rows, the node list and hop distances."""
     nodes, sub, dists, X_S, _ = k_hop_subgraph(src, dst, num_hops, A, node_features=x,
-                                                order=order, rw_nodes=rw_nodes)
+                                                order=order, rw_nodes=rw_nodes,
+                                                sample_ratio=sample_ratio,
+                                                max_nodes_per_hop=max_nodes_per_hop, sampler=sampler)
     n = sub.shape[0]
     op = normalized_subgraph_operator(sub, dtype)
     powers = _powers(op, K)
@@ -177,8 +221,17 @@ def _links(link_index):
     return li.T.tolist()
 
 
+def _sampling_of(src, dst, ratio_per_hop, max_nodes_per_hop, sample_seed):
+    """kwargs for pos_link: the reference's (ratio_per_hop, max_nodes_per_hop) with the draw made
+    by the engine's keyed generator when `sample_seed` is given, by `random.sample` otherwise."""
+    return {"sample_ratio": 1.0 if ratio_per_hop is None else ratio_per_hop,
+            "max_nodes_per_hop": max_nodes_per_hop,
+            "sampler": None if sample_seed is None else hash_sampler(sample_seed, src, dst)}
+
+
 def get_PoS_prepped_ds(link_index, num_hops, A, x, y, sign_kwargs, *, dtype=np.float32,
-                       order="canonical", rw_node_sets=None):
+                       order="canonical", rw_node_sets=None, ratio_per_hop=1.0,
+                       max_nodes_per_hop=None, sample_seed=None):
     """Reference tuned_SIGN.py:137-189 (optimised PoS flow), one dict per link.
     `rw_node_sets[l]` = the random-walk node set of link l (ScaLed branch), else k-hop BFS."""
     assert x is not None
@@ -186,14 +239,16 @@ def get_PoS_prepped_ds(link_index, num_hops, A, x, y, sign_kwargs, *, dtype=np.f
     out = []
     for l, (src, dst) in enumerate(_links(link_index)):
         d = pos_link(src, dst, num_hops, A, x, K, plus=False, dtype=dtype, order=order,
-                     rw_nodes=None if rw_node_sets is None else rw_node_sets[l])
+                     rw_nodes=None if rw_node_sets is None else rw_node_sets[l],
+                     **_sampling_of(src, dst, ratio_per_hop, max_nodes_per_hop, sample_seed))
         d["y"] = y
         out.append(d)
     return out
 
 
 def get_PoS_Plus_prepped_ds(link_index, num_hops, A, x, y, sign_kwargs, *, dtype=np.float32,
-                            order="canonical", rw_node_sets=None):
+                            order="canonical", rw_node_sets=None, ratio_per_hop=1.0,
+                            max_nodes_per_hop=None, sample_seed=None):
     """Reference tuned_SIGN.py:192-262 (optimised PoS Plus flow), one dict per link."""
     assert x is not None
     K = sign_kwargs["sign_k"]
@@ -201,7 +256,8 @@ def get_PoS_Plus_prepped_ds(link_index, num_hops, A, x, y, sign_kwargs, *, dtype
     out = []
     for l, (src, dst) in enumerate(_links(link_index)):
         d = pos_link(src, dst, num_hops, A, x, K, plus=True, strategy=strat, dtype=dtype,
-                     order=order, rw_nodes=None if rw_node_sets is None else rw_node_sets[l])
+                     order=order, rw_nodes=None if rw_node_sets is None else rw_node_sets[l],
+                     **_sampling_of(src, dst, ratio_per_hop, max_nodes_per_hop, sample_seed))
         d["y"] = y
         out.append(d)
     return out

@@ -41,7 +41,14 @@ SYMBOLS = [
 
 class Cfg(C.Structure):
     _fields_ = [("mode", C.c_int32), ("num_hops", C.c_int32), ("sign_k", C.c_int32),
-                ("strategy", C.c_int32), ("directed", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("strategy", C.c_int32), ("directed", C.c_int32), ("flags", C.c_uint32),
+                ("rw_m", C.c_int32), ("rw_M", C.c_int32), ("seed", C.c_uint32),
+                ("max_nodes_per_hop", C.c_int32), ("ratio_per_hop", C.c_double),
+                ("reserved", C.c_int32 * 4)]
+
+
+ABI_VERSION = 2
+FLAG_FULL_STATS, FLAG_NO_FOLD = 1, 2
 
 
 class PlanStats(C.Structure):
@@ -113,7 +120,7 @@ def lib():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = i32
-    if L.s3grl_abi_version() != 1:
+    if L.s3grl_abi_version() != ABI_VERSION:
         raise ImportError("libs3grl_hip.so ABI version mismatch")
     _lib = L
     return L

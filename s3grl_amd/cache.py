@@ -132,8 +132,12 @@ def load(path, device=None):
 
         dev = torch.device(device)
         # mmap pages are read-only: copy on the host only when the result stays on the host
-        out = {k: (torch.from_numpy(np.array(v)) if dev.type == "cpu"
-                   else torch.as_tensor(np.asarray(v)).to(dev)) for k, v in out.items()}
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", UserWarning)   # "array is not writable": it is only read
+            out = {k: (torch.from_numpy(np.array(v)) if dev.type == "cpu"
+                       else torch.from_numpy(np.asarray(v)).to(dev)) for k, v in out.items()}
     return out["rows"], out["row_ptr"], out["y"], header["meta"]
 
 

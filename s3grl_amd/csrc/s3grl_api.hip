@@ -270,6 +270,20 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
     return S3GRL_ERR_GRAPH_TOO_LARGE;
   }
   if (L >= (int64_t)INT32_MAX / 16) return S3GRL_ERR_INVALID_ARGUMENT;
+  if (cfg->rw_m < 0 || cfg->rw_M < 0 || cfg->rw_m > 65535 || cfg->rw_M > 65535 ||
+      (cfg->rw_m > 0) != (cfg->rw_M > 0)) {
+    set_last_error("rw_m and rw_M must both be 0 or both be in 1..65535");
+    return S3GRL_ERR_INVALID_ARGUMENT;
+  }
+  if (cfg->max_nodes_per_hop < 0 || !(cfg->ratio_per_hop >= 0.0)) {
+    set_last_error("max_nodes_per_hop must be >= 0 and ratio_per_hop >= 0 (0 or >= 1: keep all)");
+    return S3GRL_ERR_INVALID_ARGUMENT;
+  }
+  for (int r : cfg->reserved)
+    if (r != 0) {
+      set_last_error("s3grl_cfg.reserved must be zero");
+      return S3GRL_ERR_INVALID_ARGUMENT;
+    }
   S3GRL_HIP_TRY(hipSetDevice(ctx->device));
   const int K = cfg->sign_k;
 
@@ -315,17 +329,21 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   int64_t* hs = ctx->h_scalars;
   class_count = reinterpret_cast<int32_t*>(ds + 8);
   S3GRL_HIP_TRY(hipMemsetAsync(ds, 0, 32 * sizeof(int64_t), ctx->stream));
-  // ScaLed: per-node random walks replace the BFS (cfg.reserved[1] = m | M << 16, [2] = seed)
-  const int rw_m = cfg->reserved[1] & 0xffff, rw_M = (cfg->reserved[1] >> 16) & 0xffff;
+  // ScaLed: per-node random walks replace the BFS
+  const int rw_m = cfg->rw_m, rw_M = cfg->rw_M;
   int32_t* rw_raw = nullptr;
   const int rw_len = rw_m * rw_M;
   if (rw_len > 0) {
     S3GRL_TRY(arena_alloc(ctx, (size_t)g->num_nodes * rw_len, &rw_raw, tr));
-    S3GRL_TRY(launch_random_walks(ctx, g, rw_m, rw_M, (uint32_t)cfg->reserved[2], rw_raw));
+    S3GRL_TRY(launch_random_walks(ctx, g, rw_m, rw_M, cfg->seed, rw_raw));
   }
   // reversed duplicates (both directions of a train edge) are folded into one extraction
   int32_t *partner = nullptr, *mirror_of = nullptr;
-  const bool fold = !(cfg->reserved[0] & 3) && !getenv("S3GRL_NO_MIRROR");
+  const bool fold = !(cfg->flags & (S3GRL_FLAG_FULL_STATS | S3GRL_FLAG_NO_FOLD)) && !getenv("S3GRL_NO_MIRROR");
+  // per-hop sampling (utils.py:66-70; the reference's rw branch ignores it).  Its BFS keeps a
+  // fourth bitmap, so the plan stays on the bitmap flavour of the visited set.
+  HopSampling smp{rw_len > 0 ? 1.0 : cfg->ratio_per_hop, rw_len > 0 ? 0 : cfg->max_nodes_per_hop, cfg->seed};
+  const bool sampling = hop_sampling_on(smp);
   if (fold) {
     uint64_t* keys;
     int32_t* vals;
@@ -340,7 +358,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   S3GRL_TRY(launch_count(ctx, g, plan->links, L, cfg->num_hops, plus ? 1 : 0, K, rw_raw, rw_len,
                          partner, mirror_of,
                          plan->n_nodes, p_nodes, n_rows, n_jobs, lvl_max,
-                         reinterpret_cast<int32_t*>(ds), ds + 6));
+                         reinterpret_cast<int32_t*>(ds), ds + 6, smp));
   if (fold) S3GRL_TRY(launch_mirror_rows(ctx, partner, L, n_rows));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, plan->n_nodes, L, plan->node_off, scan_ws));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_rows, L, plan->row_ptr, scan_ws));
@@ -350,7 +368,8 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   S3GRL_HIP_TRY(hipGetLastError());
   // PoS has no common-neighbour rows: the LDS classes are known without a round trip
   if (!plus)
-    S3GRL_TRY(launch_classify(ctx, g, 1, K, plan->n_nodes, p_nodes, lvl_max, L, class_count, class_list));
+    S3GRL_TRY(launch_classify(ctx, g, 1, K, plan->n_nodes, p_nodes, lvl_max, L, class_count, class_list,
+                              !sampling));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs, ds, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs + 16, plan->node_off + L, 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs + 17, plan->row_ptr + L, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -370,7 +389,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   const int cn_cap = (int)std::max<int64_t>(max_R - 2, 0) + 1;
   if (plus) {
     S3GRL_TRY(launch_classify(ctx, g, cn_cap, K, plan->n_nodes, p_nodes, lvl_max, L, class_count,
-                              class_list));
+                              class_list, !sampling));
     S3GRL_HIP_TRY(hipMemcpyAsync(hs + 8, ds + 8, 8 * 8, hipMemcpyDeviceToHost, ctx->stream));
     S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
@@ -416,11 +435,11 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   S3GRL_TRY(arena_alloc(ctx, (size_t)L * kMaxLevels, &plan->lvl, own));
   S3GRL_TRY(record(ctx, 1));
   S3GRL_TRY(launch_links(ctx, g, plan->links, L, class_list, class_count_host, cfg->num_hops,
-                         plus ? 1 : 0, cn_cap, cfg->reserved[0] & 1, K, rw_raw, rw_len, p_nodes,
+                         plus ? 1 : 0, cn_cap, (cfg->flags & S3GRL_FLAG_FULL_STATS) ? 1 : 0, K, rw_raw, rw_len, p_nodes,
                          plan->node_off,
                          plan->row_ptr, plan->job_off, coef_off, mirror_of, plan->c_ids,
                          plan->c_coef, plan->jobs, plan->job_z, plan->row_nodes, plan->lvl, ds + 2,
-                         ds + 3, ds + 4));
+                         ds + 3, ds + 4, smp));
   S3GRL_TRY(record(ctx, 2));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs + 2, ds + 2, 3 * 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));

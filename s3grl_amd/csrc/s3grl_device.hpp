@@ -207,6 +207,81 @@ __device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
   __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------
+// Per-hop sampling (reference utils.py:66-70): of the m nodes a hop discovers, keep
+// k = min(int(ratio * m), max_nodes_per_hop) drawn uniformly without replacement; the others stay
+// "visited" (they are never rediscovered) but are not part of the subgraph.  The reference draws
+// with Python's random.sample; here every node gets a key from a counter-based generator keyed by
+// (seed, the link's endpoints as an unordered pair, node) and the k smallest keys are kept: a
+// uniform k-subset as well, the same one in every kernel that re-derives the subgraph and for
+// both directions of a link.  (A node is discovered in at most one hop of a link, so the hop
+// needs no place in the key; ratio and cap applied one after the other keep the min(k1, k2)
+// smallest keys, which is what one draw of that size keeps.)
+__device__ __forceinline__ bool sampling_on(const HopSampling& s) {
+  return (s.ratio > 0.0 && s.ratio < 1.0) || s.max_nodes > 0;
+}
+
+__device__ __forceinline__ int hop_keep(const HopSampling& s, int added) {
+  int k = added;
+  if (s.ratio > 0.0 && s.ratio < 1.0) k = (int)(s.ratio * (double)added);   // Python: int(ratio * len)
+  if (s.max_nodes > 0 && s.max_nodes < k) k = s.max_nodes;
+  return k;
+}
+
+// distinct for distinct nodes: the node id sits in the low half
+__device__ __forceinline__ uint64_t hop_sample_key(uint32_t seed, int a, int b, int u) {
+  uint64_t x = (uint64_t)seed << 32;
+  x ^= (uint64_t)(uint32_t)a * 0x9E3779B97F4A7C15ull;
+  x ^= (uint64_t)(uint32_t)b * 0xC2B2AE3D27D4EB4Full;
+  x += (uint64_t)(uint32_t)u * 0x165667B19E3779F9ull;
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdull;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ull;
+  x ^= x >> 33;
+  return (x & 0xffffffff00000000ull) | (uint32_t)u;
+}
+
+// Clears all but the `keep` smallest-keyed bits of the level bitmap `nxt` (0 < keep < popcount).
+// A bisection over the 64-bit key space finds a threshold with exactly `keep` keys at or below
+// it (keys are distinct, so one exists); ~log2(level size) + a few rounds of one block reduction.
+template <int T>
+__device__ __forceinline__ void sample_level(uint32_t* nxt, int W, int keep, uint32_t seed, int a,
+                                             int b, int* sh) {
+  const int tid = threadIdx.x;
+  const int C = (W + T - 1) / T;
+  const int w0 = min(tid * C, W), w1 = min(w0 + C, W);
+  uint64_t lo = 0, hi = ~0ull, tau = 0;
+  for (int it = 0; it < 70; ++it) {           // <= 64 halvings; the bound is a safety net
+    const uint64_t mid = lo + ((hi - lo) >> 1);
+    int c = 0;
+    for (int t = w0; t < w1; ++t) {
+      uint32_t w = nxt[t];
+      while (w) {
+        const int bit = __ffs(w) - 1;
+        w &= w - 1;
+        c += hop_sample_key(seed, a, b, t * 32 + bit) <= mid ? 1 : 0;
+      }
+    }
+    c = block_sum<T>(c, sh);
+    if (c == keep) {
+      tau = mid;
+      break;
+    }
+    if (c < keep) lo = mid + 1; else hi = mid - 1;
+  }
+  for (int t = w0; t < w1; ++t) {
+    uint32_t w = nxt[t], kept = 0;
+    while (w) {
+      const int bit = __ffs(w) - 1;
+      w &= w - 1;
+      if (hop_sample_key(seed, a, b, t * 32 + bit) <= tau) kept |= 1u << bit;
+    }
+    nxt[t] = kept;
+  }
+  __syncthreads();
+}
+
 // Word-level popcount prefix of a bitmap (local id = rank): thread-contiguous runs, one block scan.
 template <int T>
 __device__ __forceinline__ void rank_prefix(const uint32_t* bm, uint32_t* wpre, int W, int* sh) {
@@ -235,7 +310,7 @@ __device__ __forceinline__ int bfs_list(const int32_t* __restrict__ indptr,
                                         int dst, int hops, uint32_t* vis, uint32_t* nxt,
                                         int32_t* list, int cap, int* lvl_end, int* sh, int* hub,
                                         int& nlev_out, const int32_t* __restrict__ rw_raw = nullptr,
-                                        int rw_len = 0) {
+                                        int rw_len = 0, HopSampling smp = HopSampling{1.0, 0, 0}) {
   const int tid = threadIdx.x;
   for (int t = tid; t < W; t += T) {
     vis[t] = 0;
@@ -283,6 +358,20 @@ __device__ __forceinline__ int bfs_list(const int32_t* __restrict__ indptr,
     for (int t = w0; t < w1; ++t) mine += __popc(nxt[t]);
     int added;
     int pos = n + block_excl_scan<T>(mine, sh, added);
+    if (!rw_raw && added > 0 && sampling_on(smp)) {   // utils.py:66-70 (uniform: block-wide values)
+      const int keep = hop_keep(smp, added);
+      if (keep < added) {
+        if (keep > 0) {
+          sample_level<T>(nxt, W, keep, smp.seed, min(src, dst), max(src, dst), sh);
+          mine = 0;
+          for (int t = w0; t < w1; ++t) mine += __popc(nxt[t]);
+          pos = n + block_excl_scan<T>(mine, sh, added);
+        } else {
+          added = 0;                                   // utils.py:71-72: an empty sample ends the walk
+          for (int t = w0; t < w1; ++t) nxt[t] = 0;
+        }
+      }
+    }
     for (int t = w0; t < w1; ++t) {
       uint32_t w = nxt[t];
       nxt[t] = 0;
@@ -300,6 +389,13 @@ __device__ __forceinline__ int bfs_list(const int32_t* __restrict__ indptr,
     __syncthreads();
   }
   __syncthreads();
+  if (!rw_raw && sampling_on(smp)) {
+    // vis also holds the discovered-but-dropped nodes: rebuild it as the membership bitmap of S
+    for (int t = tid; t < W; t += T) vis[t] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += T) atomicOr(&vis[list[i] >> 5], 1u << (list[i] & 31));
+    __syncthreads();
+  }
   nlev_out = nlev;
   return n;
 }

@@ -40,6 +40,17 @@ constexpr int kNumClasses = 6;
 // variable LDS bytes per link (list + state on the propagation prefix), upper bound per class
 #define S3GRL_CLASS_BOUNDS {6144, 12288, 24576, 49152, 98304, 163840}
 
+// per-hop sampling settings of a plan (reference utils.py:66-70); ratio outside (0,1) and
+// max_nodes == 0 mean "keep every node"
+struct HopSampling {
+  double ratio;
+  int32_t max_nodes;
+  uint32_t seed;
+};
+static inline bool hop_sampling_on(const HopSampling& s) {
+  return (s.ratio > 0.0 && s.ratio < 1.0) || s.max_nodes > 0;
+}
+
 // One gather job = one pair of output rows of one link (rows 2p, 2p+1 of that link).
 struct Job {
   int64_t coef_off;   // first float2 of this job's coefficients, laid out [K][support]
@@ -157,7 +168,7 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           int hops, int plus, int K, const int32_t* rw_raw, int rw_len,
                           const int32_t* partner, const int32_t* mirror_of, int32_t* n_nodes, int32_t* p_nodes,
                           int32_t* n_rows, int32_t* n_jobs, int32_t* lvl_max, int32_t* err_flag,
-                          int64_t* tot_nodes_alg);
+                          int64_t* tot_nodes_alg, HopSampling smp = HopSampling{1.0, 0, 0});
 int num_class_lists();
 s3grl_status launch_random_walks(s3grl_context* ctx, const s3grl_graph* g, int m, int M,
                                  uint32_t seed, int32_t* raw);
@@ -175,7 +186,7 @@ s3grl_status launch_scan_i32_to_i64(s3grl_context* ctx, const int32_t* in, int64
 s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_cap, int K,
                              const int32_t* n_nodes, const int32_t* p_nodes,
                              const int32_t* lvl_max, int64_t L, int32_t* class_count,
-                             int32_t* class_list);
+                             int32_t* class_list, bool allow_hash = true);
 s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                           const int32_t* class_list, const int32_t* class_count_host, int hops,
                           int plus, int cn_cap, int full_stats, int K, const int32_t* rw_raw,
@@ -183,7 +194,8 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           const int64_t* node_off, const int64_t* row_ptr, const int64_t* job_off,
                           const int64_t* coef_off, const int32_t* mirror_of, int32_t* c_ids,
                           float* c_coef, Job* jobs, float* job_z, int64_t* row_nodes, int32_t* lvl,
-                          int64_t* tot_edges, int64_t* tot_support, int64_t* tot_vol);
+                          int64_t* tot_edges, int64_t* tot_support, int64_t* tot_vol,
+                          HopSampling smp = HopSampling{1.0, 0, 0});
 s3grl_status launch_dists(s3grl_context* ctx, const int64_t* node_off, const int32_t* lvl, int64_t L,
                           int8_t* dists);
 // gather.hip

@@ -73,12 +73,16 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
     const int32_t* __restrict__ rw_raw, int rw_len, const int32_t* __restrict__ partner, const int32_t* __restrict__ mirror_of,
     int32_t* __restrict__ n_nodes, int32_t* __restrict__ p_nodes, int32_t* __restrict__ n_rows,
     int32_t* __restrict__ n_jobs, int32_t* __restrict__ lvl_max, int32_t* __restrict__ err_flag,
-    unsigned long long* __restrict__ tot_nodes_alg) {
+    unsigned long long* __restrict__ tot_nodes_alg, HopSampling smp) {
   extern __shared__ uint32_t smem[];
   uint32_t* vis = smem;
   uint32_t* cur = smem + W;
   uint32_t* nxt = smem + 2 * W;
   int* sh = reinterpret_cast<int*>(smem + 3 * W);
+  // per-hop sampling: `vis` also holds discovered-but-dropped nodes, so the members of S get a
+  // bitmap of their own (the launcher adds W words behind the list when sampling is on)
+  const bool sampling = !rw_raw && sampling_on(smp);
+  uint32_t* mem = sampling ? smem + 3 * W + 8 + kHubWords + kCountList : nullptr;
   const int tid = threadIdx.x;
   const int l = blockIdx.x;
   const int64_t s64 = links[2 * (int64_t)l], d64 = links[2 * (int64_t)l + 1];
@@ -110,11 +114,16 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
     vis[t] = 0;
     cur[t] = 0;
     nxt[t] = 0;
+    if (mem) mem[t] = 0;
   }
   __syncthreads();
   if (tid == 0) {
     atomicOr(&vis[src >> 5], 1u << (src & 31));
     atomicOr(&vis[dst >> 5], 1u << (dst & 31));
+    if (mem) {
+      atomicOr(&mem[src >> 5], 1u << (src & 31));
+      atomicOr(&mem[dst >> 5], 1u << (dst & 31));
+    }
     list[0] = src;
     list[1] = dst;
     if (hub) hub[0] = 0;
@@ -171,6 +180,17 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
     int added;
     int pos = f1 + block_excl_scan<kBlock>(mine, sh, added);
     if (added == 0) break;
+    if (sampling) {  // utils.py:66-70, the same draw link_kernel's BFS makes
+      const int keep = hop_keep(smp, added);
+      if (keep == 0) break;                     // utils.py:71-72
+      if (keep < added) {
+        sample_level<kBlock>(nxt, W, keep, smp.seed, min(src, dst), max(src, dst), sh);
+        mine = 0;
+        for (int t = w0; t < w1; ++t) mine += __popc(nxt[t]);
+        pos = f1 + block_excl_scan<kBlock>(mine, sh, added);
+      }
+      for (int t = w0; t < w1; ++t) mem[t] |= nxt[t];
+    }
     if (d < hops) {  // the new level is the next frontier
       if (use_list && f1 + added <= kCountList) {
         for (int t = w0; t < w1; ++t) {
@@ -199,8 +219,10 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
     if (d <= K) cum_b = n;
   }
   int R = 2;
+  if (sampling) __syncthreads();   // mem is complete
+  const uint32_t* member = sampling ? mem : vis;
   if (plus && wave_id() == 0)
-    R = 2 + common_neighbours(indptr, indices, [&](int x) { return test_bit(vis, x); }, src, dst, nullptr);
+    R = 2 + common_neighbours(indptr, indices, [&](int x) { return test_bit(member, x); }, src, dst, nullptr);
   if (tid == 0) {
     n_nodes[l] = n;
     p_nodes[l] = R > 2 ? cum_b : cum_a;
@@ -465,7 +487,8 @@ __global__ __launch_bounds__(T) void link_kernel(
     Job* __restrict__ jobs, float* __restrict__ job_z, int64_t* __restrict__ row_nodes,
     int32_t* __restrict__ lvl_out, unsigned long long* __restrict__ tot_edges,
     unsigned long long* __restrict__ tot_support, unsigned long long* __restrict__ tot_vol,
-    char* __restrict__ scratch, int64_t scratch_stride, unsigned long long* __restrict__ dbg) {
+    char* __restrict__ scratch, int64_t scratch_stride, unsigned long long* __restrict__ dbg,
+    HopSampling smp) {
   extern __shared__ uint32_t smem[];
   // diagnostic only (S3GRL_DEBUG_STAMPS): cycles per phase, summed over workgroups; the extra
   // barriers change the timing of the build they run in — read shares, not totals
@@ -530,7 +553,7 @@ __global__ __launch_bounds__(T) void link_kernel(
                        hub, nlev, rw_raw, rw_len);
   else
     n = bfs_list<T, G>(indptr, indices, W, src, dst, hops, vis, inP, list, n_alloc, lvl_end, sh, hub, nlev,
-                       rw_raw, rw_len);
+                       rw_raw, rw_len, smp);
   // set queries of the passes below: membership in S; index into the P-state arrays (+ is it in P);
   // the P-state index of list entry t (= node v)
   auto in_s = [&](int u) -> bool {
@@ -816,10 +839,14 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           int hops, int plus, int K, const int32_t* rw_raw, int rw_len,
                           const int32_t* partner, const int32_t* mirror_of, int32_t* n_nodes, int32_t* p_nodes,
                           int32_t* n_rows, int32_t* n_jobs, int32_t* lvl_max, int32_t* err_flag,
-                          int64_t* tot_nodes_alg) {
+                          int64_t* tot_nodes_alg, HopSampling smp) {
   if (L == 0) return S3GRL_OK;
   const int W = words_for(g->num_nodes);
-  const size_t lds = (size_t)(3 * W + 8 + kHubWords + kCountList) * 4;
+  const size_t lds = (size_t)(3 * W + 8 + kHubWords + kCountList + (hop_sampling_on(smp) ? W : 0)) * 4;
+  if (lds > 163840) {
+    set_last_error("num_nodes " + std::to_string(g->num_nodes) + ": the LDS bitmaps exceed 160 KiB");
+    return S3GRL_ERR_GRAPH_TOO_LARGE;
+  }
   const bool sparse = (double)g->nnz / (double)std::max<int64_t>(g->num_nodes, 1) <= 6.0;
   auto kern = sparse ? count_kernel<4> : count_kernel<8>;
   S3GRL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -828,7 +855,7 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
                      g->indices, (int)g->num_nodes, W, links, hops, plus, K,
                      g->max_degree > kHubArmDegree ? 1 : 0, rw_raw, rw_len, partner, mirror_of, n_nodes,
                      p_nodes, n_rows, n_jobs, lvl_max, err_flag,
-                     reinterpret_cast<unsigned long long*>(tot_nodes_alg));
+                     reinterpret_cast<unsigned long long*>(tot_nodes_alg), smp);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -890,7 +917,7 @@ int num_class_lists() { return kNumLists; }
 s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_cap, int K,
                              const int32_t* n_nodes, const int32_t* p_nodes,
                              const int32_t* lvl_max, int64_t L, int32_t* class_count,
-                             int32_t* class_list) {
+                             int32_t* class_list, bool allow_hash) {
   if (L == 0) return S3GRL_OK;
   const ClassBounds cb = class_bounds(g->num_nodes, cn_cap, K);
   if (cb.b[kNumClasses - 1] < 0) {
@@ -899,7 +926,7 @@ s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_ca
     return S3GRL_ERR_GRAPH_TOO_LARGE;
   }
   hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream,
-                     n_nodes, p_nodes, lvl_max, L, cb, sparse_mode_for(g) ? 1 : 0,
+                     n_nodes, p_nodes, lvl_max, L, cb, (allow_hash && sparse_mode_for(g)) ? 1 : 0,
                      class_bounds_sparse(cn_cap, K), class_count, class_list);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
@@ -927,6 +954,7 @@ struct LinkArgs {
   char* scratch;
   int64_t scratch_stride;
   unsigned long long* dbg;
+  HopSampling smp;
 };
 
 template <int T, int K, int G, bool GS, bool HS>
@@ -950,7 +978,7 @@ s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t 
                      reinterpret_cast<unsigned long long*>(a.tot_edges),
                      reinterpret_cast<unsigned long long*>(a.tot_support),
                      reinterpret_cast<unsigned long long*>(a.tot_vol), a.scratch, a.scratch_stride,
-                     a.dbg);
+                     a.dbg, a.smp);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -1006,7 +1034,8 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           const int64_t* node_off, const int64_t* row_ptr, const int64_t* job_off,
                           const int64_t* coef_off, const int32_t* mirror_of, int32_t* c_ids,
                           float* c_coef, Job* jobs, float* job_z, int64_t* row_nodes, int32_t* lvl,
-                          int64_t* tot_edges, int64_t* tot_support, int64_t* tot_vol) {
+                          int64_t* tot_edges, int64_t* tot_support, int64_t* tot_vol,
+                          HopSampling smp) {
   if (L == 0) return S3GRL_OK;
   // links too large for LDS keep their lists in HBM scratch: one 256-byte aligned slice each
   Transient scratch_owner{ctx, {}};
@@ -1023,7 +1052,8 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
              row_ptr,
              job_off, coef_off, mirror_of, c_ids, c_coef, jobs, job_z, row_nodes, lvl, tot_edges,
              tot_support, tot_vol, scratch, scratch_stride,
-             getenv("S3GRL_DEBUG_STAMPS") ? reinterpret_cast<unsigned long long*>(ctx->d_scalars + 16) : nullptr};
+             getenv("S3GRL_DEBUG_STAMPS") ? reinterpret_cast<unsigned long long*>(ctx->d_scalars + 16) : nullptr,
+             smp};
   switch (K) {
     case 1: return launch_links_k<1>(ctx, a, L, class_count_host);
     case 2: return launch_links_k<2>(ctx, a, L, class_count_host);

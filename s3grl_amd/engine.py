@@ -274,7 +274,8 @@ class Engine:
 
     # ---- the batched native entry ----------------------------------------------------------
     def plan(self, graph, links, *, mode="pos", num_hops=1, sign_k=3, strategy="intersection",
-             directed=False, full_stats=False, fold_reversed=True, rw=None):
+             directed=False, full_stats=False, fold_reversed=True, rw=None, ratio_per_hop=1.0,
+             max_nodes_per_hop=None, seed=0):
         cfg = N.Cfg()
         cfg.mode = {"pos": N.MODE_POS, "pos_plus": N.MODE_POS_PLUS}[mode]
         cfg.num_hops = int(num_hops)
@@ -283,27 +284,41 @@ class Engine:
             raise NotImplementedError(f"check strat {strategy}")      # tuned_SIGN.py:235
         cfg.strategy = N.STRATEGY[strategy]
         cfg.directed = int(bool(directed))
-        # bit 0: per-link diagnostics (exact edge totals, export of every subgraph);
-        # bit 1: do not fold reversed duplicates (d,s) into (s,d)
-        cfg.reserved[0] = (1 if full_stats else 0) | (0 if fold_reversed else 2)
+        cfg.flags = (N.FLAG_FULL_STATS if full_stats else 0) | (0 if fold_reversed else N.FLAG_NO_FOLD)
+        cfg.seed = int(seed) & 0xffffffff
+        cfg.ratio_per_hop = 1.0
         if rw is not None:
             # ScaLed subgraphs (reference rw_kwargs): rw = (m, M[, seed]) — M walks of length m per
             # node instead of the k-hop BFS
             m, M = int(rw[0]), int(rw[1])
             if not (0 < m < 65536 and 0 < M < 65536):
                 raise ValueError("rw = (m, M[, seed]) with 0 < m, M < 65536")
-            cfg.reserved[1] = m | (M << 16)
-            cfg.reserved[2] = int(rw[2]) & 0x7fffffff if len(rw) > 2 else 0
+            cfg.rw_m, cfg.rw_M = m, M
+            if len(rw) > 2:
+                cfg.seed = int(rw[2]) & 0xffffffff
+        else:
+            # per-hop sampling (reference utils.py:66-70); the rw branch of the reference ignores it
+            if ratio_per_hop is not None:
+                if not ratio_per_hop > 0.0:
+                    raise ValueError("ratio_per_hop must be > 0")
+                cfg.ratio_per_hop = min(float(ratio_per_hop), 1.0)
+            if max_nodes_per_hop is not None:
+                if int(max_nodes_per_hop) < 1:
+                    raise ValueError("max_nodes_per_hop must be >= 1 (or None)")
+                cfg.max_nodes_per_hop = int(max_nodes_per_hop)
         return Plan(self, graph, links, cfg)
 
     def precompute(self, graph, x, links, *, mode="pos", num_hops=1, sign_k=3,
-                   strategy="intersection", directed=False, out=None, rw=None):
+                   strategy="intersection", directed=False, out=None, rw=None, ratio_per_hop=1.0,
+                   max_nodes_per_hop=None, seed=0):
         """links: int64 [L,2] device tensor (see `links()`); x: fp32 [N,F] device tensor."""
         if x is None:
             N.check(N.ERR_NO_FEATURES, "precompute")
         if mode == "hybrid":
             # reference utils.py:454-480: PoS keys kept, SoP x2..xK appended as x{K+1}..x{2K-1}
-            pos = self.precompute(graph, x, links, mode="pos", num_hops=num_hops, sign_k=sign_k, rw=rw)
+            pos = self.precompute(graph, x, links, mode="pos", num_hops=num_hops, sign_k=sign_k, rw=rw,
+                                  ratio_per_hop=ratio_per_hop, max_nodes_per_hop=max_nodes_per_hop,
+                                  seed=seed)
             if sign_k == 1:
                 return pos
             sop = self.precompute(graph, x, links, mode="sop", sign_k=sign_k)
@@ -320,7 +335,8 @@ class Engine:
             return Precomputed(rows, row_ptr, links.reshape(-1).clone(), {"num_links": L,
                                                                           "total_rows": 2 * L})
         plan = self.plan(graph, links, mode=mode, num_hops=num_hops, sign_k=sign_k,
-                         strategy=strategy, directed=directed, rw=rw)
+                         strategy=strategy, directed=directed, rw=rw, ratio_per_hop=ratio_per_hop,
+                         max_nodes_per_hop=max_nodes_per_hop, seed=seed)
         try:
             rows = plan.run(x, out)
             res = Precomputed(rows, plan.row_ptr(), plan.row_nodes(), dict(plan.stats))

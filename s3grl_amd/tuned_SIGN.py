@@ -7,10 +7,12 @@ static method uploads (and caches) A and x, runs the HIP engine once for the who
 returns a `list` of per-link `Data`-like objects that are views into one collated tensor.
 
 What is NOT mirrored (raises NotImplementedError, the reference's own convention for unsupported
-flows): per-hop sampling (`ratio_per_hop < 1`, `max_nodes_per_hop`), directed graphs (`A_csc`), and
-`k_node_set_strategy='union'`, which the reference itself cannot execute (tuned_SIGN.py:243
-builds a ragged tensor).  ScaLed random-walk subgraphs (`rw_kwargs`) are supported with the
-engine's own walks (same distribution, different random numbers than torch_cluster's).
+flows): directed graphs (`A_csc`), and `k_node_set_strategy='union'`, which the reference itself
+cannot execute (tuned_SIGN.py:243 builds a ragged tensor).  The two randomised options are
+supported with the engine's own counter-based generator — same distribution, different random
+numbers than the reference's: ScaLed random-walk subgraphs (`rw_kwargs`; torch_cluster's walks
+there) and per-hop sampling (`ratio_per_hop < 1`, `max_nodes_per_hop`; Python's `random.sample`
+there, utils.py:66-70), the latter seeded by `SAMPLING_SEED`.
 """
 from __future__ import annotations
 
@@ -125,13 +127,19 @@ def _rw_of(rw_kwargs):
     return (int(rw_kwargs['rw_m']), int(rw_kwargs['rw_M']), int(rw_kwargs.get('seed', 0)))
 
 
+# seed of the per-hop sampling draw (the reference seeds Python's global `random` from --seed,
+# sgrl_link_pred.py `set_random_seed`; set this from the same argument)
+SAMPLING_SEED = 0
+
+
 def _check_unsupported(ratio_per_hop, max_nodes_per_hop, directed, A_csc, rw_kwargs):
-    if ratio_per_hop is not None and ratio_per_hop < 1.0:
-        raise NotImplementedError("ratio_per_hop < 1.0 (per-hop sampling) is not implemented")
-    if max_nodes_per_hop is not None:
-        raise NotImplementedError("max_nodes_per_hop is not implemented")
     if directed or A_csc is not None:
         raise NotImplementedError("directed graphs are not implemented")
+
+
+def _sampling_of(ratio_per_hop, max_nodes_per_hop):
+    return {"ratio_per_hop": 1.0 if ratio_per_hop is None else ratio_per_hop,
+            "max_nodes_per_hop": max_nodes_per_hop, "seed": SAMPLING_SEED}
 
 
 class OptimizedSignOperations:
@@ -158,7 +166,7 @@ class OptimizedSignOperations:
         assert x is not None                                  # tuned_SIGN.py:166
         eng, g, xd = _device_inputs(A, x)
         res = eng.precompute(g, xd, eng.links(link_index), mode="pos", num_hops=num_hops, sign_k=K,
-                             rw=_rw_of(rw_kwargs))
+                             rw=_rw_of(rw_kwargs), **_sampling_of(ratio_per_hop, max_nodes_per_hop))
         return _as_data_list(res, K, y)
 
     @staticmethod
@@ -177,7 +185,8 @@ class OptimizedSignOperations:
         assert x is not None                                  # tuned_SIGN.py:221
         eng, g, xd = _device_inputs(A, x)
         res = eng.precompute(g, xd, eng.links(link_index), mode="pos_plus", num_hops=num_hops,
-                             sign_k=K, strategy=strat, rw=_rw_of(rw_kwargs))
+                             sign_k=K, strategy=strat, rw=_rw_of(rw_kwargs),
+                             **_sampling_of(ratio_per_hop, max_nodes_per_hop))
         return _as_data_list(res, K, y)
 
 

@@ -38,5 +38,10 @@ def load_diffusion(name):
     return np.load(GOLDEN / f"diffusion_{name}.npz")
 
 
+def load_sampled(name):
+    return np.load(GOLDEN / f"sampled_{name}.npz")
+
+
+SAMPLED_NAMES = ["rand300", "usair", "cora"]
 EXTRACT_NAMES = ["probe5", "triangle", "pair", "star_iso", "rand300", "usair", "cora"]
 DIFFUSION_NAMES = ["probe5", "star_iso", "rand300", "usair"]

@@ -176,6 +176,59 @@ def make_extract(ref_utils):
         print(f"extract_{name}.npz: {len(links)} links x hops {hops}")
 
 
+def make_sampled(ref_utils):
+    """sampled_*.npz — REFERENCE-PINNED control flow of the per-hop sampling (utils.py:62-74:
+    what stays visited, ratio before cap, int() truncation, the empty-sample break), executed by
+    the reference's own k_hop_subgraph.  Its draw, `random.sample(fringe, k)`, is swapped for the
+    engine's keyed pick (oracle.hash_sampler) while the call runs, so the outcome is a fixed
+    vector instead of a function of Python's RNG state and set iteration order."""
+    import random
+
+    import oracle
+
+    seed = 1234
+    settings = [(0.5, None), (1.0, 10), (0.7, 25), (0.05, None), (0.9, 3)]
+    rng = np.random.default_rng(7)
+    all_links = {name: fixture_links(name, n, edges, rng) for name, (n, edges) in fixture_graphs().items()}
+    for name in ["rand300", "usair", "cora"]:
+        n, edges = fixture_graphs()[name]
+        A = csr_from_undirected(n, edges)
+        links = all_links[name]
+        h = 3 if name == "cora" else 2
+        blob = {"num_nodes": np.int64(n), "edges": np.asarray(edges, dtype=np.int32),
+                "links": np.asarray(links, dtype=np.int64), "num_hops": np.int64(h),
+                "seed": np.int64(seed),
+                "ratio": np.asarray([r for r, _ in settings]),
+                "max_nodes": np.asarray([-1 if m is None else m for _, m in settings])}
+        X = np.arange(n, dtype=np.float32).reshape(-1, 1)
+        for si, (ratio, cap) in enumerate(settings):
+            cat = {"nodes": [], "dists": [], "cn": []}
+            for s_, d_ in links:
+                pick = oracle.hash_sampler(seed, s_, d_)
+                real = random.sample
+                random.sample = lambda pop, k: pick(pop, k)
+                try:
+                    nodes, sub, dists, _, _ = ref_utils.k_hop_subgraph(
+                        s_, d_, h, A, ratio, cap, node_features=X, y=1, directed=False, A_csc=None,
+                        rw_kwargs=None)
+                finally:
+                    random.sample = real
+                nodes = [int(v) for v in nodes]
+                sub = ssp.csr_matrix(sub)
+                cn_local = ref_utils.neighbors({0}, sub) & ref_utils.neighbors({1}, sub)
+                order = np.lexsort((np.asarray(nodes), np.asarray(dists)))
+                cat["nodes"].append(np.asarray(nodes, dtype=np.int32)[order])
+                cat["dists"].append(np.asarray(dists, dtype=np.int8)[order])
+                cat["cn"].append(np.asarray(sorted(nodes[int(a)] for a in cn_local), dtype=np.int32))
+            for k, parts in cat.items():
+                off = np.zeros(len(parts) + 1, dtype=np.int64)
+                np.cumsum([len(p) for p in parts], out=off[1:])
+                blob[f"s{si}_{k}"] = np.concatenate(parts, axis=0)
+                blob[f"s{si}_{k}_off"] = off
+        np.savez_compressed(HERE / f"sampled_{name}.npz", **blob)
+        print(f"sampled_{name}.npz: {len(links)} links x {len(settings)} settings, h={h}")
+
+
 def make_diffusion():
     import oracle
 
@@ -206,5 +259,7 @@ def make_diffusion():
 if __name__ == "__main__":
     if not REFERENCE.exists():
         sys.exit("needs /root/reference (build container only)")
-    make_extract(import_reference_utils())
+    ref = import_reference_utils()
+    make_extract(ref)
+    make_sampled(ref)
     make_diffusion()

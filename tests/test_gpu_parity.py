@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import DIFFUSION_NAMES, EXTRACT_NAMES, csr_from_undirected, load_diffusion, load_extract
+from conftest import (DIFFUSION_NAMES, EXTRACT_NAMES, SAMPLED_NAMES, csr_from_undirected, load_diffusion,
+                      load_extract, load_sampled)
 
 pytestmark = pytest.mark.gpu
 
@@ -196,7 +197,7 @@ def test_dropin_operator_api(eng):
         for k in ("x", "x1", "x2"):
             assert rel_err(d[k].numpy(), r[k]) < TOL
     with pytest.raises(NotImplementedError):
-        OptimizedSignOperations.get_PoS_prepped_ds(link_index, 1, A, 0.5, None, False, None, X, 1, kw,
+        OptimizedSignOperations.get_PoS_prepped_ds(link_index, 1, A, 1.0, None, True, A.tocsc(), X, 1, kw,
                                                    None)
     with pytest.raises(AssertionError):
         OptimizedSignOperations.get_PoS_prepped_ds(link_index, 1, A, 1.0, None, False, None, None, 1,
@@ -861,3 +862,100 @@ def test_collab_scale_sampled_links(eng):
     sel = np.unique(np.concatenate([np.random.default_rng(5).choice(link_index.shape[1], 40000, replace=False),
                                     heavy]))
     _all_links_vs_c(eng, w, "pos", links_sel=sel, chunk=10000)
+
+
+# ------------------------------------------------------------------------------------------
+# per-hop sampling (reference utils.py:66-70: ratio_per_hop, max_nodes_per_hop)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", SAMPLED_NAMES)
+def test_sampled_extraction_vs_reference_fixture(eng, name):
+    """Node sets per hop and CN rows, bit-exact against what the reference's own k_hop_subgraph
+    produced with the keyed draw (tests/golden/sampled_*.npz)."""
+    g = load_sampled(name)
+    n, h, seed = int(g["num_nodes"]), int(g["num_hops"]), int(g["seed"])
+    G = eng.graph(csr_from_undirected(n, g["edges"]))
+    L = eng.links(g["links"].T)
+    for si, (ratio, cap) in enumerate(zip(g["ratio"], g["max_nodes"])):
+        cap = None if cap < 0 else int(cap)
+        plan = eng.plan(G, L, mode="pos_plus", num_hops=h, sign_k=2, full_stats=True,
+                        ratio_per_hop=float(ratio), max_nodes_per_hop=cap, seed=seed)
+        node_ptr, nodes, dists = (t.cpu().numpy() for t in plan.export_subgraphs())
+        row_ptr = plan.row_ptr().cpu().numpy()
+        row_nodes = plan.row_nodes().cpu().numpy()
+        for li in range(len(g["links"])):
+            mine = nodes[node_ptr[li]:node_ptr[li + 1]]
+            md = dists[node_ptr[li]:node_ptr[li + 1]]
+            order = np.lexsort((mine, md))
+            np.testing.assert_array_equal(mine[order], _ragged(g, f"s{si}_nodes", li))
+            np.testing.assert_array_equal(md[order], _ragged(g, f"s{si}_dists", li))
+            np.testing.assert_array_equal(row_nodes[row_ptr[li] + 2:row_ptr[li + 1]], _ragged(g, f"s{si}_cn", li))
+        plan.close()
+    G.close()
+
+
+@pytest.mark.parametrize("mode", ["pos", "pos_plus"])
+@pytest.mark.parametrize("ratio,cap", [(0.5, None), (1.0, 7), (0.8, 12)])
+def test_sampled_diffusion_vs_oracle(eng, mode, ratio, cap):
+    g = load_extract("rand300")
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = np.random.default_rng(3).standard_normal((n, 11))
+    links = np.concatenate([g["links"], g["links"][:10, ::-1]])          # + reversed duplicates (folded)
+    G = eng.graph(A)
+    res = eng.precompute(G, eng.features(X), eng.links(links.T), mode=mode, num_hops=2, sign_k=3,
+                         ratio_per_hop=ratio, max_nodes_per_hop=cap, seed=99)
+    fn = oracle.get_PoS_prepped_ds if mode == "pos" else oracle.get_PoS_Plus_prepped_ds
+    lst = fn(links.T, 2, A, X.astype(np.float32).astype(np.float64), 1,
+             {"sign_k": 3, "k_node_set_strategy": "intersection"}, dtype=np.float64,
+             ratio_per_hop=ratio, max_nodes_per_hop=cap, sample_seed=99)
+    ref, ref_ptr, _ = oracle.collate_rows(lst, 3)
+    np.testing.assert_array_equal(res.row_ptr.cpu().numpy(), ref_ptr)
+    assert rel_err(res.rows.cpu().numpy(), ref) < TOL
+    assert res.stats["folded_links"] == 10
+    full = eng.precompute(G, eng.features(X), eng.links(links.T), mode=mode, num_hops=2, sign_k=3)
+    assert res.stats["total_nodes"] < full.stats["total_nodes"]
+    # another seed draws other nodes
+    other = eng.precompute(G, eng.features(X), eng.links(links.T), mode=mode, num_hops=2, sign_k=3,
+                           ratio_per_hop=ratio, max_nodes_per_hop=cap, seed=100)
+    assert not np.array_equal(other.rows.cpu().numpy(), res.rows.cpu().numpy())
+    G.close()
+
+
+def test_sampling_through_the_dropin_api_and_hbm_scratch(eng, monkeypatch):
+    import torch
+    from s3grl_amd import tuned_SIGN
+
+    g = load_extract("usair")
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = torch.from_numpy(np.random.default_rng(4).standard_normal((n, 6)).astype(np.float32))
+    link_index = torch.from_numpy(g["links"].T.copy())
+    kw = {"sign_k": 2, "k_node_set_strategy": "intersection"}
+    monkeypatch.setattr(tuned_SIGN, "SAMPLING_SEED", 21)
+    for budget in (None, "2048"):                    # LDS classes, then the HBM-scratch class
+        if budget:
+            monkeypatch.setenv("S3GRL_LDS_BUDGET", budget)
+        lst = tuned_SIGN.OptimizedSignOperations.get_PoS_Plus_prepped_ds(link_index, 2, A, 0.3, 40, False, None,
+                                                                         X, 1, kw, None)
+        ref = oracle.get_PoS_Plus_prepped_ds(link_index.numpy(), 2, A, X.numpy().astype(np.float64), 1, kw,
+                                             dtype=np.float64, ratio_per_hop=0.3, max_nodes_per_hop=40,
+                                             sample_seed=21)
+        for d, r in zip(lst, ref):
+            assert d.x.shape == r["x"].shape
+            for k in ("x", "x1", "x2"):
+                assert rel_err(d[k].numpy(), r[k]) < TOL
+    tuned_SIGN.clear_cache()
+
+
+def test_sampling_argument_errors(eng):
+    G = eng.graph(csr_from_undirected(5, [[0, 2], [1, 2], [0, 3], [1, 3], [3, 4]]))
+    L = eng.links(np.array([[0], [1]]))
+    with pytest.raises(ValueError):
+        eng.plan(G, L, num_hops=1, sign_k=1, ratio_per_hop=0.0)
+    with pytest.raises(ValueError):
+        eng.plan(G, L, num_hops=1, sign_k=1, max_nodes_per_hop=0)
+    # a ratio small enough to empty the first hop ends the walk there: the subgraph is {src,dst}
+    p = eng.plan(G, L, num_hops=2, sign_k=1, ratio_per_hop=0.1, full_stats=True)
+    assert p.stats["total_nodes"] == 2
+    p.close()
+    G.close()

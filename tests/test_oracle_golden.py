@@ -6,7 +6,8 @@ import pytest
 import scipy.sparse as ssp
 
 import oracle
-from conftest import DIFFUSION_NAMES, EXTRACT_NAMES, csr_from_undirected, load_diffusion, load_extract
+from conftest import (DIFFUSION_NAMES, EXTRACT_NAMES, SAMPLED_NAMES, csr_from_undirected, load_diffusion,
+                      load_extract, load_sampled)
 
 
 def _ragged(blob, key, i):
@@ -37,6 +38,47 @@ def test_extraction_matches_reference(name):
             # PoS Plus row selection (K4)
             cn = oracle.neighbors({0}, sub) & oracle.neighbors({1}, sub)
             np.testing.assert_array_equal(sorted(nodes[a] for a in cn), _ragged(g, f"h{h}_cn", li))
+
+
+@pytest.mark.parametrize("name", SAMPLED_NAMES)
+def test_sampled_extraction_matches_reference(name):
+    """Per-hop sampling (utils.py:62-74) as the reference's own k_hop_subgraph executes it with the
+    keyed draw in place of random.sample (tests/golden/make_golden.py:make_sampled)."""
+    g = load_sampled(name)
+    A = csr_from_undirected(int(g["num_nodes"]), g["edges"])
+    h, seed = int(g["num_hops"]), int(g["seed"])
+    shrunk = 0
+    for si, (ratio, cap) in enumerate(zip(g["ratio"], g["max_nodes"])):
+        cap = None if cap < 0 else int(cap)
+        for li, (s, d) in enumerate(g["links"]):
+            nodes, sub, dists, _, _ = oracle.k_hop_subgraph(
+                int(s), int(d), h, A, sample_ratio=float(ratio), max_nodes_per_hop=cap,
+                sampler=oracle.hash_sampler(seed, int(s), int(d)))
+            order = np.lexsort((np.asarray(nodes), np.asarray(dists)))
+            np.testing.assert_array_equal(np.asarray(nodes)[order], _ragged(g, f"s{si}_nodes", li))
+            np.testing.assert_array_equal(np.asarray(dists)[order], _ragged(g, f"s{si}_dists", li))
+            cn = oracle.neighbors({0}, ssp.csr_matrix(sub)) & oracle.neighbors({1}, ssp.csr_matrix(sub))
+            np.testing.assert_array_equal(sorted(nodes[a] for a in cn), _ragged(g, f"s{si}_cn", li))
+            full = oracle.k_hop_subgraph(int(s), int(d), h, A)[0]
+            assert set(nodes) <= set(full)
+            shrunk += len(nodes) < len(full)
+    assert shrunk > 0
+
+
+def test_sampling_key_is_symmetric_and_default_sampler_is_random_sample():
+    assert oracle.hop_sample_key(5, 3, 9, 77) & 0xffffffff == 77
+    a = oracle.hash_sampler(5, 3, 9)(range(100), 10)
+    b = oracle.hash_sampler(5, 9, 3)(range(100), 10)
+    assert a == b and len(set(a)) == 10 and a != oracle.hash_sampler(6, 3, 9)(range(100), 10)
+    g = load_extract("usair")
+    A = csr_from_undirected(int(g["num_nodes"]), g["edges"])
+    s, d = (int(v) for v in g["links"][0])
+    import random
+
+    random.seed(0)
+    n1 = oracle.k_hop_subgraph(s, d, 2, A, sample_ratio=0.5)[0]
+    full = oracle.k_hop_subgraph(s, d, 2, A)[0]
+    assert set(n1) < set(full) and n1[:2] == [s, d]
 
 
 def test_set_order_variant_same_sets():
