@@ -159,9 +159,11 @@ s3grl_status s3grl_run(s3grl_context* ctx, const s3grl_plan* p, const float* X, 
 
 /* The feature operand x of the reference operators (dense fp32 [N,F], utils.py:83), prepared
  * once: 16-byte aligned rows (borrowed when X already is: keep X alive and unchanged while the
- * handle is in use).  flags: 0 or 1 = dense rows (default); 2 = additionally build sparse rows
- * (column, value pairs) that the gather streams instead — same sums; opt-in because it measured
- * slower than the dense kernel at 10 % density on MI355X. */
+ * handle is in use).  flags: 0 = let the engine choose: when at most half of X's 16-byte
+ * chunks hold a non-zero (bag-of-words / TF-IDF / one-hot rows) it also keeps a packed copy —
+ * per row a bit mask of the non-zero chunks + those chunks — and the gather fetches only them;
+ * same sums bit for bit.  1 = dense rows only; 4 = packed rows whatever the density;
+ * 2 = (column, value)-pair rows accumulated in LDS (kept for comparison: slower than both). */
 s3grl_status s3grl_features_create(s3grl_context* ctx, const float* X, int64_t ldx,
                                    int64_t num_nodes, int64_t num_features, int32_t flags,
                                    s3grl_features** out);

@@ -511,6 +511,8 @@ static s3grl_status run_with(s3grl_context* ctx, const s3grl_plan* p, const s3gr
   S3GRL_TRY(record(ctx, 3));
   if (f->sparse)
     S3GRL_TRY(launch_gather_sparse(ctx, p, f, rows));
+  else if (f->packed)
+    S3GRL_TRY(launch_gather_packed(ctx, p, f, rows));
   else
     S3GRL_TRY(launch_gather(ctx, p->jobs, p->njobs, p->c_ids, p->c_coef, p->job_z, p->cfg.sign_k,
                             f->dense, f->ld, f->F, rows));

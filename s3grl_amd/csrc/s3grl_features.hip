@@ -289,6 +289,12 @@ s3grl_status s3grl_features_create(s3grl_context* ctx, const float* X, int64_t l
   // gather — the LDS read-modify-write chain at 12 waves/CU loses to the register-accumulator
   // kernel fed from the Infinity Cache.  Dense is therefore the default; sparse rows are opt-in.
   if (flags != 2 && !getenv("S3GRL_SPARSE_FEATURES")) {
+    // flags 0 (auto): packed rows when at most half of the 16-byte chunks of X are non-zero
+    // (PubMed TF-IDF: 33 %, Cora bag-of-words: 5 %); flags 4: always; flags 1: never
+    const char* env = getenv("S3GRL_PACKED_FEATURES");
+    const bool never = flags == 1 || (env && atoi(env) == 0);
+    const bool always = flags == 4 || (env && atoi(env) == 1);
+    if (!never) S3GRL_TRY(build_packed_rows(ctx, f.get(), always ? 2.0 : 0.5));
     *out = f.release();
     return S3GRL_OK;
   }
@@ -338,8 +344,8 @@ s3grl_status s3grl_features_create(s3grl_context* ctx, const float* X, int64_t l
 
 s3grl_status s3grl_features_info(const s3grl_features* f, int64_t* nnz, int32_t* is_sparse) {
   if (!f) return S3GRL_ERR_INVALID_ARGUMENT;
-  if (nnz) *nnz = f->nnz;
-  if (is_sparse) *is_sparse = f->sparse ? 1 : 0;
+  if (nnz) *nnz = f->packed || !f->sparse ? f->pk_chunks : f->nnz;
+  if (is_sparse) *is_sparse = f->sparse ? 1 : (f->packed ? 2 : 0);
   return S3GRL_OK;
 }
 

@@ -139,7 +139,20 @@ struct s3grl_features {
   int64_t nnz = 0;
   const int64_t* sp_ptr = nullptr;  // [tiles*N + 1]
   const void* sp_ent = nullptr;     // [nnz] (column-in-tile int32, value fp32)
+  // packed rows (s3grl_packed.hip): per (tile, row) a 128-bit mask of the non-zero 16-byte chunks
+  // of the 512-column tile + where its chunks start; the non-zero chunks back to back
+  bool packed = false;
+  const void* pk_hdr = nullptr;     // [tiles*N] PackedHdr
+  const void* pk_data = nullptr;    // [chunks] float4
+  int64_t pk_chunks = 0;            // non-zero chunks (of tiles*N*128 slots... F/4 real ones per row)
   std::vector<void*> owned;
+};
+
+// header of one (tile, row) of the packed operand: 32 bytes, read with one scalar load
+struct PackedHdr {
+  uint64_t m0, m1;   // bit j of m0: chunk j (columns 4j..4j+3 of the tile) is non-zero; m1: chunks 64..127
+  uint64_t off;      // index of the row's first chunk in pk_data
+  uint64_t pad;
 };
 
 struct s3grl_sop {
@@ -203,6 +216,9 @@ s3grl_status launch_gather(s3grl_context* ctx, const Job* jobs, int64_t njobs, c
                            const float* c_coef, const float* job_z, int K, const float* X,
                            int64_t ldx, int64_t F, float* rows);
 // features.hip
+s3grl_status build_packed_rows(s3grl_context* ctx, s3grl_features* f, double max_density);
+s3grl_status launch_gather_packed(s3grl_context* ctx, const s3grl_plan* p, const s3grl_features* f,
+                                  float* rows);
 s3grl_status launch_gather_sparse(s3grl_context* ctx, const s3grl_plan* p, const s3grl_features* f,
                                   float* rows);
 s3grl_status launch_copy_pad(s3grl_context* ctx, const float* X, int64_t ldx, int64_t N, int64_t F,

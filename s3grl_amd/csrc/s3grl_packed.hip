@@ -1,0 +1,307 @@
+// Packed-row feature operand and its gather kernel, gfx950.
+//
+// The reference hands its operators a dense fp32 X, but the matrices it is run on are row-
+// normalised bag-of-words / TF-IDF / one-hot rows (sgrl_link_pred.py:851,961-963): PubMed has
+// ~50 non-zeros in 500 columns, Cora ~18 in 1433.  The dense gather (s3grl_gather.hip) is bound
+// by the bytes it pulls through the fabric, and two thirds of its 16-byte lane loads fetch four
+// zeros.  Here X is stored a second time with the all-zero 16-byte chunks squeezed out:
+//
+//   pk_hdr[tile][row] = { 128-bit mask of the non-zero chunks of the 512-column tile, offset }
+//   pk_data           = one chunk of zeros, then the non-zero chunks in (tile, row, chunk) order
+//
+// The kernel is the dense one with a different fetch: a lane still OWNS chunk `lane` and chunk
+// `64 + lane` of the tile and keeps their 2K accumulators in registers (no LDS, no atomics —
+// the (column, value)-pair format of s3grl_features.hip lost to the dense kernel exactly there);
+// the row's header arrives through the scalar cache (the row id is wave-uniform), the lane's
+// chunk sits at offset + popcount(mask bits below the lane) = one v_mbcnt pair, and a lane whose
+// mask bit is clear reads a shared chunk of zeros instead.  c·0 adds nothing, so the sums are the dense
+// kernel's sums bit for bit.  PubMed: 33 % of the chunks are non-zero -> 0.7 KB instead of 2 KB
+// per subgraph node.
+#include <algorithm>
+#include <cstdlib>
+
+#include "s3grl_internal.hpp"
+#include "s3grl_gather_common.hpp"
+
+namespace s3grl {
+namespace {
+
+constexpr int kTile = 512;          // feature columns per tile = 128 chunks = 2 mask words
+constexpr int kWavesPerBlock = 4;
+
+__device__ __forceinline__ int below(uint64_t m) {   // set bits of m below this lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// chunk `j` of tile `tile` of row `row` of the dense X (rows 16-byte aligned, ld % 4 == 0,
+// ld >= F rounded up to 4); columns >= F read as zero, whatever a borrowed X holds there
+__device__ __forceinline__ float4_t dense_chunk(const float* __restrict__ X, int64_t ld, int F, int64_t row,
+                                                int tile, int j) {
+  const int col = tile * kTile + j * 4;
+  if (col >= F) return (float4_t)(0.f);
+  float4_t v = *reinterpret_cast<const float4_t*>(X + row * ld + col);
+  if (col + 1 >= F) v.y = 0.f;
+  if (col + 2 >= F) v.z = 0.f;
+  if (col + 3 >= F) v.w = 0.f;
+  return v;
+}
+
+__device__ __forceinline__ bool nonzero(float4_t v) {
+  return v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f;
+}
+
+// one wave per (tile, row): number of non-zero chunks
+__global__ __launch_bounds__(256) void pk_count_kernel(const float* __restrict__ X, int64_t ld, int F,
+                                                       int64_t N, int tiles, int32_t* __restrict__ cnt) {
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= N * tiles) return;
+  const int tile = (int)(item / N);
+  const int64_t row = item - (int64_t)tile * N;
+  const uint64_t m0 = __ballot(nonzero(dense_chunk(X, ld, F, row, tile, lane)));
+  const uint64_t m1 = __ballot(nonzero(dense_chunk(X, ld, F, row, tile, 64 + lane)));
+  if (lane == 0) cnt[item] = __popcll(m0) + __popcll(m1);
+}
+
+__global__ __launch_bounds__(256) void pk_fill_kernel(const float* __restrict__ X, int64_t ld, int F,
+                                                      int64_t N, int tiles, const int64_t* __restrict__ ptr,
+                                                      PackedHdr* __restrict__ hdr,
+                                                      float4_t* __restrict__ data) {
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= N * tiles) return;
+  const int tile = (int)(item / N);
+  const int64_t row = item - (int64_t)tile * N;
+  const float4_t v0 = dense_chunk(X, ld, F, row, tile, lane);
+  const float4_t v1 = dense_chunk(X, ld, F, row, tile, 64 + lane);
+  const uint64_t m0 = __ballot(nonzero(v0));
+  const uint64_t m1 = __ballot(nonzero(v1));
+  const int64_t off = ptr[item] + 1;   // pk_data[0] is a chunk of zeros (what a masked-off lane loads)
+  if (item == 0 && lane == 0) data[0] = (float4_t)(0.f);
+  if ((m0 >> lane) & 1) data[off + below(m0)] = v0;
+  if ((m1 >> lane) & 1) data[off + __popcll(m0) + below(m1)] = v1;
+  if (lane == 0) {
+    PackedHdr h;
+    h.m0 = m0;
+    h.m1 = m1;
+    h.off = (uint64_t)off;
+    h.pad = 0;
+    hdr[item] = h;
+  }
+}
+
+// One wavefront owns one row pair and one 512-column tile; see the file comment.
+//
+// Schedule.  At 0.7 KB per row the kernel is no longer bound by bytes but by how well the chain
+// id -> header -> chunk loads -> 2K FMAs per chunk overlaps inside a wavefront (116 VGPRs allow 4
+// waves per SIMD).  It is software-pipelined by hand over groups of U = 4 rows with two register
+// buffers: while the FMAs of group g run, the chunk loads of group g+1 are in flight and the
+// ids/headers of group g+2 are on their way through the scalar cache.  (Measured alternatives on
+// PubMed, K=3: no pipelining 17.8 ms; U=2 x 4 buffers 16.6 ms — more scalar instructions per row;
+// U=4 x 3 buffers 17.1 ms — 156 VGPRs, 3 waves per SIMD; this form 14.4 ms.)  For the compiler to wait
+// for "all but the newest 2U loads" (vmcnt) rather than for all of them, the loads must not sit
+// behind divergent branches: a lane whose mask bit is clear loads pk_data[0], a chunk of zeros
+// (one line, L1-resident), chosen with one v_cndmask on the wave-uniform mask — so every load
+// is unconditional and the steady-state loop body has no control flow at all.  The phases are
+// kept apart with scheduling barriers; left alone, the compiler serialises the scalar loads
+// (load, wait, use, load, wait, ...).
+__device__ __forceinline__ uint32_t select_by_mask(uint64_t mask, uint32_t if_set) {
+  uint32_t r;   // lane-wise: bit `lane` of the wave-uniform mask ? if_set : 0
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(if_set), "s"(mask));
+  return r;
+}
+
+template <int K>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
+    const Job* __restrict__ jobs, int njobs, const int32_t* __restrict__ c_ids,
+    const float* __restrict__ c_coef, const float* __restrict__ job_z,
+    const PackedHdr* __restrict__ hdr, const float4_t* __restrict__ data, int64_t N,
+    const float* __restrict__ X, int64_t ldx, int F, float* __restrict__ rows) {
+  constexpr int CH = 2;
+  constexpr int U = 4;   // rows per group
+  const int lane = threadIdx.x & 63;
+  const int jid = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+  if (jid >= njobs) return;
+  const int col0 = blockIdx.y * kTile;
+  const Job job = jobs[jid];
+  const int cnt = __builtin_amdgcn_readfirstlane(job.support);
+  const uint32_t* __restrict__ uid = reinterpret_cast<const uint32_t*>(c_ids + job.ids_off);
+  const float2* __restrict__ cf = reinterpret_cast<const float2*>(c_coef) + job.coef_off;
+  const PackedHdr* __restrict__ th = hdr + (int64_t)blockIdx.y * N;
+  const char* __restrict__ bytes = reinterpret_cast<const char*>(data);
+
+  int coff[CH];
+  bool cok[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    coff[c] = col0 + (lane + 64 * c) * 4;
+    cok[c] = coff[c] < F;
+  }
+  float4_t acc[K][2][CH];
+#pragma unroll
+  for (int i = 0; i < K; ++i)
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < CH; ++c) acc[i][r][c] = (float4_t)(0.f);
+
+  auto load_hdrs = [&](int g, PackedHdr(&h)[U]) {   // scalar: ids (one wide load), then headers
+    uint32_t id[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) id[u] = uid[g * U + u];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) h[u] = th[id[u]];
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto issue = [&](const PackedHdr(&h)[U], float4_t(&v)[U][CH]) {   // 2U unconditional loads
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t base = (uint32_t)h[u].off;
+      const uint32_t o0 = select_by_mask(h[u].m0, (base + (uint32_t)below(h[u].m0)) << 4);
+      const uint32_t o1 = select_by_mask(
+          h[u].m1, (base + (uint32_t)__popcll(h[u].m0) + (uint32_t)below(h[u].m1)) << 4);
+      v[u][0] = *reinterpret_cast<const float4_t*>(bytes + o0);
+      v[u][1] = *reinterpret_cast<const float4_t*>(bytes + o1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto fma = [&](int g, const float4_t(&v)[U][CH]) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float2 q = cf[(int64_t)i * cnt + g * U + u];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          acc[i][0][c] += q.x * v[u][c];
+          acc[i][1][c] += q.y * v[u][c];
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  const int ngf = cnt / U;   // full groups
+  int g = 0;
+  if (ngf > 0) {
+    PackedHdr hA[U], hB[U];
+    float4_t vA[U][CH], vB[U][CH];
+    load_hdrs(0, hA);
+    issue(hA, vA);
+    if (ngf > 1) load_hdrs(1, hB);
+    // steady state, no control flow inside: vA = group g in flight, hB = headers of group g+1
+    for (; g + 3 < ngf; g += 2) {
+      issue(hB, vB);
+      load_hdrs(g + 2, hA);
+      fma(g, vA);
+      issue(hA, vA);
+      load_hdrs(g + 3, hB);
+      fma(g + 1, vB);
+    }
+    fma(g, vA);
+    ++g;
+    for (; g < ngf; ++g) {   // at most 3 groups
+      load_hdrs(g, hA);
+      issue(hA, vA);
+      fma(g, vA);
+    }
+  }
+  for (int j = ngf * U; j < cnt; ++j) {   // at most U-1 rows
+    const PackedHdr h = th[uid[j]];
+    const uint32_t base = (uint32_t)h.off;
+    const uint32_t o0 = select_by_mask(h.m0, (base + (uint32_t)below(h.m0)) << 4);
+    const uint32_t o1 = select_by_mask(h.m1, (base + (uint32_t)__popcll(h.m0) + (uint32_t)below(h.m1)) << 4);
+    float4_t v[CH];
+    v[0] = *reinterpret_cast<const float4_t*>(bytes + o0);
+    v[1] = *reinterpret_cast<const float4_t*>(bytes + o1);
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const float2 q = cf[(int64_t)i * cnt + j];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        acc[i][0][c] += q.x * v[c];
+        acc[i][1][c] += q.y * v[c];
+      }
+    }
+  }
+  write_pair_rows<K, CH>(job, jid, acc, coff, cok, job_z, X, ldx, F, rows, blockIdx.y == 0);
+}
+
+template <int K>
+s3grl_status launch_packed_k(s3grl_context* ctx, const s3grl_plan* p, const s3grl_features* f,
+                             float* rows) {
+  const unsigned gx = (unsigned)((p->njobs + kWavesPerBlock - 1) / kWavesPerBlock);
+  hipLaunchKernelGGL((gather_packed_kernel<K>), dim3(gx, (unsigned)f->tiles), dim3(kWavesPerBlock * 64),
+                     0, ctx->stream, p->jobs, (int)p->njobs, p->c_ids, p->c_coef, p->job_z,
+                     static_cast<const PackedHdr*>(f->pk_hdr), static_cast<const float4_t*>(f->pk_data),
+                     f->N, f->dense, f->ld, (int)f->F, rows);
+  S3GRL_HIP_TRY(hipGetLastError());
+  return S3GRL_OK;
+}
+
+}  // namespace
+
+// Builds the packed copy of f->dense when at most `max_density` of its chunks are non-zero
+// (otherwise leaves f->packed false: the dense kernel moves no more bytes and issues fewer
+// instructions).  One host round trip for the chunk total.
+s3grl_status build_packed_rows(s3grl_context* ctx, s3grl_features* f, double max_density) {
+  const int64_t N = f->N;
+  const int tiles = (int)((f->F + kTile - 1) / kTile);
+  const int64_t items = N * tiles;
+  Transient tmp{ctx, {}};
+  void* q = nullptr;
+  S3GRL_TRY(ctx->arena.alloc((size_t)items * 4, &q));
+  tmp.ptrs.push_back(q);
+  int32_t* cnt = static_cast<int32_t*>(q);
+  S3GRL_TRY(ctx->arena.alloc((size_t)(items + 1) * 8, &q));
+  tmp.ptrs.push_back(q);
+  int64_t* ptr = static_cast<int64_t*>(q);
+  S3GRL_TRY(ctx->arena.alloc((size_t)scan_workspace_elems(items) * 8, &q));
+  tmp.ptrs.push_back(q);
+  int64_t* ws = static_cast<int64_t*>(q);
+  const unsigned grid = (unsigned)((items + 3) / 4);
+  hipLaunchKernelGGL(pk_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, f->dense, f->ld, (int)f->F, N, tiles, cnt);
+  S3GRL_HIP_TRY(hipGetLastError());
+  S3GRL_TRY(launch_scan_i32_to_i64(ctx, cnt, items, ptr, ws));
+  S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_scalars, ptr + items, 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const int64_t chunks = ctx->h_scalars[0];
+  const double slots = (double)N * (double)((f->F + 3) / 4);
+  f->pk_chunks = chunks;
+  if ((double)chunks > max_density * slots) return S3GRL_OK;
+  if ((chunks + 1) * 16 >= ((int64_t)1 << 32)) return S3GRL_OK;   // the kernel addresses chunks with 32-bit byte offsets
+  void* hdr = nullptr;
+  void* data = nullptr;
+  S3GRL_TRY(ctx->arena.alloc((size_t)items * sizeof(PackedHdr), &hdr));
+  f->owned.push_back(hdr);
+  S3GRL_TRY(ctx->arena.alloc((size_t)(chunks + 1) * 16, &data));
+  f->owned.push_back(data);
+  hipLaunchKernelGGL(pk_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, f->dense, f->ld, (int)f->F, N, tiles, ptr,
+                     static_cast<PackedHdr*>(hdr), static_cast<float4_t*>(data));
+  S3GRL_HIP_TRY(hipGetLastError());
+  f->pk_hdr = hdr;
+  f->pk_data = data;
+  f->packed = true;
+  return S3GRL_OK;
+}
+
+s3grl_status launch_gather_packed(s3grl_context* ctx, const s3grl_plan* p, const s3grl_features* f,
+                                  float* rows) {
+  if (p->njobs == 0) return S3GRL_OK;
+  switch (p->cfg.sign_k) {
+    case 1: return launch_packed_k<1>(ctx, p, f, rows);
+    case 2: return launch_packed_k<2>(ctx, p, f, rows);
+    case 3: return launch_packed_k<3>(ctx, p, f, rows);
+    case 4: return launch_packed_k<4>(ctx, p, f, rows);
+    case 5: return launch_packed_k<5>(ctx, p, f, rows);
+    case 6: return launch_packed_k<6>(ctx, p, f, rows);
+    case 7: return launch_packed_k<7>(ctx, p, f, rows);
+    case 8: return launch_packed_k<8>(ctx, p, f, rows);
+    default:
+      set_last_error("sign_k must be in 1..8");
+      return S3GRL_ERR_INVALID_ARGUMENT;
+  }
+}
+
+}  // namespace s3grl

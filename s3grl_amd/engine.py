@@ -66,11 +66,12 @@ class Graph:
 
 
 class Features:
-    """The feature operand x, prepared once for the gather: aligned dense rows (`mode` "auto" /
-    "dense"), or additionally sparse (column, value) rows (`mode` "sparse", opt-in: slower than
-    dense at 10 % density on MI355X)."""
+    """The feature operand x, prepared once for the gather: aligned dense rows, plus — `mode`
+    "auto" when at most half of x's 16-byte chunks are non-zero, "packed" always — a packed copy
+    (per row a bit mask of its non-zero chunks + those chunks) that the gather fetches instead.
+    "dense": dense rows only.  "sparse": (column, value) rows accumulated in LDS (comparison only)."""
 
-    _MODES = {"auto": 0, "dense": 1, "sparse": 2}
+    _MODES = {"auto": 0, "dense": 1, "sparse": 2, "packed": 4}
 
     def __init__(self, engine, x, mode="auto"):
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
@@ -83,7 +84,7 @@ class Features:
         engine._children.add(self)
         nnz, sp = C.c_int64(), C.c_int32()
         N.check(N.lib().s3grl_features_info(h, C.byref(nnz), C.byref(sp)), "s3grl_features_info")
-        self.nnz, self.is_sparse = int(nnz.value), bool(sp.value)
+        self.nnz, self.is_sparse, self.is_packed = int(nnz.value), sp.value == 1, sp.value == 2
 
     @property
     def shape(self):

@@ -338,9 +338,13 @@ def test_sparse_and_dense_feature_paths(eng, F, density):
     G = eng.graph(A)
     L = eng.links(links)
     outs = {}
-    for mode in ("auto", "dense", "sparse"):
+    Xp = np.zeros((n, (F + 3) // 4 * 4), np.float32)
+    Xp[:, :F] = X
+    chunk_density = float((Xp.reshape(n, -1, 4) != 0).any(-1).mean())
+    for mode in ("auto", "dense", "sparse", "packed"):
         f = eng.features(X, mode)
         assert f.is_sparse == (mode == "sparse")
+        assert f.is_packed == (mode == "packed" or (mode == "auto" and chunk_density <= 0.5))
         res = eng.precompute(G, f, L, mode="pos_plus", num_hops=2, sign_k=3)
         np.testing.assert_array_equal(res.row_ptr.cpu().numpy(), ptr)
         assert rel_err(res.rows.cpu().numpy(), ref) < TOL
@@ -350,6 +354,43 @@ def test_sparse_and_dense_feature_paths(eng, F, density):
     raw = eng.precompute(G, eng.features(X, "dense").tensor, L, mode="pos_plus", num_hops=2, sign_k=3)
     import torch
     assert torch.equal(raw.rows, outs["dense"])
+    # packed rows skip only all-zero chunks: the sums are the dense kernel's sums bit for bit
+    assert torch.equal(outs["packed"], outs["dense"])
+    G.close()
+
+
+@pytest.mark.parametrize("K", [1, 2, 5, 8])
+@pytest.mark.parametrize("F", [3, 130, 515])
+def test_packed_rows_on_a_borrowed_strided_operand(eng, F, K):
+    """Packed copy built from a view whose row stride exceeds F (the columns between F and the
+    stride hold OTHER data, which must not leak in), every sign_k instantiation."""
+    import torch
+
+    g = load_extract("usair")
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    rng = np.random.default_rng(F + K)
+    ld = (F + 3) // 4 * 4 + 8
+    big = rng.standard_normal((n, ld)).astype(np.float32)
+    big[:, :F] *= rng.random((n, F)) < 0.2
+    Xd = torch.from_numpy(big).to(eng.device)
+    view = Xd[:, :F]
+    assert view.stride(0) == ld and view.data_ptr() % 16 == 0
+    links = g["links"][:10].T
+    kw = {"sign_k": K, "k_node_set_strategy": "intersection"}
+    ref, _, _ = oracle.collate_rows(
+        oracle.get_PoS_prepped_ds(links, 1, A, big[:, :F].astype(np.float64), 1, kw, dtype=np.float64), K)
+    G = eng.graph(A)
+    from s3grl_amd.engine import Features
+
+    outs = {}
+    for mode in ("dense", "packed"):
+        f = Features(eng, view, mode)
+        res = eng.precompute(G, f, eng.links(links), mode="pos", num_hops=1, sign_k=K)
+        assert rel_err(res.rows.cpu().numpy(), ref) < TOL
+        outs[mode] = res.rows
+        f.close()
+    assert torch.equal(outs["packed"], outs["dense"])
     G.close()
 
 
