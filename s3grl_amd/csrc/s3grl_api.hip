@@ -431,6 +431,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   S3GRL_TRY(arena_alloc(ctx, (size_t)std::max<int64_t>(tot_coef, 1) * 2 * K, &plan->c_coef, own));
   S3GRL_TRY(arena_alloc(ctx, (size_t)njobs, &plan->jobs, own));
   S3GRL_TRY(arena_alloc(ctx, (size_t)njobs * K * 2, &plan->job_z, own));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)std::max<int64_t>(njobs * K, 1), &plan->job_lim, own));
   S3GRL_TRY(arena_alloc(ctx, (size_t)tot_rows, &plan->row_nodes, own));
   S3GRL_TRY(arena_alloc(ctx, (size_t)L * kMaxLevels, &plan->lvl, own));
   S3GRL_TRY(record(ctx, 1));
@@ -438,7 +439,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
                          plus ? 1 : 0, cn_cap, (cfg->flags & S3GRL_FLAG_FULL_STATS) ? 1 : 0, K, rw_raw, rw_len, p_nodes,
                          plan->node_off,
                          plan->row_ptr, plan->job_off, coef_off, mirror_of, plan->c_ids,
-                         plan->c_coef, plan->jobs, plan->job_z, plan->row_nodes, plan->lvl, ds + 2,
+                         plan->c_coef, plan->jobs, plan->job_z, plan->job_lim, plan->row_nodes, plan->lvl, ds + 2,
                          ds + 3, ds + 4, smp));
   S3GRL_TRY(record(ctx, 2));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs + 2, ds + 2, 3 * 8, hipMemcpyDeviceToHost, ctx->stream));

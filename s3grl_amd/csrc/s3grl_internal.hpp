@@ -124,6 +124,8 @@ struct s3grl_plan {
   s3grl::Job* jobs = nullptr;    // [njobs]
   int64_t njobs = 0;
   float* job_z = nullptr;        // [njobs, K, 2] label column of operators 1..K
+  int32_t* job_lim = nullptr;    // [njobs, K] operator i+1 has no non-zero coefficient at list
+                                 // positions >= job_lim[j, i] (non-decreasing in i)
   float* c_coef = nullptr;       // [Σ_jobs n, K, 2]
   int64_t* row_nodes = nullptr;  // [ΣR]
   std::vector<void*> owned;      // everything above, for release
@@ -206,7 +208,8 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           int rw_len, const int32_t* p_nodes,
                           const int64_t* node_off, const int64_t* row_ptr, const int64_t* job_off,
                           const int64_t* coef_off, const int32_t* mirror_of, int32_t* c_ids,
-                          float* c_coef, Job* jobs, float* job_z, int64_t* row_nodes, int32_t* lvl,
+                          float* c_coef, Job* jobs, float* job_z, int32_t* job_lim, int64_t* row_nodes,
+                          int32_t* lvl,
                           int64_t* tot_edges, int64_t* tot_support, int64_t* tot_vol,
                           HopSampling smp = HopSampling{1.0, 0, 0});
 s3grl_status launch_dists(s3grl_context* ctx, const int64_t* node_off, const int32_t* lvl, int64_t L,

@@ -19,12 +19,14 @@
 // per subgraph node.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "s3grl_internal.hpp"
 #include "s3grl_gather_common.hpp"
 
 namespace s3grl {
 namespace {
+
 
 constexpr int kTile = 512;          // feature columns per tile = 128 chunks = 2 mask words
 constexpr int kWavesPerBlock = 4;
@@ -93,18 +95,20 @@ __global__ __launch_bounds__(256) void pk_fill_kernel(const float* __restrict__ 
 // One wavefront owns one row pair and one 512-column tile; see the file comment.
 //
 // Schedule.  At 0.7 KB per row the kernel is no longer bound by bytes but by how well the chain
-// id -> header -> chunk loads -> 2K FMAs per chunk overlaps inside a wavefront (116 VGPRs allow 4
-// waves per SIMD).  It is software-pipelined by hand over groups of U = 4 rows with two register
-// buffers: while the FMAs of group g run, the chunk loads of group g+1 are in flight and the
-// ids/headers of group g+2 are on their way through the scalar cache.  (Measured alternatives on
-// PubMed, K=3: no pipelining 17.8 ms; U=2 x 4 buffers 16.6 ms — more scalar instructions per row;
-// U=4 x 3 buffers 17.1 ms — 156 VGPRs, 3 waves per SIMD; this form 14.4 ms.)  For the compiler to wait
-// for "all but the newest 2U loads" (vmcnt) rather than for all of them, the loads must not sit
-// behind divergent branches: a lane whose mask bit is clear loads pk_data[0], a chunk of zeros
-// (one line, L1-resident), chosen with one v_cndmask on the wave-uniform mask — so every load
-// is unconditional and the steady-state loop body has no control flow at all.  The phases are
-// kept apart with scheduling barriers; left alone, the compiler serialises the scalar loads
-// (load, wait, use, load, wait, ...).
+// id -> header -> chunk loads -> multiply-adds overlaps inside a wavefront.  It is software-
+// pipelined by hand over groups of U = 4 rows with two register buffers: while the FMAs of group
+// g run, the chunk loads of group g+1 are in flight and the ids/headers of group g+2 are on
+// their way through the scalar cache.  For the compiler to wait for "all but the newest 2U
+// loads" (vmcnt) rather than for all of them, the loads must not sit behind divergent branches:
+// a lane whose mask bit is clear loads pk_data[0], a chunk of zeros (one line, L1-resident),
+// chosen with one v_cndmask on the wave-uniform mask — so every load is unconditional.  The
+// phases are kept apart with scheduling barriers; left alone, the compiler serialises the scalar
+// loads (load, wait, use, load, wait, ...).
+// Measured on PubMed PoS K=3 (164 000 links): no pipelining 17.8 ms; this form 14.4 ms; plus
+// skipping the operators that cannot reach a row 13.6 ms.  Deeper pipelines lost: U=2 x 4
+// buffers 16.6 ms (more scalar instructions per row), U=4 x 3 buffers 17.1 ms and U=4 x 5
+// buffers 19.0 ms (156-250 VGPRs: fewer waves per SIMD, and the unrolled body outgrows the
+// instruction cache).
 __device__ __forceinline__ uint32_t select_by_mask(uint64_t mask, uint32_t if_set) {
   uint32_t r;   // lane-wise: bit `lane` of the wave-uniform mask ? if_set : 0
   asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(if_set), "s"(mask));
@@ -115,8 +119,9 @@ template <int K>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
     const Job* __restrict__ jobs, int njobs, const int32_t* __restrict__ c_ids,
     const float* __restrict__ c_coef, const float* __restrict__ job_z,
-    const PackedHdr* __restrict__ hdr, const float4_t* __restrict__ data, int64_t N,
-    const float* __restrict__ X, int64_t ldx, int F, float* __restrict__ rows) {
+    const int32_t* __restrict__ job_lim, const PackedHdr* __restrict__ hdr,
+    const float4_t* __restrict__ data, int64_t N, const float* __restrict__ X, int64_t ldx, int F,
+    float* __restrict__ rows) {
   constexpr int CH = 2;
   constexpr int U = 4;   // rows per group
   const int lane = threadIdx.x & 63;
@@ -129,6 +134,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
   const float2* __restrict__ cf = reinterpret_cast<const float2*>(c_coef) + job.coef_off;
   const PackedHdr* __restrict__ th = hdr + (int64_t)blockIdx.y * N;
   const char* __restrict__ bytes = reinterpret_cast<const char*>(data);
+  // Operator i+1 has no non-zero coefficient at list positions >= lim[i] (a walk of i+1 steps
+  // stays within i+1 hops, and the list is hop-major), lim non-decreasing: its multiply-adds are
+  // skipped there.  On PubMed (3 hops, K = 3) four fifths of the rows only feed the last operator.
+  int lim[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) lim[i] = __builtin_amdgcn_readfirstlane(job_lim[(int64_t)jid * K + i]);
 
   int coff[CH];
   bool cok[CH];
@@ -166,9 +177,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto fma = [&](int g, const float4_t(&v)[U][CH]) {
+  auto fma_from = [&](auto first, int g, const float4_t(&v)[U][CH]) {   // operators first+1 .. K
+    constexpr int I0 = decltype(first)::value;
 #pragma unroll
-    for (int i = 0; i < K; ++i) {
+    for (int i = I0; i < K; ++i) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const float2 q = cf[(int64_t)i * cnt + g * U + u];
@@ -178,6 +190,23 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
           acc[i][1][c] += q.y * v[u][c];
         }
       }
+    }
+  };
+  // Operator dispatch: three code variants for K <= 3 (all operators / all but the first / the
+  // last one only).  For K >= 4 every variant costs ~16 more live VGPRs and a wave per SIMD, which
+  // measured slower than the multiply-adds it saves (PubMed K=5: 42 ms with variants, 25 ms
+  // without), so all operators are applied to every row there.
+  auto fma = [&](int g, const float4_t(&v)[U][CH]) {
+    [[maybe_unused]] const int lo = g * U;   // wave-uniform: scalar branches, no memory operation inside
+    if constexpr (K == 2) {
+      if (lo >= lim[0]) fma_from(std::integral_constant<int, 1>{}, g, v);
+      else fma_from(std::integral_constant<int, 0>{}, g, v);
+    } else if constexpr (K == 3) {
+      if (lo >= lim[1]) fma_from(std::integral_constant<int, 2>{}, g, v);
+      else if (lo >= lim[0]) fma_from(std::integral_constant<int, 1>{}, g, v);
+      else fma_from(std::integral_constant<int, 0>{}, g, v);
+    } else {
+      fma_from(std::integral_constant<int, 0>{}, g, v);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -190,7 +219,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
     load_hdrs(0, hA);
     issue(hA, vA);
     if (ngf > 1) load_hdrs(1, hB);
-    // steady state, no control flow inside: vA = group g in flight, hB = headers of group g+1
+    // steady state, no control flow inside besides the uniform operator dispatch:
+    // vA = group g in flight, hB = headers of group g+1
     for (; g + 3 < ngf; g += 2) {
       issue(hB, vB);
       load_hdrs(g + 2, hA);
@@ -233,7 +263,7 @@ s3grl_status launch_packed_k(s3grl_context* ctx, const s3grl_plan* p, const s3gr
                              float* rows) {
   const unsigned gx = (unsigned)((p->njobs + kWavesPerBlock - 1) / kWavesPerBlock);
   hipLaunchKernelGGL((gather_packed_kernel<K>), dim3(gx, (unsigned)f->tiles), dim3(kWavesPerBlock * 64),
-                     0, ctx->stream, p->jobs, (int)p->njobs, p->c_ids, p->c_coef, p->job_z,
+                     0, ctx->stream, p->jobs, (int)p->njobs, p->c_ids, p->c_coef, p->job_z, p->job_lim,
                      static_cast<const PackedHdr*>(f->pk_hdr), static_cast<const float4_t*>(f->pk_data),
                      f->N, f->dense, f->ld, (int)f->F, rows);
   S3GRL_HIP_TRY(hipGetLastError());

@@ -484,7 +484,8 @@ __global__ __launch_bounds__(T) void link_kernel(
     const int64_t* __restrict__ node_off, const int64_t* __restrict__ row_ptr,
     const int64_t* __restrict__ job_off, const int64_t* __restrict__ coef_off,
     const int32_t* __restrict__ mirror_of, int32_t* __restrict__ c_ids, float* __restrict__ c_coef,
-    Job* __restrict__ jobs, float* __restrict__ job_z, int64_t* __restrict__ row_nodes,
+    Job* __restrict__ jobs, float* __restrict__ job_z, int32_t* __restrict__ job_lim,
+    int64_t* __restrict__ row_nodes,
     int32_t* __restrict__ lvl_out, unsigned long long* __restrict__ tot_edges,
     unsigned long long* __restrict__ tot_support, unsigned long long* __restrict__ tot_vol,
     char* __restrict__ scratch, int64_t scratch_stride, unsigned long long* __restrict__ dbg,
@@ -744,6 +745,9 @@ __global__ __launch_bounds__(T) void link_kernel(
       const int i = tid >> 1, r = tid & 1;
       job_z[(jid * K + i) * 2 + r] = zbuf[(0 * K + i) * 2 + r] + zbuf[(1 * K + i) * 2 + r];
     }
+    // operator i+1 reaches the list prefix within i+1 hops of the row (the limits of the passes
+    // above): the gather skips its multiply-adds beyond that
+    if (tid < K) job_lim[jid * K + tid] = tid == K - 1 ? support : lvl_end[min(tid + 1 + row_hop, nlev - 1)];
     if (tid == 0) {
       Job j;
       j.coef_off = coff * K;
@@ -948,6 +952,7 @@ struct LinkArgs {
   float* c_coef;
   Job* jobs;
   float* job_z;
+  int32_t* job_lim;
   int64_t* row_nodes;
   int32_t* lvl;
   int64_t *tot_edges, *tot_support, *tot_vol;
@@ -974,7 +979,7 @@ s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t 
                      a.g->indices, W, a.links, a.class_list + (int64_t)cls * L, a.hops, a.plus,
                      a.cn_cap, a.full_stats, a.g->max_degree > kHubArmDegree ? 1 : 0, a.rw_raw,
                      a.rw_len, a.p_nodes, a.node_off, a.row_ptr, a.job_off, a.coef_off,
-                     a.mirror_of, a.c_ids, a.c_coef, a.jobs, a.job_z, a.row_nodes, a.lvl,
+                     a.mirror_of, a.c_ids, a.c_coef, a.jobs, a.job_z, a.job_lim, a.row_nodes, a.lvl,
                      reinterpret_cast<unsigned long long*>(a.tot_edges),
                      reinterpret_cast<unsigned long long*>(a.tot_support),
                      reinterpret_cast<unsigned long long*>(a.tot_vol), a.scratch, a.scratch_stride,
@@ -1033,7 +1038,8 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           int rw_len, const int32_t* p_nodes,
                           const int64_t* node_off, const int64_t* row_ptr, const int64_t* job_off,
                           const int64_t* coef_off, const int32_t* mirror_of, int32_t* c_ids,
-                          float* c_coef, Job* jobs, float* job_z, int64_t* row_nodes, int32_t* lvl,
+                          float* c_coef, Job* jobs, float* job_z, int32_t* job_lim, int64_t* row_nodes,
+                          int32_t* lvl,
                           int64_t* tot_edges, int64_t* tot_support, int64_t* tot_vol,
                           HopSampling smp) {
   if (L == 0) return S3GRL_OK;
@@ -1050,7 +1056,7 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
   }
   LinkArgs a{g, links, class_list, hops, plus, cn_cap, full_stats, rw_raw, rw_len, p_nodes, node_off,
              row_ptr,
-             job_off, coef_off, mirror_of, c_ids, c_coef, jobs, job_z, row_nodes, lvl, tot_edges,
+             job_off, coef_off, mirror_of, c_ids, c_coef, jobs, job_z, job_lim, row_nodes, lvl, tot_edges,
              tot_support, tot_vol, scratch, scratch_stride,
              getenv("S3GRL_DEBUG_STAMPS") ? reinterpret_cast<unsigned long long*>(ctx->d_scalars + 16) : nullptr,
              smp};

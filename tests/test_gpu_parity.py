@@ -354,8 +354,9 @@ def test_sparse_and_dense_feature_paths(eng, F, density):
     raw = eng.precompute(G, eng.features(X, "dense").tensor, L, mode="pos_plus", num_hops=2, sign_k=3)
     import torch
     assert torch.equal(raw.rows, outs["dense"])
-    # packed rows skip only all-zero chunks: the sums are the dense kernel's sums bit for bit
-    assert torch.equal(outs["packed"], outs["dense"])
+    # packed rows skip only all-zero chunks and zero coefficients: the same sums as the dense
+    # kernel's, up to where the compiler fuses a multiply-add (1 ulp)
+    assert rel_err(outs["packed"].cpu().numpy(), outs["dense"].cpu().numpy()) < 1e-6
     G.close()
 
 
@@ -390,7 +391,7 @@ def test_packed_rows_on_a_borrowed_strided_operand(eng, F, K):
         assert rel_err(res.rows.cpu().numpy(), ref) < TOL
         outs[mode] = res.rows
         f.close()
-    assert torch.equal(outs["packed"], outs["dense"])
+    assert rel_err(outs["packed"].cpu().numpy(), outs["dense"].cpu().numpy()) < 1e-6
     G.close()
 
 
