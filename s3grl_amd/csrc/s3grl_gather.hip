@@ -1,4 +1,5 @@
-// Feature half of PoS / PoS Plus on gfx950: the dominant, HBM/Infinity-Cache-bound kernel.
+// Feature half of PoS / PoS Plus on gfx950, dense-row flavour (X without exploitable zeros; the
+// packed-row flavour for sparse X is s3grl_packed.hip): bound by the L2 <-> Infinity-Cache fabric.
 //
 //   rows[r, i, 1 + f] = Σ_w  Â^i[row r, w] · X[w, f]        i = 1..K, both rows of a pair
 //   rows[r, 0, :]     = [z_r | X[node_r, :]]
@@ -8,9 +9,7 @@
 // :240,258) and its two dense copies of X_S (utils.py:83, tuned_SIGN.py:179).
 //
 // One wavefront owns one row pair.  The node-id list and the [K][support] coefficient rows are
-// wave-uniform, so they
-// are
-// is read through the scalar cache into SGPRs; each lane owns 4·CH feature columns and keeps
+// wave-uniform, so they are read through the scalar cache into SGPRs; each lane owns 4·CH feature columns and keeps
 // 2K·4·CH fp32 accumulators in VGPRs; every X row of the support is fetched ONCE per pair with
 // 16-byte loads (64 lanes × 16 B = one 1 KiB wave-instruction per 256 columns), UNROLL rows
 // in flight per wave.  No LDS, no MFMA: 2·2K flop per 4 B of X.
