@@ -355,10 +355,20 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
     S3GRL_TRY(launch_find_mirrors(ctx, plan->links, L, g->num_nodes, keys, vals, slots, partner,
                                   mirror_of, ds + 7));
   }
+  // count_kernel leaves every link's node list in HBM for link_kernel (one slot per link: lists
+  // longer than the slot are walked again there).  4096 entries cover 97 % of PubMed's 3-hop
+  // subgraphs; the slot shrinks when L slots would pass 6 GB.
+  S3GRL_TRY(arena_alloc(ctx, (size_t)L * kMaxLevels, &plan->lvl, own));
+  int32_t* stash = nullptr;
+  int slot = 4096;
+  if (const char* e = getenv("S3GRL_STASH_SLOT")) slot = std::max(0, atoi(e));   // test hook; 0 = off
+  while (slot > 256 && (int64_t)L * slot * 4 > ((int64_t)6 << 30)) slot >>= 1;
+  if (slot > 0 && (int64_t)L * slot * 4 <= ((int64_t)6 << 30))
+    S3GRL_TRY(arena_alloc(ctx, (size_t)L * slot, &stash, tr));
   S3GRL_TRY(launch_count(ctx, g, plan->links, L, cfg->num_hops, plus ? 1 : 0, K, rw_raw, rw_len,
                          partner, mirror_of,
                          plan->n_nodes, p_nodes, n_rows, n_jobs, lvl_max,
-                         reinterpret_cast<int32_t*>(ds), ds + 6, smp));
+                         reinterpret_cast<int32_t*>(ds), ds + 6, smp, stash, slot, plan->lvl));
   if (fold) S3GRL_TRY(launch_mirror_rows(ctx, partner, L, n_rows));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, plan->n_nodes, L, plan->node_off, scan_ws));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_rows, L, plan->row_ptr, scan_ws));
@@ -433,14 +443,13 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   S3GRL_TRY(arena_alloc(ctx, (size_t)njobs * K * 2, &plan->job_z, own));
   S3GRL_TRY(arena_alloc(ctx, (size_t)std::max<int64_t>(njobs * K, 1), &plan->job_lim, own));
   S3GRL_TRY(arena_alloc(ctx, (size_t)tot_rows, &plan->row_nodes, own));
-  S3GRL_TRY(arena_alloc(ctx, (size_t)L * kMaxLevels, &plan->lvl, own));
   S3GRL_TRY(record(ctx, 1));
   S3GRL_TRY(launch_links(ctx, g, plan->links, L, class_list, class_count_host, cfg->num_hops,
                          plus ? 1 : 0, cn_cap, (cfg->flags & S3GRL_FLAG_FULL_STATS) ? 1 : 0, K, rw_raw, rw_len, p_nodes,
                          plan->node_off,
                          plan->row_ptr, plan->job_off, coef_off, mirror_of, plan->c_ids,
                          plan->c_coef, plan->jobs, plan->job_z, plan->job_lim, plan->row_nodes, plan->lvl, ds + 2,
-                         ds + 3, ds + 4, smp));
+                         ds + 3, ds + 4, smp, stash, slot));
   S3GRL_TRY(record(ctx, 2));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs + 2, ds + 2, 3 * 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));

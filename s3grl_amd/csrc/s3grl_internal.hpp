@@ -183,7 +183,8 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           int hops, int plus, int K, const int32_t* rw_raw, int rw_len,
                           const int32_t* partner, const int32_t* mirror_of, int32_t* n_nodes, int32_t* p_nodes,
                           int32_t* n_rows, int32_t* n_jobs, int32_t* lvl_max, int32_t* err_flag,
-                          int64_t* tot_nodes_alg, HopSampling smp = HopSampling{1.0, 0, 0});
+                          int64_t* tot_nodes_alg, HopSampling smp = HopSampling{1.0, 0, 0},
+                          int32_t* stash = nullptr, int slot = 0, int32_t* lvl_stash = nullptr);
 int num_class_lists();
 s3grl_status launch_random_walks(s3grl_context* ctx, const s3grl_graph* g, int m, int M,
                                  uint32_t seed, int32_t* raw);
@@ -211,7 +212,8 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           float* c_coef, Job* jobs, float* job_z, int32_t* job_lim, int64_t* row_nodes,
                           int32_t* lvl,
                           int64_t* tot_edges, int64_t* tot_support, int64_t* tot_vol,
-                          HopSampling smp = HopSampling{1.0, 0, 0});
+                          HopSampling smp = HopSampling{1.0, 0, 0}, const int32_t* stash = nullptr,
+                          int slot = 0);
 s3grl_status launch_dists(s3grl_context* ctx, const int64_t* node_off, const int32_t* lvl, int64_t L,
                           int8_t* dists);
 // gather.hip

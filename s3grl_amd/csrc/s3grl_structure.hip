@@ -73,7 +73,8 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
     const int32_t* __restrict__ rw_raw, int rw_len, const int32_t* __restrict__ partner, const int32_t* __restrict__ mirror_of,
     int32_t* __restrict__ n_nodes, int32_t* __restrict__ p_nodes, int32_t* __restrict__ n_rows,
     int32_t* __restrict__ n_jobs, int32_t* __restrict__ lvl_max, int32_t* __restrict__ err_flag,
-    unsigned long long* __restrict__ tot_nodes_alg, HopSampling smp) {
+    unsigned long long* __restrict__ tot_nodes_alg, HopSampling smp, int32_t* __restrict__ stash,
+    int slot, int32_t* __restrict__ lvl_stash) {
   extern __shared__ uint32_t smem[];
   uint32_t* vis = smem;
   uint32_t* cur = smem + W;
@@ -110,6 +111,12 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
   const int src = (int)s64, dst = (int)d64;
   int* hub = hubs ? sh + 8 : nullptr;
   int32_t* list = reinterpret_cast<int32_t*>(sh + 8 + kHubWords);   // frontier nodes of the levels < hops
+  // The node list found here is left in HBM for link_kernel (hop 1 onwards, `slot` entries per
+  // link, level ends in lvl_stash): it then rebuilds its LDS state from the list instead of
+  // repeating the BFS.  A list longer than the slot is simply not used (link_kernel walks again).
+  int32_t* stash_l = stash ? stash + (int64_t)l * slot : nullptr;
+  int32_t* lvl_l = stash ? lvl_stash + (int64_t)l * kMaxLevels : nullptr;
+  if (lvl_l && tid == 0) lvl_l[0] = 2;
   for (int t = tid; t < W; t += kBlock) {
     vis[t] = 0;
     cur[t] = 0;
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
   // The frontier is a node list (G lanes per node: no serial row walks) as long as the levels
   // below `hops` fit kCountList entries; beyond that it degrades to a bitmap walked one thread
   // per word.  cum_a / cum_b: nodes within K-1 / K hops (P for a row at hop 0 / hop 1).
-  int n = 2, cum_a = 2, cum_b = 2, f0 = 0, f1 = 2, biggest = 2;
+  int n = 2, cum_a = 2, cum_b = 2, f0 = 0, f1 = 2, biggest = 2, nlev_seen = 1;
   bool use_list = true;
   if (rw_raw) hops = 1;  // ScaLed: the "hop" is what the cached random walks of src and dst visited
   for (int d = 1; d <= hops; ++d) {
@@ -191,17 +198,27 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
       }
       for (int t = w0; t < w1; ++t) mem[t] |= nxt[t];
     }
-    if (d < hops) {  // the new level is the next frontier
-      if (use_list && f1 + added <= kCountList) {
-        for (int t = w0; t < w1; ++t) {
-          uint32_t w = nxt[t];
-          nxt[t] = 0;
-          while (w) {
-            const int b = __ffs(w) - 1;
-            w &= w - 1;
-            list[pos++] = t * 32 + b;
-          }
+    // enumerate the new level in ascending id order: into the LDS frontier list (levels below
+    // `hops`, while they fit) and into the HBM stash
+    const bool to_list = d < hops && use_list && f1 + added <= kCountList;
+    if (to_list || stash_l) {
+      int lp = pos;
+      int sp = n - 2 + (pos - f1);
+      for (int t = w0; t < w1; ++t) {
+        uint32_t w = nxt[t];
+        while (w) {
+          const int b = __ffs(w) - 1;
+          w &= w - 1;
+          if (to_list) list[lp++] = t * 32 + b;
+          if (stash_l && sp < slot) stash_l[sp] = t * 32 + b;
+          ++sp;
         }
+      }
+    }
+    if (lvl_l && tid == 0) lvl_l[d] = n + added;
+    if (d < hops) {  // the new level is the next frontier
+      if (to_list) {
+        for (int t = w0; t < w1; ++t) nxt[t] = 0;
         f0 = f1;
         f1 += added;
       } else {
@@ -214,6 +231,7 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
       __syncthreads();
     }
     n += added;
+    nlev_seen = d + 1;
     biggest = max(biggest, added);
     if (d <= K - 1) cum_a = n;
     if (d <= K) cum_b = n;
@@ -224,6 +242,7 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
   if (plus && wave_id() == 0)
     R = 2 + common_neighbours(indptr, indices, [&](int x) { return test_bit(member, x); }, src, dst, nullptr);
   if (tid == 0) {
+    if (lvl_l) lvl_l[kMaxLevels - 1] = nlev_seen;   // levels 0 .. nlev_seen-1 are complete
     n_nodes[l] = n;
     p_nodes[l] = R > 2 ? cum_b : cum_a;
     n_rows[l] = R;
@@ -489,7 +508,7 @@ __global__ __launch_bounds__(T) void link_kernel(
     int32_t* __restrict__ lvl_out, unsigned long long* __restrict__ tot_edges,
     unsigned long long* __restrict__ tot_support, unsigned long long* __restrict__ tot_vol,
     char* __restrict__ scratch, int64_t scratch_stride, unsigned long long* __restrict__ dbg,
-    HopSampling smp) {
+    HopSampling smp, const int32_t* __restrict__ stash, int slot) {
   extern __shared__ uint32_t smem[];
   // diagnostic only (S3GRL_DEBUG_STAMPS): cycles per phase, summed over workgroups; the extra
   // barriers change the timing of the build they run in — read shares, not totals
@@ -549,12 +568,46 @@ __global__ __launch_bounds__(T) void link_kernel(
   // ---- BFS on the unmasked graph (reference utils.py:53-74) --------------------------------
   int nlev;
   int n;
-  if constexpr (HS)
+  if (stash && n_alloc - 2 <= slot) {
+    // count_kernel left this link's node list (hop-major, ascending id inside a hop) and its
+    // level ends in HBM: rebuild the LDS state from them instead of walking the graph again
+    const int32_t* __restrict__ st = stash + (int64_t)l * slot;
+    const int32_t* lv = lvl_out + (int64_t)l * kMaxLevels;   // rewritten below, after the barriers
+    if constexpr (HS) {
+      for (uint32_t t = tid; t <= hmask; t += T) hkeys[t] = -1;
+    } else {
+      for (int t = tid; t < W; t += T) {
+        vis[t] = 0;
+        inP[t] = 0;
+      }
+    }
+    nlev = lv[kMaxLevels - 1];
+    if (tid < nlev) lvl_end[tid] = lv[tid];
+    if (tid == 0) {
+      list[0] = min(src, dst);
+      list[1] = max(src, dst);
+      if (hub) hub[0] = 0;
+    }
+    __syncthreads();
+    for (int t = tid; t < n_alloc; t += T) {
+      const int v = t < 2 ? list[t] : st[t - 2];
+      if (t >= 2) list[t] = v;
+      if constexpr (HS) {
+        hs_insert(hkeys, hmask, v);
+        hvals[hs_find(hkeys, hmask, v)] = t;
+      } else {
+        atomicOr(&vis[v >> 5], 1u << (v & 31));
+      }
+    }
+    __syncthreads();
+    n = n_alloc;
+  } else if constexpr (HS) {
     n = bfs_hash<T, G>(indptr, indices, src, dst, hops, hkeys, hvals, hmask, list, n_alloc, lvl_end, sh + 31,
                        hub, nlev, rw_raw, rw_len);
-  else
+  } else {
     n = bfs_list<T, G>(indptr, indices, W, src, dst, hops, vis, inP, list, n_alloc, lvl_end, sh, hub, nlev,
                        rw_raw, rw_len, smp);
+  }
   // set queries of the passes below: membership in S; index into the P-state arrays (+ is it in P);
   // the P-state index of list entry t (= node v)
   auto in_s = [&](int u) -> bool {
@@ -843,7 +896,8 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           int hops, int plus, int K, const int32_t* rw_raw, int rw_len,
                           const int32_t* partner, const int32_t* mirror_of, int32_t* n_nodes, int32_t* p_nodes,
                           int32_t* n_rows, int32_t* n_jobs, int32_t* lvl_max, int32_t* err_flag,
-                          int64_t* tot_nodes_alg, HopSampling smp) {
+                          int64_t* tot_nodes_alg, HopSampling smp, int32_t* stash, int slot,
+                          int32_t* lvl_stash) {
   if (L == 0) return S3GRL_OK;
   const int W = words_for(g->num_nodes);
   const size_t lds = (size_t)(3 * W + 8 + kHubWords + kCountList + (hop_sampling_on(smp) ? W : 0)) * 4;
@@ -859,7 +913,7 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
                      g->indices, (int)g->num_nodes, W, links, hops, plus, K,
                      g->max_degree > kHubArmDegree ? 1 : 0, rw_raw, rw_len, partner, mirror_of, n_nodes,
                      p_nodes, n_rows, n_jobs, lvl_max, err_flag,
-                     reinterpret_cast<unsigned long long*>(tot_nodes_alg), smp);
+                     reinterpret_cast<unsigned long long*>(tot_nodes_alg), smp, stash, slot, lvl_stash);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -960,6 +1014,8 @@ struct LinkArgs {
   int64_t scratch_stride;
   unsigned long long* dbg;
   HopSampling smp;
+  const int32_t* stash;
+  int slot;
 };
 
 template <int T, int K, int G, bool GS, bool HS>
@@ -983,7 +1039,7 @@ s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t 
                      reinterpret_cast<unsigned long long*>(a.tot_edges),
                      reinterpret_cast<unsigned long long*>(a.tot_support),
                      reinterpret_cast<unsigned long long*>(a.tot_vol), a.scratch, a.scratch_stride,
-                     a.dbg, a.smp);
+                     a.dbg, a.smp, a.stash, a.slot);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -1041,7 +1097,7 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           float* c_coef, Job* jobs, float* job_z, int32_t* job_lim, int64_t* row_nodes,
                           int32_t* lvl,
                           int64_t* tot_edges, int64_t* tot_support, int64_t* tot_vol,
-                          HopSampling smp) {
+                          HopSampling smp, const int32_t* stash, int slot) {
   if (L == 0) return S3GRL_OK;
   // links too large for LDS keep their lists in HBM scratch: one 256-byte aligned slice each
   Transient scratch_owner{ctx, {}};
@@ -1059,7 +1115,7 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
              job_off, coef_off, mirror_of, c_ids, c_coef, jobs, job_z, job_lim, row_nodes, lvl, tot_edges,
              tot_support, tot_vol, scratch, scratch_stride,
              getenv("S3GRL_DEBUG_STAMPS") ? reinterpret_cast<unsigned long long*>(ctx->d_scalars + 16) : nullptr,
-             smp};
+             smp, stash, slot};
   switch (K) {
     case 1: return launch_links_k<1>(ctx, a, L, class_count_host);
     case 2: return launch_links_k<2>(ctx, a, L, class_count_host);
