@@ -55,8 +55,18 @@ def centre_pool(h, row_ptr, k_heuristic=0, k_pool_strategy=""):
         raise RuntimeError("centre_pool runs on the MI355X only; there is no CPU fallback")
     if h.dtype != torch.float32 or row_ptr.dtype != torch.int64:
         raise ValueError("h must be float32 and row_ptr int64")
-    if k_heuristic and k_pool_strategy not in ("mean", "sum"):
+    if k_heuristic and k_pool_strategy not in ("mean", "sum", "concat"):
         raise NotImplementedError(f"Check pool strat: {k_pool_strategy}")   # models.py:335
+    if k_heuristic and k_pool_strategy == "concat":
+        # models.py:363-367: every link must carry exactly k_heuristic rows after its two centre
+        # rows (the reference's reshape fails otherwise); they are appended side by side
+        B, H, R = row_ptr.numel() - 1, h.shape[1], 2 + int(k_heuristic)
+        if h.shape[0] != B * R:
+            raise RuntimeError(f"shape '[{B}, {H * k_heuristic}]' is invalid: 'concat' pooling needs "
+                               f"exactly {k_heuristic} common-neighbour rows per link")
+        h_a = _CentrePool.apply(h, row_ptr, 0)
+        h_k = h.view(B, R, H)[:, 2:, :].reshape(B, H * int(k_heuristic))
+        return torch.cat([h_a, h_k], dim=-1)
     mode = _MODES[k_pool_strategy] if k_heuristic else 0
     return _CentrePool.apply(h, row_ptr, mode)
 

@@ -436,7 +436,19 @@ def test_centre_pool_forward_backward(eng, H, strategy):
                                     torch.tensor(counts, device=eng.device))
     assert torch.equal(row_ptr_from_batch(batch), rp)
     with pytest.raises(NotImplementedError):
-        centre_pool(ht, rp, k_heuristic=1, k_pool_strategy="concat")
+        centre_pool(ht, rp, k_heuristic=1, k_pool_strategy="max")
+    with pytest.raises(RuntimeError):                      # ragged rows: the reference's reshape fails too
+        centre_pool(ht, rp, k_heuristic=50, k_pool_strategy="concat")
+    # 'concat' (models.py:363-367): exactly k_heuristic rows after the two centre rows of every link
+    k, B = 3, 17
+    hc = rng.standard_normal((B * (2 + k), H)).astype(np.float32)
+    rpc = torch.arange(0, B * (2 + k) + 1, 2 + k, dtype=torch.int64, device=eng.device)
+    hct = torch.from_numpy(hc).to(eng.device).requires_grad_(True)
+    got = centre_pool(hct, rpc, k_heuristic=k, k_pool_strategy="concat")
+    ref = oracle.centre_pool(hc, rpc.cpu().numpy(), k_heuristic=k, k_pool_strategy="concat")
+    assert got.shape == (B, H * (1 + k)) and np.allclose(got.detach().cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+    got.sum().backward()
+    assert hct.grad is not None and torch.isfinite(hct.grad).all()
 
 
 def test_reversed_duplicates_are_folded_bit_exactly(eng):
