@@ -658,7 +658,10 @@ __global__ __launch_bounds__(T) void link_kernel(
   walk_rows<T, G, 2>(
       0, p, list, indptr, indices, hub,
       [&](RowAcc& a, int v, int u, bool valid) {
-        a.n += (valid && in_s(u) && !((v == src && u == dst) || (v == dst && u == src))) ? 1 : 0;
+        // the target link is masked (utils.py:79-80): one compare per neighbour against the
+        // row's partner (-1 for every row but src and dst; hoisted out of the neighbour loop)
+        const int mp = v == src ? dst : (v == dst ? src : -1);
+        a.n += (valid && in_s(u) && u != mp) ? 1 : 0;
       },
       [&](RowAcc& a, int t, int v) {
         dinvP[p_index_of_row(t, v)] = a.n > 0 ? 1.0f / sqrtf((float)a.n) : 0.0f;
@@ -729,7 +732,8 @@ __global__ __launch_bounds__(T) void link_kernel(
               sv = s_in[min(r, p - 1)];
               on = valid && ((wp >> (u & 31)) & 1u);
             }
-            on = on && !((v == src && u == dst) || (v == dst && u == src));
+            const int mp = v == src ? dst : (v == dst ? src : -1);
+            on = on && u != mp;
             a.x += on ? sv.x : 0.f;
             a.y += on ? sv.y : 0.f;
           },
@@ -773,7 +777,8 @@ __global__ __launch_bounds__(T) void link_kernel(
               member = valid && (wv & bit);
               on = member && (wp & bit);
             }
-            const bool masked = (v == src && u == dst) || (v == dst && u == src);
+            const int mp = v == src ? dst : (v == dst ? src : -1);
+            const bool masked = u == mp;
             member = member && !masked;
             on = on && !masked;
             a.n += member ? 1 : 0;
