@@ -19,7 +19,7 @@
 namespace s3grl {
 namespace {
 
-constexpr int kWavesPerBlock = 4;
+constexpr int kWavesPerBlock = 4;   // fabric-bound: 1 wave per workgroup measured the same (24.1 vs 23.5 ms)
 constexpr int kUnroll = 8;  // rows of X in flight per wavefront (8: 23.1 ms, 4: 23.6 ms on PubMed)
 
 template <int K, int CH>

@@ -29,7 +29,10 @@ namespace {
 
 
 constexpr int kTile = 512;          // feature columns per tile = 128 chunks = 2 mask words
-constexpr int kWavesPerBlock = 4;
+// one wavefront per workgroup: the jobs of a workgroup differ in length by an order of magnitude
+// (positive vs negative links), and a workgroup holds its registers until its longest job is
+// done.  Measured on PubMed K=3: 8 waves per workgroup 16.9 ms, 4: 13.6 ms, 2: 11.1 ms, 1: 10.7 ms.
+constexpr int kWavesPerBlock = 1;
 
 __device__ __forceinline__ int below(uint64_t m) {   // set bits of m below this lane
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
