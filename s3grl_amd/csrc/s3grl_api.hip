@@ -418,6 +418,12 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   plan->stats.total_rows = tot_rows;
   plan->stats.num_row_pairs = njobs;
   plan->njobs = njobs;
+  {
+    int32_t* hist;
+    S3GRL_TRY(arena_alloc(ctx, (size_t)256, &hist, tr));
+    S3GRL_TRY(arena_alloc(ctx, (size_t)std::max<int64_t>(njobs, 1), &plan->job_order, own));
+    S3GRL_TRY(launch_job_order(ctx, plan->n_nodes, n_jobs, plan->job_off, L, hist, plan->job_order));
+  }
 
   // coefficient lists: one per row pair, sized by the link's node count
   const int64_t* coef_off = nullptr;          // PoS: one pair per link, list at node_off[link]

@@ -124,6 +124,7 @@ struct s3grl_plan {
   s3grl::Job* jobs = nullptr;    // [njobs]
   int64_t njobs = 0;
   float* job_z = nullptr;        // [njobs, K, 2] label column of operators 1..K
+  int32_t* job_order = nullptr;  // [njobs] the order the gather starts its jobs in (largest first)
   int32_t* job_lim = nullptr;    // [njobs, K] operator i+1 has no non-zero coefficient at list
                                  // positions >= job_lim[j, i] (non-decreasing in i)
   float* c_coef = nullptr;       // [Σ_jobs n, K, 2]
@@ -196,6 +197,8 @@ s3grl_status launch_find_mirrors(s3grl_context* ctx, const int64_t* links, int64
                                  int32_t* mirror_of, int64_t* n_mirrored);
 s3grl_status launch_mirror_rows(s3grl_context* ctx, const int32_t* partner, int64_t L,
                                 int32_t* n_rows);
+s3grl_status launch_job_order(s3grl_context* ctx, const int32_t* n_nodes, const int32_t* n_jobs,
+                              const int64_t* job_off, int64_t L, int32_t* hist, int32_t* job_order);
 int64_t scan_workspace_elems(int64_t n);
 s3grl_status launch_scan_i32_to_i64(s3grl_context* ctx, const int32_t* in, int64_t n, int64_t* out,
                                     int64_t* workspace);

@@ -122,14 +122,16 @@ template <int K>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
     const Job* __restrict__ jobs, int njobs, const int32_t* __restrict__ c_ids,
     const float* __restrict__ c_coef, const float* __restrict__ job_z,
-    const int32_t* __restrict__ job_lim, const PackedHdr* __restrict__ hdr,
+    const int32_t* __restrict__ job_lim, const int32_t* __restrict__ job_order,
+    const PackedHdr* __restrict__ hdr,
     const float4_t* __restrict__ data, int64_t N, const float* __restrict__ X, int64_t ldx, int F,
     float* __restrict__ rows) {
   constexpr int CH = 2;
   constexpr int U = 4;   // rows per group
   const int lane = threadIdx.x & 63;
-  const int jid = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
-  if (jid >= njobs) return;
+  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+  if (wid >= njobs) return;
+  const int jid = __builtin_amdgcn_readfirstlane(job_order[wid]);   // longest jobs start first
   const int col0 = blockIdx.y * kTile;
   const Job job = jobs[jid];
   const int cnt = __builtin_amdgcn_readfirstlane(job.support);
@@ -266,7 +268,7 @@ s3grl_status launch_packed_k(s3grl_context* ctx, const s3grl_plan* p, const s3gr
                              float* rows) {
   const unsigned gx = (unsigned)((p->njobs + kWavesPerBlock - 1) / kWavesPerBlock);
   hipLaunchKernelGGL((gather_packed_kernel<K>), dim3(gx, (unsigned)f->tiles), dim3(kWavesPerBlock * 64),
-                     0, ctx->stream, p->jobs, (int)p->njobs, p->c_ids, p->c_coef, p->job_z, p->job_lim,
+                     0, ctx->stream, p->jobs, (int)p->njobs, p->c_ids, p->c_coef, p->job_z, p->job_lim, p->job_order,
                      static_cast<const PackedHdr*>(f->pk_hdr), static_cast<const float4_t*>(f->pk_data),
                      f->N, f->dense, f->ld, (int)f->F, rows);
   S3GRL_HIP_TRY(hipGetLastError());

@@ -923,6 +923,102 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
   return S3GRL_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Gather order: one wavefront per job, and the jobs differ in length by two orders of magnitude.
+// Started in list order, a long job that begins late is the tail of the launch; started longest
+// first (LPT) the tail is made of short ones (PubMed: 10.7 -> 9.7 ms).  A counting sort of the
+// jobs by their link's node count in kOrderBuckets descending buckets; inside a bucket the order
+// is whatever the atomics give (results do not depend on it).
+constexpr int kOrderBuckets = 256;
+constexpr int kOrderShift = 5;   // 32 nodes per bucket, everything >= 8160 nodes in the first
+
+__device__ __forceinline__ int order_bucket(int n) {
+  return kOrderBuckets - 1 - min(n >> kOrderShift, kOrderBuckets - 1);
+}
+
+// Both passes keep a workgroup-local histogram in LDS and touch the global one once per
+// (workgroup, bucket): 164 000 global atomics on 256 counters cost 0.2 ms per pass otherwise.
+constexpr int kOrderThreads = 1024;
+
+__global__ __launch_bounds__(kOrderThreads) void order_hist_kernel(
+    const int32_t* __restrict__ n_nodes, const int32_t* __restrict__ n_jobs, int64_t L, int64_t per_block,
+    int32_t* __restrict__ hist) {
+  __shared__ int h[kOrderBuckets];
+  const int t = threadIdx.x;
+  if (t < kOrderBuckets) h[t] = 0;
+  __syncthreads();
+  const int64_t l0 = (int64_t)blockIdx.x * per_block, l1 = min(l0 + per_block, L);
+  for (int64_t l = l0 + t; l < l1; l += kOrderThreads) {
+    const int nj = n_jobs[l];
+    if (nj > 0) atomicAdd(&h[order_bucket(n_nodes[l])], nj);
+  }
+  __syncthreads();
+  if (t < kOrderBuckets && h[t]) atomicAdd(&hist[t], h[t]);
+}
+
+__global__ void order_scan_kernel(int32_t* __restrict__ hist /* in: counts, out: cursors */) {
+  __shared__ int sh[kOrderBuckets];
+  const int t = threadIdx.x;
+  sh[t] = hist[t];
+  __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int b = 0; b < kOrderBuckets; ++b) {
+      const int c = sh[b];
+      sh[b] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  hist[t] = sh[t];
+}
+
+__global__ __launch_bounds__(kOrderThreads) void order_fill_kernel(
+    const int32_t* __restrict__ n_nodes, const int32_t* __restrict__ n_jobs,
+    const int64_t* __restrict__ job_off, int64_t L, int64_t per_block, int32_t* __restrict__ cursor,
+    int32_t* __restrict__ job_order) {
+  __shared__ int h[kOrderBuckets];     // this workgroup's jobs per bucket, then its running cursor
+  __shared__ int base[kOrderBuckets];  // where its share of the bucket starts
+  const int t = threadIdx.x;
+  if (t < kOrderBuckets) h[t] = 0;
+  __syncthreads();
+  const int64_t l0 = (int64_t)blockIdx.x * per_block, l1 = min(l0 + per_block, L);
+  for (int64_t l = l0 + t; l < l1; l += kOrderThreads) {
+    const int nj = n_jobs[l];
+    if (nj > 0) atomicAdd(&h[order_bucket(n_nodes[l])], nj);
+  }
+  __syncthreads();
+  if (t < kOrderBuckets) {
+    base[t] = h[t] ? atomicAdd(&cursor[t], h[t]) : 0;
+    h[t] = 0;
+  }
+  __syncthreads();
+  for (int64_t l = l0 + t; l < l1; l += kOrderThreads) {
+    const int nj = n_jobs[l];
+    if (nj <= 0) continue;
+    const int b = order_bucket(n_nodes[l]);
+    const int at = base[b] + atomicAdd(&h[b], nj);
+    const int j0 = (int)job_off[l];
+    for (int j = 0; j < nj; ++j) job_order[at + j] = j0 + j;
+  }
+}
+
+s3grl_status launch_job_order(s3grl_context* ctx, const int32_t* n_nodes, const int32_t* n_jobs,
+                              const int64_t* job_off, int64_t L, int32_t* hist /* [256] scratch */,
+                              int32_t* job_order) {
+  if (L == 0) return S3GRL_OK;
+  S3GRL_HIP_TRY(hipMemsetAsync(hist, 0, kOrderBuckets * sizeof(int32_t), ctx->stream));
+  const int64_t per_block = std::max<int64_t>((L + 255) / 256, 4 * kOrderThreads);
+  const unsigned grid = (unsigned)((L + per_block - 1) / per_block);
+  hipLaunchKernelGGL(order_hist_kernel, dim3(grid), dim3(kOrderThreads), 0, ctx->stream, n_nodes, n_jobs, L,
+                     per_block, hist);
+  hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(kOrderBuckets), 0, ctx->stream, hist);
+  hipLaunchKernelGGL(order_fill_kernel, dim3(grid), dim3(kOrderThreads), 0, ctx->stream, n_nodes, n_jobs, job_off,
+                     L, per_block, hist, job_order);
+  S3GRL_HIP_TRY(hipGetLastError());
+  return S3GRL_OK;
+}
+
 int64_t scan_workspace_elems(int64_t n) { return (n + kScanTile - 1) / kScanTile + 1; }
 
 s3grl_status launch_scan_i32_to_i64(s3grl_context* ctx, const int32_t* in, int64_t n, int64_t* out,
