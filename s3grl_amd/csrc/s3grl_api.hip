@@ -158,6 +158,13 @@ s3grl_status s3grl_context_destroy(s3grl_context* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& e : ctx->ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto& st : ctx->side)
+    if (st) {
+      (void)hipStreamSynchronize(st);
+      (void)hipStreamDestroy(st);
+    }
+  for (auto& e : ctx->side_ev)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
   if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
   delete ctx;

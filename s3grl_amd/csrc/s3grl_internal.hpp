@@ -93,6 +93,11 @@ struct s3grl_context {
   bool gather_pending = false;  // ev[3], ev[4] recorded but not yet read
   double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // side streams for launches that do not depend on each other (the link kernels of the LDS
+  // classes): forked from and joined back into `stream` with events, created on first use
+  static constexpr int kSide = 3;
+  hipStream_t side[kSide] = {nullptr, nullptr, nullptr};
+  hipEvent_t side_ev[kSide + 1] = {nullptr, nullptr, nullptr, nullptr};
   int64_t* d_scalars = nullptr;  // small device scratch for totals (32 x int64)
   int64_t* h_scalars = nullptr;  // pinned host mirror
 };

@@ -1120,7 +1120,8 @@ struct LinkArgs {
 };
 
 template <int T, int K, int G, bool GS, bool HS>
-s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t L, int cls, int count) {
+s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t L, int cls, int count,
+                                 hipStream_t stream) {
   const int W = words_for(a.g->num_nodes);
   size_t lds;
   if (HS)
@@ -1132,7 +1133,7 @@ s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t 
   auto kern = link_kernel<T, K, G, GS, HS>;
   S3GRL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(T), lds, ctx->stream, a.g->indptr,
+  hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(T), lds, stream, a.g->indptr,
                      a.g->indices, W, a.links, a.class_list + (int64_t)cls * L, a.hops, a.plus,
                      a.cn_cap, a.full_stats, a.g->max_degree > kHubArmDegree ? 1 : 0, a.rw_raw,
                      a.rw_len, a.p_nodes, a.node_off, a.row_ptr, a.job_off, a.coef_off,
@@ -1147,32 +1148,60 @@ s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t 
 
 // lanes per CSR row: 4 for sparse graphs (PubMed/Cora: mean degree ~4), 8 otherwise
 template <int T, int K>
-s3grl_status launch_link_class(s3grl_context* ctx, const LinkArgs& a, int64_t L, int cls, int count) {
+s3grl_status launch_link_class(s3grl_context* ctx, const LinkArgs& a, int64_t L, int cls, int count,
+                               hipStream_t stream) {
   const double mean_deg = (double)a.g->nnz / (double)std::max<int64_t>(a.g->num_nodes, 1);
   static const int force_g = getenv("S3GRL_LANES_PER_ROW") ? atoi(getenv("S3GRL_LANES_PER_ROW")) : 0;
   const int gsel = force_g ? force_g : (mean_deg <= 6.0 ? 4 : 8);
   if (cls == kNumClasses) {   // HBM-scratch overflow class
-    if (gsel <= 4) return launch_link_class_g<1024, K, 4, true, false>(ctx, a, L, cls, count);
-    return launch_link_class_g<1024, K, 8, true, false>(ctx, a, L, cls, count);
+    if (gsel <= 4) return launch_link_class_g<1024, K, 4, true, false>(ctx, a, L, cls, count, stream);
+    return launch_link_class_g<1024, K, 8, true, false>(ctx, a, L, cls, count, stream);
   }
   if (cls >= kSparseBase) {   // hash flavour
-    if (gsel <= 4) return launch_link_class_g<256, K, 4, false, true>(ctx, a, L, cls, count);
-    return launch_link_class_g<256, K, 8, false, true>(ctx, a, L, cls, count);
+    if (gsel <= 4) return launch_link_class_g<256, K, 4, false, true>(ctx, a, L, cls, count, stream);
+    return launch_link_class_g<256, K, 8, false, true>(ctx, a, L, cls, count, stream);
   }
-  if (gsel == 2) return launch_link_class_g<T, K, 2, false, false>(ctx, a, L, cls, count);
-  if (gsel == 4) return launch_link_class_g<T, K, 4, false, false>(ctx, a, L, cls, count);
-  return launch_link_class_g<T, K, 8, false, false>(ctx, a, L, cls, count);
+  if (gsel == 2) return launch_link_class_g<T, K, 2, false, false>(ctx, a, L, cls, count, stream);
+  if (gsel == 4) return launch_link_class_g<T, K, 4, false, false>(ctx, a, L, cls, count, stream);
+  return launch_link_class_g<T, K, 8, false, false>(ctx, a, L, cls, count, stream);
+}
+
+// The launches of the LDS classes do not depend on each other: they go round-robin onto the
+// context's stream and its side streams (forked and joined with events), so that the tail of one
+// class overlaps the start of the next instead of draining the chip five times per plan.
+static s3grl_status side_streams(s3grl_context* ctx) {
+  for (int i = 0; i < s3grl_context::kSide; ++i)
+    if (!ctx->side[i]) S3GRL_HIP_TRY(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
+  for (int i = 0; i <= s3grl_context::kSide; ++i)
+    if (!ctx->side_ev[i]) S3GRL_HIP_TRY(hipEventCreateWithFlags(&ctx->side_ev[i], hipEventDisableTiming));
+  return S3GRL_OK;
 }
 
 template <int K>
 s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
                             const int32_t* class_count_host) {
+  static const bool serial = getenv("S3GRL_SERIAL_CLASSES") != nullptr;
+  int launches = 0;
+  for (int c = 0; c < kNumLists; ++c) launches += class_count_host[c] > 0 && c != kNumClasses + 1;
+  const bool fork = !serial && launches > 1;
+  if (fork) {
+    S3GRL_TRY(side_streams(ctx));
+    S3GRL_HIP_TRY(hipEventRecord(ctx->side_ev[s3grl_context::kSide], ctx->stream));
+    for (int i = 0; i < s3grl_context::kSide; ++i)
+      S3GRL_HIP_TRY(hipStreamWaitEvent(ctx->side[i], ctx->side_ev[s3grl_context::kSide], 0));
+  }
+  int turn = 0;
+  auto next_stream = [&]() -> hipStream_t {
+    if (!fork) return ctx->stream;
+    const int k = turn++ % (s3grl_context::kSide + 1);
+    return k == 0 ? ctx->stream : ctx->side[k - 1];
+  };
   // largest subgraphs first: they are the long poles of the tail
   if (class_count_host[kNumClasses] > 0)
-    S3GRL_TRY((launch_link_class<1024, K>(ctx, a, L, kNumClasses, class_count_host[kNumClasses])));
+    S3GRL_TRY((launch_link_class<1024, K>(ctx, a, L, kNumClasses, class_count_host[kNumClasses], next_stream())));
   for (int c = kNumLists - 1; c >= kSparseBase; --c)
     if (class_count_host[c] > 0)
-      S3GRL_TRY((launch_link_class<256, K>(ctx, a, L, c, class_count_host[c])));
+      S3GRL_TRY((launch_link_class<256, K>(ctx, a, L, c, class_count_host[c], next_stream())));
   for (int c = kNumClasses - 1; c >= 0; --c) {
     const int count = class_count_host[c];
     if (count == 0) continue;
@@ -1180,10 +1209,15 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
     // graph whose three N-bit bitmaps alone take tens of KB): give each more waves then.
     const size_t lds = (size_t)4 * link_fixed_words(a.g->num_nodes, a.cn_cap, K) +
                        class_bounds(a.g->num_nodes, a.cn_cap, K).b[c];
-    if (lds <= 40 * 1024) S3GRL_TRY((launch_link_class<256, K>(ctx, a, L, c, count)));
-    else if (lds <= 80 * 1024) S3GRL_TRY((launch_link_class<512, K>(ctx, a, L, c, count)));
-    else S3GRL_TRY((launch_link_class<1024, K>(ctx, a, L, c, count)));
+    if (lds <= 40 * 1024) S3GRL_TRY((launch_link_class<256, K>(ctx, a, L, c, count, next_stream())));
+    else if (lds <= 80 * 1024) S3GRL_TRY((launch_link_class<512, K>(ctx, a, L, c, count, next_stream())));
+    else S3GRL_TRY((launch_link_class<1024, K>(ctx, a, L, c, count, next_stream())));
   }
+  if (fork)
+    for (int i = 0; i < s3grl_context::kSide; ++i) {
+      S3GRL_HIP_TRY(hipEventRecord(ctx->side_ev[i], ctx->side[i]));
+      S3GRL_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->side_ev[i], 0));
+    }
   return S3GRL_OK;
 }
 
