@@ -654,9 +654,15 @@ __global__ __launch_bounds__(T) void link_kernel(
   S3GRL_STAMP(1)
   // ---- D^-1/2 on P (inf -> 0) -------------------------------------------------------------
   // reference tuned_SIGN.py:153-161: structure only, target link removed, no self-loops added
+  // Only for the hops the row nodes themselves sit in (src/dst; the common neighbours at hop 1):
+  // every later pass derives the D^-1/2 of the list rows it reaches for the first time from its
+  // own walk of those rows (dinv_rows = how far that has got), so no row of P is walked for its
+  // degree alone.
   int edges_local = 0;
+  int edges_exact = -1;   // set when a pass of pair 0 walked every row of S
+  int dinv_rows = lvl_end[min(max_row_hop, nlev - 1)];
   walk_rows<T, G, 2>(
-      0, p, list, indptr, indices, hub,
+      0, dinv_rows, list, indptr, indices, hub,
       [&](RowAcc& a, int v, int u, bool valid) {
         // the target link is masked (utils.py:79-80): one compare per neighbour against the
         // row's partner (-1 for every row but src and dst; hoisted out of the neighbour loop)
@@ -720,26 +726,39 @@ __global__ __launch_bounds__(T) void link_kernel(
           [&](RowAcc& a, int v, int u, bool valid) {
             bool on;
             float2 sv;
+            bool member;
             if constexpr (HS) {
               const int slot = hs_find(hkeys, hmask, u);
               const int r = hvals[max(slot, 0)];
               sv = s_in[min(max(r, 0), p - 1)];
-              on = valid && slot >= 0 && r < p;
+              member = valid && slot >= 0;
+              on = member && r < p;
             } else {
-              // all LDS reads unconditional, the contribution selected afterwards
-              const uint32_t wp = inP[u >> 5];
-              const int r = (int)wpreP[u >> 5] + __popc(wp & ((1u << (u & 31)) - 1u));
+              // all LDS reads unconditional, count and contribution selected afterwards
+              const uint32_t bit = 1u << (u & 31);
+              const uint32_t wv = vis[u >> 5], wp = inP[u >> 5];
+              const int r = (int)wpreP[u >> 5] + __popc(wp & (bit - 1u));
               sv = s_in[min(r, p - 1)];
-              on = valid && ((wp >> (u & 31)) & 1u);
+              member = valid && (wv & bit);
+              on = member && (wp & bit);
             }
             const int mp = v == src ? dst : (v == dst ? src : -1);
+            member = member && u != mp;
             on = on && u != mp;
+            a.n += member ? 1 : 0;
             a.x += on ? sv.x : 0.f;
             a.y += on ? sv.y : 0.f;
           },
           [&](RowAcc& a, int t, int v) {
             const int w = p_index_of_row(t, v);
-            const float dw = dinvP[w];
+            float dw;
+            if (t >= dinv_rows) {   // first pass to reach this row: its degree comes from this walk
+              dw = a.n > 0 ? 1.0f / sqrtf((float)a.n) : 0.0f;
+              dinvP[w] = dw;
+              edges_local += a.n;
+            } else {
+              dw = dinvP[w];
+            }
             const float rx = dw * a.x, ry = dw * a.y;
             s_out[w] = make_float2(dw * rx, dw * ry);
             coef[(int64_t)i * support + t] = make_float2(rx, ry);
@@ -748,6 +767,7 @@ __global__ __launch_bounds__(T) void link_kernel(
             if (v == dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
           });
       for (int t = limit + tid; t < support; t += T) coef[(int64_t)i * support + t] = make_float2(0.f, 0.f);
+      dinv_rows = max(dinv_rows, limit);
       __syncthreads();
       float2* tmp = s_in;
       s_in = s_out;
@@ -795,7 +815,7 @@ __global__ __launch_bounds__(T) void link_kernel(
               if (v == dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
             }
           });
-      if (pr == 0) edges_local = (last_rows == n) ? edges_pass : edges_local;
+      if (pr == 0 && last_rows == n) edges_exact = edges_pass;
       __syncthreads();
     }
     S3GRL_STAMP(4)
@@ -828,7 +848,7 @@ __global__ __launch_bounds__(T) void link_kernel(
   // edges of the masked induced subgraph: exact when the last pass of pair 0 covered all of S
   // (always with full_stats; otherwise whenever K >= num_hops), else the edges of P's rows
   S3GRL_STAMP(5)
-  edges_local = block_sum<T>(edges_local, sh);
+  edges_local = block_sum<T>(edges_exact >= 0 ? edges_exact : edges_local, sh);
   vol_local = block_sum<T>(vol_local, sh);
   if (tid == 0) {
     atomicAdd(tot_edges, (unsigned long long)edges_local * (mirror >= 0 ? 2ull : 1ull));
