@@ -110,8 +110,9 @@ __device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      be[u].x = indptr[v[u]];
-      be[u].y = indptr[v[u] + 1];
+      // unsigned indices: a 32-bit offset on a uniform base (no sign extension, no 64-bit add)
+      be[u].x = indptr[(uint32_t)v[u]];
+      be[u].y = indptr[(uint32_t)v[u] + 1u];
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
@@ -132,8 +133,8 @@ __device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
     int second[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      first[u] = indices[c0[u] < e1[u] ? c0[u] : 0];
-      second[u] = indices[c0[u] + G < e1[u] ? c0[u] + G : 0];
+      first[u] = indices[(uint32_t)(c0[u] < e1[u] ? c0[u] : 0)];
+      second[u] = indices[(uint32_t)(c0[u] + G < e1[u] ? c0[u] + G : 0)];
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
@@ -156,8 +157,8 @@ __device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
       // longer rows: two neighbours per lane in flight per trip
       for (int c = c0[u] + 2 * G; c < e1[u]; c += 2 * G) {
         const bool vb = c + G < e1[u];
-        const int ua = indices[c];
-        const int ub = indices[vb ? c + G : c];
+        const int ua = indices[(uint32_t)c];
+        const int ub = indices[(uint32_t)(vb ? c + G : c)];
         visit(acc[u], v[u], ua, true);
         visit(acc[u], v[u], ub, vb);
       }

@@ -661,18 +661,32 @@ __global__ __launch_bounds__(T) void link_kernel(
   int edges_local = 0;
   int edges_exact = -1;   // set when a pass of pair 0 walked every row of S
   int dinv_rows = lvl_end[min(max_row_hop, nlev - 1)];
-  walk_rows<T, G, 2>(
-      0, dinv_rows, list, indptr, indices, hub,
-      [&](RowAcc& a, int v, int u, bool valid) {
-        // the target link is masked (utils.py:79-80): one compare per neighbour against the
-        // row's partner (-1 for every row but src and dst; hoisted out of the neighbour loop)
-        const int mp = v == src ? dst : (v == dst ? src : -1);
-        a.n += (valid && in_s(u) && u != mp) ? 1 : 0;
-      },
-      [&](RowAcc& a, int t, int v) {
-        dinvP[p_index_of_row(t, v)] = a.n > 0 ? 1.0f / sqrtf((float)a.n) : 0.0f;
-        edges_local += a.n;
-      });
+  if (!rw_raw && !sampling_on(smp) && hops > max_row_hop) {
+    // A plain BFS to `hops` holds every neighbour of a node that sits below hop `hops`: the
+    // subgraph degree of such a row is its global degree, minus the masked target link at src and
+    // dst (utils.py:79-80).  No walk.
+    for (int t = tid; t < dinv_rows; t += T) {
+      const int v = list[t];
+      const int b = indptr[v], e = indptr[v + 1];
+      int d = e - b;
+      if (v == src || v == dst) d -= sorted_contains(indices + b, d, v == src ? dst : src) ? 1 : 0;
+      dinvP[p_index_of_row(t, v)] = d > 0 ? 1.0f / sqrtf((float)d) : 0.0f;
+      edges_local += d;
+    }
+  } else {
+    walk_rows<T, G, 2>(
+        0, dinv_rows, list, indptr, indices, hub,
+        [&](RowAcc& a, int v, int u, bool valid) {
+          // the target link is masked (utils.py:79-80): one compare per neighbour against the
+          // row's partner (-1 for every row but src and dst; hoisted out of the neighbour loop)
+          const int mp = v == src ? dst : (v == dst ? src : -1);
+          a.n += (valid && in_s(u) && u != mp) ? 1 : 0;
+        },
+        [&](RowAcc& a, int t, int v) {
+          dinvP[p_index_of_row(t, v)] = a.n > 0 ? 1.0f / sqrtf((float)a.n) : 0.0f;
+          edges_local += a.n;
+        });
+  }
   __syncthreads();
 
   S3GRL_STAMP(2)
