@@ -115,13 +115,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # one rank per GPU; a rehearsal with more ranks than GPUs (S3GRL_BENCH_BACKEND=gloo on a
+    # one-GPU box) shares the devices round-robin
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    backend = os.environ.get("S3GRL_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    torch.cuda.set_device(dev_index)
 
     import __graft_entry__ as ge
 
@@ -136,7 +143,7 @@ def main():
     L = link_index.shape[1]
     F, K = w.X.shape[1], w.sign_k
 
-    eng = Engine(f"cuda:{local_rank}")
+    eng = Engine(f"cuda:{dev_index}")
     g = eng.graph(w.A)
     x = eng.features(w.X)
     links = eng.links(link_index)
@@ -176,7 +183,7 @@ def main():
     tm = eng.timings()
     eng.set_profiling(False)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+        t = torch.tensor([dt], dtype=torch.float64, device=eng.device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
