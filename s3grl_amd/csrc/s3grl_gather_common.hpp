@@ -11,12 +11,15 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 // rows are [K+1][1+F] fp32; the +1 label column makes them 4-byte aligned only.  A folded
 // reversed duplicate gets the same values with the two rows swapped.  acc[i][r][c]: operator i+1,
 // row r of the pair, this lane's c-th float4 of columns coff[c]..coff[c]+3.
-template <int K, int CH>
-__device__ __forceinline__ void write_pair_rows(const Job& job, int jid, const float4_t (&acc)[K][2][CH],
-                                                const int (&coff)[CH], const bool (&cok)[CH],
-                                                const float* __restrict__ job_z,
-                                                const float* __restrict__ X, int64_t ldx, int F,
-                                                float* __restrict__ rows, bool first_tile) {
+// Writes the operator rows I0+1 .. I1 (acc[I0 .. I1-1]); XROW: also operator 0 = X[node];
+// ZCOL: also the label column of every operator.  The packed gather writes in two parts (the
+// operators that are complete early free their accumulators for the rest of the kernel).
+template <int K, int CH, int I0, int I1, bool XROW, bool ZCOL>
+__device__ __forceinline__ void write_pair_rows_part(const Job& job, int jid, const float4_t (&acc)[K][2][CH],
+                                                     const int (&coff)[CH], const bool (&cok)[CH],
+                                                     const float* __restrict__ job_z,
+                                                     const float* __restrict__ X, int64_t ldx, int F,
+                                                     float* __restrict__ rows, bool first_tile) {
   const int lane = threadIdx.x & 63;
   const int Fp = F + 1;
   const int64_t rstride = (int64_t)(K + 1) * Fp;
@@ -34,14 +37,16 @@ __device__ __forceinline__ void write_pair_rows(const Job& job, int jid, const f
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
         if (cok[c]) {
-          const float4_t x0 = *reinterpret_cast<const float4_t*>(xr + coff[c]);
           const int nv = min(4, F - coff[c]);  // F need not be a multiple of 4 (X is padded)
-          float* o = out + 1 + coff[c];
+          if constexpr (XROW) {
+            const float4_t x0 = *reinterpret_cast<const float4_t*>(xr + coff[c]);
+            float* o = out + 1 + coff[c];
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (e < nv) o[e] = x0[e];
+            for (int e = 0; e < 4; ++e)
+              if (e < nv) o[e] = x0[e];
+          }
 #pragma unroll
-          for (int i = 0; i < K; ++i) {
+          for (int i = I0; i < I1; ++i) {
             const float4_t a = acc[i][r][c];
             float* oi = out + (int64_t)(i + 1) * Fp + 1 + coff[c];
 #pragma unroll
@@ -50,13 +55,24 @@ __device__ __forceinline__ void write_pair_rows(const Job& job, int jid, const f
           }
         }
       }
-      if (first_tile && lane <= K) {
-        const float z = lane == 0 ? (float)(r == 0 ? job.z_a : job.z_b)
-                                  : job_z[((int64_t)jid * K + (lane - 1)) * 2 + r];
-        out[(int64_t)lane * Fp] = z;
+      if constexpr (ZCOL) {
+        if (first_tile && lane <= K) {
+          const float z = lane == 0 ? (float)(r == 0 ? job.z_a : job.z_b)
+                                    : job_z[((int64_t)jid * K + (lane - 1)) * 2 + r];
+          out[(int64_t)lane * Fp] = z;
+        }
       }
     }
   }
+}
+
+template <int K, int CH>
+__device__ __forceinline__ void write_pair_rows(const Job& job, int jid, const float4_t (&acc)[K][2][CH],
+                                                const int (&coff)[CH], const bool (&cok)[CH],
+                                                const float* __restrict__ job_z,
+                                                const float* __restrict__ X, int64_t ldx, int F,
+                                                float* __restrict__ rows, bool first_tile) {
+  write_pair_rows_part<K, CH, 0, K, true, true>(job, jid, acc, coff, cok, job_z, X, ldx, F, rows, first_tile);
 }
 
 }  // namespace

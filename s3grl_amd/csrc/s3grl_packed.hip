@@ -197,70 +197,126 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
       }
     }
   };
-  // Operator dispatch: three code variants for K <= 3 (all operators / all but the first / the
-  // last one only).  For K >= 4 every variant costs ~16 more live VGPRs and a wave per SIMD, which
-  // measured slower than the multiply-adds it saves (PubMed K=5: 42 ms with variants, 25 ms
-  // without), so all operators are applied to every row there.
-  auto fma = [&](int g, const float4_t(&v)[U][CH]) {
-    [[maybe_unused]] const int lo = g * U;   // wave-uniform: scalar branches, no memory operation inside
-    if constexpr (K == 2) {
-      if (lo >= lim[0]) fma_from(std::integral_constant<int, 1>{}, g, v);
-      else fma_from(std::integral_constant<int, 0>{}, g, v);
-    } else if constexpr (K == 3) {
-      if (lo >= lim[1]) fma_from(std::integral_constant<int, 2>{}, g, v);
-      else if (lo >= lim[0]) fma_from(std::integral_constant<int, 1>{}, g, v);
-      else fma_from(std::integral_constant<int, 0>{}, g, v);
-    } else {
-      fma_from(std::integral_constant<int, 0>{}, g, v);
-    }
+  // Two phases.  A: the list prefix that operators before the last can reach (rows < lim[K-2]),
+  // all accumulators live, two chunk buffers.  Then the rows of operators 1..K-1 are complete and
+  // are written out, which frees their 2(K-1)·CH·4 accumulator registers.  B: the rest of the list
+  // feeds the last operator only; the freed registers hold a third chunk buffer, so 8 rows are in
+  // flight under the multiply-adds of 4 instead of 4 — at the same 3 waves per SIMD.
+  auto fma_A = [&](int g, const float4_t(&v)[U][CH]) {
+    // (a variant without the first operator for the rows it cannot reach costs more registers
+    // than the multiply-adds it saves: K = 3 goes from 3 waves per SIMD to 2)
+    fma_from(std::integral_constant<int, 0>{}, g, v);
     __builtin_amdgcn_sched_barrier(0);
+  };
+  auto fma_B = [&](int g, const float4_t(&v)[U][CH]) {
+    fma_from(std::integral_constant<int, K - 1>{}, g, v);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto tail_rows = [&](auto first, int j0) {   // at most U-1 rows, operators first+1 .. K
+    constexpr int I0 = decltype(first)::value;
+    for (int j = j0; j < cnt; ++j) {
+      const PackedHdr h = th[uid[j]];
+      const uint32_t base = (uint32_t)h.off;
+      const uint32_t o0 = select_by_mask(h.m0, (base + (uint32_t)below(h.m0)) << 4);
+      const uint32_t o1 = select_by_mask(h.m1, (base + (uint32_t)__popcll(h.m0) + (uint32_t)below(h.m1)) << 4);
+      float4_t v[CH];
+      v[0] = *reinterpret_cast<const float4_t*>(bytes + o0);
+      v[1] = *reinterpret_cast<const float4_t*>(bytes + o1);
+#pragma unroll
+      for (int i = I0; i < K; ++i) {
+        const float2 q = cf[(int64_t)i * cnt + j];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          acc[i][0][c] += q.x * v[c];
+          acc[i][1][c] += q.y * v[c];
+        }
+      }
+    }
   };
 
   const int ngf = cnt / U;   // full groups
-  int g = 0;
-  if (ngf > 0) {
+  const int limA = K >= 2 ? lim[K >= 2 ? K - 2 : 0] : 0;
+  const int gA = min(ngf, (limA + U - 1) / U);       // groups [0, gA) belong to phase A
+  const bool tail_in_A = limA > ngf * U;             // then gA == ngf and phase B is empty
+
+  // ---- phase A ----------------------------------------------------------------------------
+  if (gA > 0) {
+    int g = 0;
     PackedHdr hA[U], hB[U];
     float4_t vA[U][CH], vB[U][CH];
     load_hdrs(0, hA);
     issue(hA, vA);
-    if (ngf > 1) load_hdrs(1, hB);
-    // steady state, no control flow inside besides the uniform operator dispatch:
-    // vA = group g in flight, hB = headers of group g+1
-    for (; g + 3 < ngf; g += 2) {
+    if (gA > 1) load_hdrs(1, hB);
+    // steady state: vA = group g in flight, hB = headers of group g+1
+    for (; g + 3 < gA; g += 2) {
       issue(hB, vB);
       load_hdrs(g + 2, hA);
-      fma(g, vA);
+      fma_A(g, vA);
       issue(hA, vA);
       load_hdrs(g + 3, hB);
-      fma(g + 1, vB);
+      fma_A(g + 1, vB);
     }
-    fma(g, vA);
+    fma_A(g, vA);
     ++g;
-    for (; g < ngf; ++g) {   // at most 3 groups
+    for (; g < gA; ++g) {   // at most 3 groups
       load_hdrs(g, hA);
       issue(hA, vA);
-      fma(g, vA);
+      fma_A(g, vA);
     }
   }
-  for (int j = ngf * U; j < cnt; ++j) {   // at most U-1 rows
-    const PackedHdr h = th[uid[j]];
-    const uint32_t base = (uint32_t)h.off;
-    const uint32_t o0 = select_by_mask(h.m0, (base + (uint32_t)below(h.m0)) << 4);
-    const uint32_t o1 = select_by_mask(h.m1, (base + (uint32_t)__popcll(h.m0) + (uint32_t)below(h.m1)) << 4);
-    float4_t v[CH];
-    v[0] = *reinterpret_cast<const float4_t*>(bytes + o0);
-    v[1] = *reinterpret_cast<const float4_t*>(bytes + o1);
-#pragma unroll
-    for (int i = 0; i < K; ++i) {
-      const float2 q = cf[(int64_t)i * cnt + j];
-#pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        acc[i][0][c] += q.x * v[c];
-        acc[i][1][c] += q.y * v[c];
+  if (tail_in_A) tail_rows(std::integral_constant<int, 0>{}, ngf * U);
+  // operators 0 .. K-1 of both rows are final
+  write_pair_rows_part<K, CH, 0, K - 1, true, false>(job, jid, acc, coff, cok, job_z, X, ldx, F, rows,
+                                                     blockIdx.y == 0);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- phase B ----------------------------------------------------------------------------
+  {
+    int g = gA;
+    PackedHdr h0[U], h1[U];                    // headers of the groups gA + even / gA + odd
+    float4_t v0[U][CH], v1[U][CH], v2[U][CH];  // chunk buffers of the groups gA + (k % 3)
+    if (ngf - gA >= 3) {
+      load_hdrs(g, h0);
+      issue(h0, v0);
+      load_hdrs(g + 1, h1);
+      issue(h1, v1);
+      load_hdrs(g + 2, h0);
+      // steady state (g - gA a multiple of 6): groups g, g+1 in flight in v0, v1; h0 = headers of g+2
+      for (; g + 8 < ngf; g += 6) {
+        issue(h0, v2);
+        load_hdrs(g + 3, h1);
+        fma_B(g, v0);
+        issue(h1, v0);
+        load_hdrs(g + 4, h0);
+        fma_B(g + 1, v1);
+        issue(h0, v1);
+        load_hdrs(g + 5, h1);
+        fma_B(g + 2, v2);
+        issue(h1, v2);
+        load_hdrs(g + 6, h0);
+        fma_B(g + 3, v0);
+        issue(h0, v0);
+        load_hdrs(g + 7, h1);
+        fma_B(g + 4, v1);
+        issue(h1, v1);
+        load_hdrs(g + 8, h0);
+        fma_B(g + 5, v2);
       }
+      issue(h0, v2);
+      fma_B(g, v0);
+      fma_B(g + 1, v1);
+      fma_B(g + 2, v2);
+      g += 3;
+    }
+    for (; g < ngf; ++g) {   // fewer than 3 groups in all, or the last 0..5 of a long list
+      load_hdrs(g, h0);
+      issue(h0, v0);
+      fma_B(g, v0);
     }
   }
-  write_pair_rows<K, CH>(job, jid, acc, coff, cok, job_z, X, ldx, F, rows, blockIdx.y == 0);
+  if (!tail_in_A) tail_rows(std::integral_constant<int, K - 1>{}, ngf * U);
+  write_pair_rows_part<K, CH, K - 1, K, false, true>(job, jid, acc, coff, cok, job_z, X, ldx, F, rows,
+                                                     blockIdx.y == 0);
 }
 
 template <int K>
