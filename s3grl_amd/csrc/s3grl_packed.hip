@@ -107,11 +107,12 @@ __global__ __launch_bounds__(256) void pk_fill_kernel(const float* __restrict__ 
 // chosen with one v_cndmask on the wave-uniform mask — so every load is unconditional.  The
 // phases are kept apart with scheduling barriers; left alone, the compiler serialises the scalar
 // loads (load, wait, use, load, wait, ...).
-// Measured on PubMed PoS K=3 (164 000 links): no pipelining 17.8 ms; this form 14.4 ms; plus
-// skipping the operators that cannot reach a row 13.6 ms.  Deeper pipelines lost: U=2 x 4
-// buffers 16.6 ms (more scalar instructions per row), U=4 x 3 buffers 17.1 ms and U=4 x 5
-// buffers 19.0 ms (156-250 VGPRs: fewer waves per SIMD, and the unrolled body outgrows the
-// instruction cache).
+// Measured on PubMed PoS K=3 (164 000 links), step by step: no pipelining 17.8 ms; two buffers
+// 14.4; skipping the operators that cannot reach a row 13.6; one wavefront per workgroup 10.8;
+// jobs started largest first 9.7; two phases with a third buffer for the last-operator rows 8.2.
+// What lost: U=2 x 4 buffers 16.6 ms (more scalar instructions per row); a third or fifth buffer
+// for ALL rows 17.1 / 19.0 ms (156-250 VGPRs: fewer waves per SIMD, and the unrolled body
+// outgrows the instruction cache); an XCD-contiguous job mapping 19 ms (load imbalance).
 __device__ __forceinline__ uint32_t select_by_mask(uint64_t mask, uint32_t if_set) {
   uint32_t r;   // lane-wise: bit `lane` of the wave-uniform mask ? if_set : 0
   asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(if_set), "s"(mask));
