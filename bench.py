@@ -217,6 +217,7 @@ def main():
                 "bound": "hbm", "kernel": "gather_packed_kernel" if getattr(x, "is_packed", False) else "gather_kernel",
                 "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_GBps": (traffic / (gather_ms * 1e-3) / 1e9) if (traffic and gather_ms > 0) else None,
                 "algorithmic_bytes_per_launch": gather_bytes, "kernel_ms": gather_ms,
                 "algorithmic_bytes_all_links": gather_all,
                 "path_algorithmic_bytes_per_step": path_bytes,
