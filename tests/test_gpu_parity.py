@@ -1013,3 +1013,26 @@ def test_sampling_argument_errors(eng):
     assert p.stats["total_nodes"] == 2
     p.close()
     G.close()
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 4])
+@pytest.mark.parametrize("name", ["probe5", "triangle", "pair", "star_iso"])
+def test_packed_gather_on_tiny_subgraphs(eng, name, K):
+    """The packed-row gather's phase logic on supports of 2..7 rows (no full group of 4 rows, the
+    prefix limits inside the tail, empty phases), hops 1..3, PoS and PoS Plus."""
+    g = load_extract(name)
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    rng = np.random.default_rng(K)
+    X = (rng.standard_normal((n, 9)) * (rng.random((n, 9)) < 0.4)).astype(np.float32)
+    G = eng.graph(A)
+    f = eng.features(X, "packed")
+    assert f.is_packed
+    kw = {"sign_k": K, "k_node_set_strategy": "intersection"}
+    for h in (1, 2, 3):
+        for mode, fn in (("pos", oracle.get_PoS_prepped_ds), ("pos_plus", oracle.get_PoS_Plus_prepped_ds)):
+            res = eng.precompute(G, f, eng.links(g["links"].T), mode=mode, num_hops=h, sign_k=K)
+            ref, ptr, _ = oracle.collate_rows(fn(g["links"].T, h, A, X.astype(np.float64), 1, kw, dtype=np.float64), K)
+            np.testing.assert_array_equal(res.row_ptr.cpu().numpy(), ptr)
+            assert rel_err(res.rows.cpu().numpy(), ref) < TOL, (name, K, h, mode)
+    G.close()
