@@ -1036,3 +1036,38 @@ def test_packed_gather_on_tiny_subgraphs(eng, name, K):
             np.testing.assert_array_equal(res.row_ptr.cpu().numpy(), ptr)
             assert rel_err(res.rows.cpu().numpy(), ref) < TOL, (name, K, h, mode)
     G.close()
+
+
+@pytest.mark.parametrize("flavour", ["bitmap", "hash"])
+def test_node_list_handover_and_its_fallback(eng, monkeypatch, flavour):
+    """count_kernel hands every link's node list to link_kernel through an HBM slot; a list longer
+    than the slot (or no slot at all) makes link_kernel walk the graph again.  All three ways give
+    the same bits, in both flavours of the visited set."""
+    import torch
+
+    g = load_extract("rand300")
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = np.random.default_rng(8).standard_normal((n, 13))
+    links = np.concatenate([g["links"], g["links"][:6, ::-1]])
+    if flavour == "hash":
+        monkeypatch.setenv("S3GRL_FORCE_HASH", "1")
+    G = eng.graph(A)
+    f = eng.features(X)
+    L = eng.links(links.T)
+    outs = []
+    for slot in (None, "0", "8", "64"):
+        if slot is None:
+            monkeypatch.delenv("S3GRL_STASH_SLOT", raising=False)
+        else:
+            monkeypatch.setenv("S3GRL_STASH_SLOT", slot)
+        res = eng.precompute(G, f, L, mode="pos_plus", num_hops=2, sign_k=3)
+        outs.append((res.rows.clone(), res.row_ptr.clone(), res.row_nodes.clone()))
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
+    ref, ptr, _ = oracle.collate_rows(
+        oracle.get_PoS_Plus_prepped_ds(links.T, 2, A, X.astype(np.float32).astype(np.float64), 1,
+                                       {"sign_k": 3, "k_node_set_strategy": "intersection"}, dtype=np.float64), 3)
+    np.testing.assert_array_equal(outs[0][1].cpu().numpy(), ptr)
+    assert rel_err(outs[0][0].cpu().numpy(), ref) < TOL
+    G.close()
