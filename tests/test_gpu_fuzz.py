@@ -1,0 +1,86 @@
+"""Seeded random sweep of the PoS / PoS Plus path against the plain-C fp64 restatement: graph
+shape (uniform / power-law with hubs / with isolated nodes), size, hops, sign_k, feature width and
+sparsity (dense and packed operand), visited-set flavour and LDS budget (LDS classes, HBM-scratch
+class) all vary together.  Every case is deterministic."""
+import numpy as np
+import pytest
+
+from conftest import csr_from_undirected
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+ATOL = 1e-10
+
+
+def rel_err(got, ref):
+    ref = np.asarray(ref, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    if not ref.size:
+        return 0.0
+    scale = np.maximum(np.abs(ref), np.abs(ref).max(axis=-1, keepdims=True))
+    return float(np.max(np.clip(np.abs(got - ref) - ATOL, 0, None) / np.maximum(scale, 1e-30)))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    from s3grl_amd.engine import Engine
+
+    assert torch.cuda.is_available()
+    e = Engine("cuda:0")
+    yield e
+    e.close()
+
+
+def _graph(rng, kind, n):
+    from s3grl_amd import workloads
+
+    if kind == "powerlaw":
+        n, e = workloads.chung_lu(n, int(n * rng.uniform(2.0, 6.0)), seed=int(rng.integers(1 << 30)))
+        return n, e
+    m = int(n * rng.uniform(0.8, 5.0))
+    e = rng.integers(0, n if kind == "uniform" else max(2, int(n * 0.8)), size=(m, 2))
+    e = e[e[:, 0] != e[:, 1]]
+    e = np.unique(np.sort(e, axis=1), axis=0)
+    return n, e
+
+
+CASES = list(range(36))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_random_configuration(eng, monkeypatch, case):
+    rng = np.random.default_rng(1000 + case)
+    kind = ["uniform", "powerlaw", "isolated"][case % 3]
+    n = int(rng.choice([40, 300, 2500, 9000]))
+    n, edges = _graph(rng, kind, n)
+    A = csr_from_undirected(n, edges)
+    hops = int(rng.integers(1, 4))
+    K = int(rng.integers(1, 6))
+    plus = bool(rng.integers(0, 2))
+    F = int(rng.choice([3, 17, 64, 300, 515]))
+    density = float(rng.choice([1.0, 0.3, 0.05]))
+    X = (rng.standard_normal((n, F)) * (rng.random((n, F)) < density)).astype(np.float32)
+    L = int(rng.integers(20, 120))
+    pos = edges[rng.choice(len(edges), min(L // 2, len(edges)), replace=False)]
+    neg = rng.integers(0, n, size=(L, 2))
+    neg = neg[neg[:, 0] != neg[:, 1]]
+    links = np.concatenate([pos, neg, pos[:5, ::-1]])                  # + a few reversed duplicates
+    if case % 4 == 1:
+        monkeypatch.setenv("S3GRL_FORCE_HASH", "1")
+    if case % 5 == 2:
+        monkeypatch.setenv("S3GRL_LDS_BUDGET", "3072")                 # pushes links into the HBM-scratch class
+    if case % 7 == 3:
+        monkeypatch.setenv("S3GRL_STASH_SLOT", "16")                   # most lists overflow their slot
+    G = eng.graph(A)
+    f = eng.features(X, ["auto", "dense", "packed"][case % 3])
+    res = eng.precompute(G, f, eng.links(links.T), mode="pos_plus" if plus else "pos", num_hops=hops, sign_k=K)
+    ref, ptr, nodes, _ = c_oracle.pos_rows(links.T, hops, A, X, K, plus=plus)
+    np.testing.assert_array_equal(res.row_ptr.cpu().numpy(), ptr)
+    np.testing.assert_array_equal(res.row_nodes.cpu().numpy(), nodes)
+    err = rel_err(res.rows.cpu().numpy(), ref)
+    assert err < TOL, (case, kind, n, hops, K, plus, F, density, err)
+    f.close()
+    G.close()
