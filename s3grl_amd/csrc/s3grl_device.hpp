@@ -163,17 +163,34 @@ __device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
         visit(acc[u], v[u], ub, vb);
       }
     }
+    // The xor tree leaves the row total in EVERY lane of the group, so lane u of a group can
+    // commit row u: the UN commits of a trip are one pass with UN of G lanes active instead of UN
+    // passes with one (the link kernel is VALU-issue-bound and a commit is ~25 instructions).
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      if (v[u] >= 0) {
 #pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) {
-          acc[u].x += __shfl_xor(acc[u].x, o);
-          acc[u].y += __shfl_xor(acc[u].y, o);
-          acc[u].n += __shfl_xor(acc[u].n, o);
-        }
-        if (g == 0) commit(acc[u], t[u], v[u]);
+      for (int o = G / 2; o > 0; o >>= 1) {
+        acc[u].x += __shfl_xor(acc[u].x, o);
+        acc[u].y += __shfl_xor(acc[u].y, o);
+        acc[u].n += __shfl_xor(acc[u].n, o);
       }
+    }
+    if constexpr (UN <= G) {
+      RowAcc c = acc[0];
+      int ct = t[0], cv = v[0];
+#pragma unroll
+      for (int u = 1; u < UN; ++u) {
+        if (g == u) {
+          c = acc[u];
+          ct = t[u];
+          cv = v[u];
+        }
+      }
+      if (g < UN && cv >= 0) commit(c, ct, cv);
+    } else {
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+        if (g == 0 && v[u] >= 0) commit(acc[u], t[u], v[u]);
     }
   }
   // deferred hub rows: one WAVEFRONT per row (64 lanes stride it), several rows in parallel per
