@@ -76,14 +76,19 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
     unsigned long long* __restrict__ tot_nodes_alg, HopSampling smp, int32_t* __restrict__ stash,
     int slot, int32_t* __restrict__ lvl_stash) {
   extern __shared__ uint32_t smem[];
+  // `cur` (the frontier as a bitmap, for levels too big for the frontier list) is only needed when
+  // a level below `hops` is expanded again: with one hop (and for ScaLed walks) the launcher
+  // leaves it out — a third of the LDS of a big graph
+  const bool one_hop = hops <= 1 || rw_raw != nullptr;
+  const int nbm = one_hop ? 2 : 3;
   uint32_t* vis = smem;
-  uint32_t* cur = smem + W;
-  uint32_t* nxt = smem + 2 * W;
-  int* sh = reinterpret_cast<int*>(smem + 3 * W);
+  uint32_t* cur = one_hop ? nullptr : smem + W;
+  uint32_t* nxt = smem + (nbm - 1) * W;
+  int* sh = reinterpret_cast<int*>(smem + nbm * W);
   // per-hop sampling: `vis` also holds discovered-but-dropped nodes, so the members of S get a
   // bitmap of their own (the launcher adds W words behind the list when sampling is on)
   const bool sampling = !rw_raw && sampling_on(smp);
-  uint32_t* mem = sampling ? smem + 3 * W + 8 + kHubWords + kCountList : nullptr;
+  uint32_t* mem = sampling ? smem + nbm * W + 8 + kHubWords + kCountList : nullptr;
   const int tid = threadIdx.x;
   const int l = blockIdx.x;
   const int64_t s64 = links[2 * (int64_t)l], d64 = links[2 * (int64_t)l + 1];
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
   if (lvl_l && tid == 0) lvl_l[0] = 2;
   for (int t = tid; t < W; t += kBlock) {
     vis[t] = 0;
-    cur[t] = 0;
+    if (cur) cur[t] = 0;
     nxt[t] = 0;
     if (mem) mem[t] = 0;
   }
@@ -939,7 +944,8 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           int32_t* lvl_stash) {
   if (L == 0) return S3GRL_OK;
   const int W = words_for(g->num_nodes);
-  const size_t lds = (size_t)(3 * W + 8 + kHubWords + kCountList + (hop_sampling_on(smp) ? W : 0)) * 4;
+  const int nbm = (hops <= 1 || rw_raw) ? 2 : 3;   // see count_kernel: no frontier bitmap for one hop
+  const size_t lds = (size_t)(nbm * W + 8 + kHubWords + kCountList + (hop_sampling_on(smp) ? W : 0)) * 4;
   if (lds > 163840) {
     set_last_error("num_nodes " + std::to_string(g->num_nodes) + ": the LDS bitmaps exceed 160 KiB");
     return S3GRL_ERR_GRAPH_TOO_LARGE;
