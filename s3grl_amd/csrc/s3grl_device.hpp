@@ -81,6 +81,7 @@ __device__ __forceinline__ bool sorted_contains(const int32_t* a, int n, int x) 
 struct RowAcc {
   float x, y;
   int n;
+  int row;   // list position of the row being walked (set by walk_rows before the visits)
 };
 
 constexpr int kHubFactor = 8;
@@ -147,7 +148,7 @@ __device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
     RowAcc acc[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      acc[u] = RowAcc{0.f, 0.f, 0};
+      acc[u] = RowAcc{0.f, 0.f, 0, t[u]};
       const int vv = max(v[u], 0);
       visit(acc[u], vv, max(first[u], 0), first[u] >= 0);
       visit(acc[u], vv, max(second[u], 0), second[u] >= 0);
@@ -204,7 +205,7 @@ __device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
     const int tt = hub[1 + h];
     const int v = list[tt];
     const int e1 = indptr[v + 1];
-    RowAcc acc{0.f, 0.f, 0};
+    RowAcc acc{0.f, 0.f, 0, tt};
     for (int c = indptr[v] + lane; c < e1; c += 128) {   // two neighbours per lane in flight
       const bool vb = c + 64 < e1;
       const int ua = indices[c];

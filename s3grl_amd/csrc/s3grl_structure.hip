@@ -425,11 +425,17 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restri
 // ---------------------------------------------------------------------------------------
 // LDS bytes link_kernel needs beyond its fixed part: list[n] + dinvP[p] + two float2 state
 // arrays [p] (+ alignment slack); the hash flavour adds its keys/vals tables.
+// When every operator reaches the whole subgraph (p == n) and the subgraph is small, link_kernel
+// also keeps its adjacency as an n x n bit matrix (+ two index maps), see there.
+constexpr int kBmMaxNodes = 512;
+__host__ __device__ __forceinline__ int link_bm_bytes(int n, int p) {
+  return (p == n && n <= kBmMaxNodes) ? 4 * n * ((n + 31) >> 5) + 4 * n + 8 : 0;
+}
 __host__ __device__ __forceinline__ int link_lds_need(int n, int p) { return 4 * n + 20 * p + 16; }
 __host__ __device__ __forceinline__ int link_lds_need_sparse(int n, int p) {
   int C = 64;
   while (C < 2 * n) C <<= 1;
-  return 8 * C + link_lds_need(n, p);
+  return 8 * C + link_lds_need(n, p) + link_bm_bytes(n, p);
 }
 
 struct ClassBounds {
@@ -702,6 +708,35 @@ __global__ __launch_bounds__(T) void link_kernel(
   // xor tree: bit-reproducible.  All terms are >= 0: no cancellation.  A walk of length i
   // from a row at hop h_r stays within hop h_r + i, so step i only visits that list prefix;
   // the last step visits everything it can reach and derives dinv[w] from the same pass.
+  // Small subgraphs that every operator reaches entirely (p == n: sign_k - 1 >= the BFS depth):
+  // the first pass over all rows also records the masked induced adjacency as an n x n bit matrix
+  // in LDS (row = list position, column = list position), and every later full pass — the
+  // remaining operators, the last one, the passes of the common-neighbour pairs — sums over the
+  // set bits of a row instead of walking its global CSR row through the bitmaps / the hash
+  // (a 1-hop subgraph of a power-law graph has a few hundred induced edges and ~13 000 stored
+  // neighbours).  Columns are list positions in both flavours of the visited set, so both sum in
+  // the same order.
+  const int WB = (n + 31) >> 5;
+  // Hash flavour only (big graphs, where a visit costs a hash probe).  In the bitmap flavour it
+  // measured a loss: USAir's 1-hop subgraphs are nearly as dense as their global rows (+20 % on
+  // the link kernel), and on PubMed K=5 the matrix of a 300-500-node subgraph pushes the link
+  // into a bigger LDS class (+10 %); the collab-scale config gains 12 %.
+  const bool use_bm = HS && !GS && K >= 2 && p == n && p_alloc == n_alloc && n <= kBmMaxNodes;
+  uint32_t* bm = reinterpret_cast<uint32_t*>(nxs + p_alloc);              // [n][WB]
+  uint16_t* pos_of_rank = reinterpret_cast<uint16_t*>(bm + (use_bm ? n * WB : 0));   // bitmap flavour
+  uint16_t* rank_of_pos = pos_of_rank + n;
+  bool bm_ready = false;
+  if (use_bm) {
+    for (int i = tid; i < n * WB; i += T) bm[i] = 0;
+    if constexpr (!HS) {
+      for (int t = tid; t < n; t += T) {
+        const int r = rank_of(inP, wpreP, list[t]);
+        pos_of_rank[r] = (uint16_t)t;
+        rank_of_pos[t] = (uint16_t)r;
+      }
+    }
+    __syncthreads();
+  }
   const int npairs = (R + 1) / 2;
   for (int pr = 0; pr < npairs; ++pr) {
     const int64_t jid = job_off[l] + pr;
@@ -737,21 +772,79 @@ __global__ __launch_bounds__(T) void link_kernel(
     float2* s_in = cur;
     float2* s_out = nxs;
     float2* coef = reinterpret_cast<float2*>(c_coef) + coff * K;  // [K][support] float2
+    // one operator step over ALL rows through the bit matrix: WL lanes per row (one word of the
+    // row each, WL = the row's word count rounded up to a power of two, at most 16), the set
+    // bits of a word in ascending position, then a fixed xor tree over the WL lanes:
+    // bit-reproducible, and the same order in both flavours of the visited set
+    int edges_bm = 0;
+    const int wl_shift = WB <= 1 ? 0 : (WB <= 2 ? 1 : (WB <= 4 ? 2 : (WB <= 8 ? 3 : 4)));
+    auto bm_pass = [&](int i, bool last) {
+      const int WL = 1 << wl_shift;
+      const int j0 = tid & (WL - 1);
+      for (int base = 0; base < n; base += T >> wl_shift) {
+        const int t = base + (tid >> wl_shift);
+        float ax = 0.f, ay = 0.f;
+        int deg = 0;
+        if (t < n) {
+          for (int j = j0; j < WB; j += WL) {
+            uint32_t w32 = bm[t * WB + j];
+            deg += __popc(w32);
+            while (w32) {
+              const int c = j * 32 + __ffs(w32) - 1;
+              w32 &= w32 - 1;
+              int idx = c;
+              if constexpr (!HS) idx = rank_of_pos[c];
+              const float2 sv = s_in[idx];
+              ax += sv.x;
+              ay += sv.y;
+            }
+          }
+        }
+        for (int o = WL >> 1; o > 0; o >>= 1) {   // WL divides 64: the partners are in this wave
+          ax += __shfl_xor(ax, o);
+          ay += __shfl_xor(ay, o);
+          deg += __shfl_xor(deg, o);
+        }
+        if (t < n && j0 == 0) {
+          edges_bm += deg;
+          const int v = list[t];
+          int w = t;
+          if constexpr (!HS) w = rank_of_pos[t];
+          const float dw = dinvP[w];
+          const float rx = dw * ax, ry = dw * ay;
+          if (!last) s_out[w] = make_float2(dw * rx, dw * ry);
+          coef[(int64_t)i * support + t] = make_float2(rx, ry);
+          if (v == src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
+          if (v == dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
+        }
+      }
+    };
 #pragma unroll 1
     for (int i = 0; i < K - 1; ++i) {
       const int limit = lvl_end[min(i + 1 + row_hop, nlev - 1)];  // <= p
+      if (bm_ready && limit == n) {
+        bm_pass(i, false);
+        __syncthreads();
+        float2* tmp = s_in;
+        s_in = s_out;
+        s_out = tmp;
+        continue;
+      }
+      const bool build_bm = use_bm && !bm_ready && limit == n;   // first pass over all rows
       walk_rows<T, G, 2>(
           0, limit, list, indptr, indices, hub,
           [&](RowAcc& a, int v, int u, bool valid) {
             bool on;
             float2 sv;
             bool member;
+            int col;   // list position of u (meaningful for members)
             if constexpr (HS) {
               const int slot = hs_find(hkeys, hmask, u);
               const int r = hvals[max(slot, 0)];
               sv = s_in[min(max(r, 0), p - 1)];
               member = valid && slot >= 0;
               on = member && r < p;
+              col = r;
             } else {
               // all LDS reads unconditional, count and contribution selected afterwards
               const uint32_t bit = 1u << (u & 31);
@@ -760,10 +853,15 @@ __global__ __launch_bounds__(T) void link_kernel(
               sv = s_in[min(r, p - 1)];
               member = valid && (wv & bit);
               on = member && (wp & bit);
+              col = r;
             }
             const int mp = v == src ? dst : (v == dst ? src : -1);
             member = member && u != mp;
             on = on && u != mp;
+            if (build_bm && member) {
+              if constexpr (!HS) col = pos_of_rank[min(col, n - 1)];
+              atomicOr(&bm[a.row * WB + (col >> 5)], 1u << (col & 31));
+            }
             a.n += member ? 1 : 0;
             a.x += on ? sv.x : 0.f;
             a.y += on ? sv.y : 0.f;
@@ -787,13 +885,19 @@ __global__ __launch_bounds__(T) void link_kernel(
           });
       for (int t = limit + tid; t < support; t += T) coef[(int64_t)i * support + t] = make_float2(0.f, 0.f);
       dinv_rows = max(dinv_rows, limit);
+      if (build_bm) bm_ready = true;
       __syncthreads();
       float2* tmp = s_in;
       s_in = s_out;
       s_out = tmp;
     }
     S3GRL_STAMP(3)
-    {  // last operator: degree and sum of every reachable row in one pass over its CSR row
+    if (bm_ready && last_rows == n && support == n) {   // last operator through the bit matrix
+      edges_bm = 0;
+      bm_pass(K - 1, true);
+      if (pr == 0) edges_exact = edges_bm;
+      __syncthreads();
+    } else {  // last operator: degree and sum of every reachable row in one pass over its CSR row
       const int i = K - 1;
       int edges_pass = 0;
       walk_rows<T, G, 2>(

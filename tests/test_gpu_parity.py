@@ -496,7 +496,10 @@ def test_hbm_scratch_path_for_oversized_subgraphs(eng, monkeypatch):
     monkeypatch.setenv("S3GRL_LDS_BUDGET", "600")
     alt = eng.precompute(G, f, L, mode="pos_plus", num_hops=2, sign_k=3)
     monkeypatch.delenv("S3GRL_LDS_BUDGET")
-    assert torch.equal(ref.row_ptr, alt.row_ptr) and torch.equal(ref.rows, alt.rows)
+    assert torch.equal(ref.row_ptr, alt.row_ptr) and torch.equal(ref.row_nodes, alt.row_nodes)
+    # same sums, not always the same bits: in LDS a small subgraph that every operator reaches
+    # entirely is propagated through its adjacency bit matrix, in HBM scratch through the row walker
+    assert rel_err(alt.rows.cpu().numpy(), ref.rows.cpu().numpy()) < 1e-6
     assert ref.stats == {**alt.stats, "workspace_bytes": ref.stats["workspace_bytes"]}
     G.close()
 
@@ -596,7 +599,9 @@ def test_hybrid_and_tuned_sign_twin(eng):
 @pytest.mark.parametrize("name,hops,K", [("rand300", 2, 3), ("usair", 2, 2), ("cora", 3, 3), ("probe5", 3, 5)])
 def test_hash_flavour_matches_bitmap_flavour(eng, monkeypatch, name, hops, K):
     """Graphs whose bitmaps would hog the LDS use a hash table as visited set (HS = true); forced
-    here on small graphs: node lists, rows and statistics must be identical bit for bit."""
+    here on small graphs: node lists, row selection and statistics must be identical bit for bit,
+    the rows equal to fp32 round-off (when every operator reaches the whole of a small subgraph
+    the hash flavour propagates through its adjacency bit matrix: another summation order)."""
     import torch
 
     g = load_extract(name)
@@ -614,7 +619,7 @@ def test_hash_flavour_matches_bitmap_flavour(eng, monkeypatch, name, hops, K):
         p1 = eng.plan(G, L, mode=mode, num_hops=hops, sign_k=K, full_stats=True)
         r1, e1 = p1.run(f), p1.export_subgraphs()
         monkeypatch.delenv("S3GRL_FORCE_HASH")
-        assert torch.equal(r0, r1) and torch.equal(p0.row_ptr(), p1.row_ptr())
+        assert rel_err(r1.cpu().numpy(), r0.cpu().numpy()) < 1e-6 and torch.equal(p0.row_ptr(), p1.row_ptr())
         assert torch.equal(p0.row_nodes(), p1.row_nodes())
         for a, b in zip(e0, e1):
             assert torch.equal(a, b)
@@ -725,11 +730,11 @@ def test_scaled_random_walk_subgraphs(eng, monkeypatch, mode):
     assert torch.equal(again.run(f), rows)
     other = eng.plan(G, L, mode=mode, num_hops=7, sign_k=K, rw=(m, M, 124), full_stats=True)
     assert not torch.equal(other.export_subgraphs()[1], plan.export_subgraphs()[1])
-    # hash flavour and folded duplicates agree bit for bit
+    # the hash flavour agrees to round-off (bit matrix there), folded duplicates bit for bit
     monkeypatch.setenv("S3GRL_FORCE_HASH", "1")
     hs = eng.plan(G, L, mode=mode, num_hops=7, sign_k=K, rw=(m, M, 123), full_stats=True)
     monkeypatch.delenv("S3GRL_FORCE_HASH")
-    assert torch.equal(hs.run(f), rows)
+    assert rel_err(hs.run(f).cpu().numpy(), rows.cpu().numpy()) < 1e-6
     both = np.concatenate([links[:10], links[:10, ::-1]])
     Lb = eng.links(both.T.copy())
     a = eng.plan(G, Lb, mode=mode, num_hops=7, sign_k=K, rw=(m, M, 5))
