@@ -7,13 +7,20 @@ One "step" = one pass of the hot path (plan: extraction + operator rows; run: fe
 over the workload's whole link list (train/valid/test x pos/neg, 164 000 links for PubMed) with
 the graph and X already resident in HBM.  Prints ONE JSON line (rank 0).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): link pairs are independent units,
-so every rank runs the same per-GPU workload with no data-path collective ("weak" scaling);
-value = units all ranks processed / max-over-ranks time.
+N > 1: STRONG scaling, as BASELINE.json's north_star describes it — the SAME link list is cut into
+N contiguous cost-balanced ranges, one per GPU (graph + X replicated), every rank runs the engine
+on its range and the result is reassembled on every rank by RCCL all-gathers over xGMI that are
+timed inside the step (`s3grl_amd/parallel.py`; pieces of a range are gathered while the next
+piece is computed).  value = links of the whole list / max-over-ranks step time.
+Launched either by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`
+(RANK / LOCAL_RANK / WORLD_SIZE in the environment) or directly as `python bench.py --gpus N`,
+which starts the N ranks itself as child processes BEFORE anything touches the GPU.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -23,20 +30,94 @@ import numpy as np
 REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
-HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# Ceilings, /opt/skills/guides/MI355X_MICROARCH.md (§ Memory hierarchy):
+HBM_PEAK_GBS = 8000.0      # HBM3E spec peak (6.3 TB/s is what a float4 copy achieves)
+L2_PEAK_GBS = 34500.0      # aggregate L2 bandwidth, 8 XCDs x 4 MiB
+MALL_ROWS_GBS = 8600.0     # uniformly random rows of a 38 MB table served by the Infinity Cache
+MALL_ROWS_BIG_GBS = 7900.0  # the same from a 151 MB table (7.4-7.9 measured)
+MALL_BYTES = 256 << 20
 
 
 def algorithmic_bytes(stats, F, K):
     """B_link = 8n + 4 vol(S) + 4 n F + 4 R (K+1)(1+F), summed exactly from the plan.
     Returns (whole path over ALL links, gather share over all links, gather share over the links
-    the gather launch actually processes).  The last one is what `roofline.achieved` uses: a link
-    that is the reversed duplicate of an earlier one is served by that link's extraction — its
-    output rows are written (counted) but no feature rows are fetched for it (not counted)."""
+    the gather launch actually processes)."""
     n, vol, R = stats["total_nodes"], stats["total_volume"], stats["total_rows"]
     out_bytes = 4 * R * (K + 1) * (1 + F)
     gather_all = 4 * n * F + out_bytes
     gather_launch = 4 * stats.get("extracted_nodes", n) * F + out_bytes
     return 8 * n + 4 * vol + gather_all, gather_all, gather_launch
+
+
+def hierarchical_roofline(levels, kernel_ms):
+    """levels: [(name, bytes, peak_GBs, what)].  A kernel cannot finish before its slowest level
+    has moved its bytes: t >= max_i bytes_i / peak_i.  frac = that bound / measured time (<= 1);
+    `bound` names the level that sets it."""
+    rows = []
+    for name, nbytes, peak, what in levels:
+        if nbytes is None:
+            continue
+        t_ms = nbytes / (peak * 1e9) * 1e3
+        rows.append({"level": name, "bytes": int(nbytes), "peak_GBps": peak, "min_ms": t_ms,
+                     "GBps": nbytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
+                     "frac": t_ms / kernel_ms if kernel_ms > 0 else 0.0, "what": what})
+    best = max(rows, key=lambda r: r["frac"])
+    return best, rows
+
+
+def committed_pmc(workload, L):
+    """A PMC summary committed under profiles/ for this workload, newest round first."""
+    cands = sorted((REPO / "profiles").glob("r*_pmc*.json"), reverse=True)
+    for p in cands:
+        try:
+            rec = json.loads(p.read_text())
+        except Exception:
+            continue
+        if rec.get("workload") == workload and rec.get("links") == L and rec.get("hbm_bytes_per_launch"):
+            return rec, p.name
+    return None, None
+
+
+def collect_pmc(args, kernel_family):
+    """Counter passes of this very command as child processes (one rocprofv3 pass per counter
+    group, no trace: MI355X_MICROARCH.md, HBM section), the program itself after `--`."""
+    import shutil
+    import tempfile
+
+    sys.path.insert(0, str(REPO / "tools"))
+    import pmc_collect
+
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not Path(rocprof).exists():
+        return None
+    merged, disp = {}, {}
+    base = Path(tempfile.mkdtemp(prefix="s3grl_pmc_", dir="/tmp"))
+    env = dict(os.environ, TMPDIR="/tmp")
+    for grp in (["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"]):
+        d = base / grp[0]
+        cmd = ["timeout", "-k", "10", "240", rocprof, "--pmc", *grp, "--output-format", "csv", "-d", str(d),
+               "--", sys.executable, str(REPO / "bench.py"), "--steps", "1", "--warmup", "0",
+               "--no-cpu-baseline", "--no-api", "--workload", args.workload]
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            sys.stderr.write(f"[bench] counter pass {grp} failed rc={r.returncode}\n")
+            return None
+        vals, dd = pmc_collect.read_pass(d)
+        for fam, cs in vals.items():
+            merged.setdefault(fam, {}).update(cs)
+        disp.update(dd)
+    shutil.rmtree(base, ignore_errors=True)
+    g = merged.get(kernel_family)
+    if not g or "FETCH_SIZE" not in g or "WRITE_SIZE" not in g:
+        return None
+    n = max(disp.get(kernel_family, 1), 1)
+    rec = {"kernel": kernel_family, "dispatches": n,
+           "FETCH_SIZE_KB": g["FETCH_SIZE"] / n, "WRITE_SIZE_KB": g["WRITE_SIZE"] / n,
+           "hbm_bytes_per_launch": (2.0 * g["FETCH_SIZE"] + g["WRITE_SIZE"]) * 1024.0 / n,
+           "counters": merged}
+    if "TCC_HIT_sum" in g:
+        rec["l2_hit_rate"] = g["TCC_HIT_sum"] / max(g["TCC_HIT_sum"] + g.get("TCC_MISS_sum", 0.0), 1.0)
+    return rec
 
 
 def cpu_baseline(w, link_index, y, budget_s, max_links):
@@ -96,6 +177,88 @@ def cpu_baseline_native(w, link_index, y, max_links):
                       f"C + OpenMP restatement, fp64 accumulation, {threads} threads"}
 
 
+def end_to_end_api(w, link_index, y):
+    """The same list through the reference's own operator API (s3grl_amd.tuned_SIGN, the drop-in
+    boundary): pos and neg calls per split like sgrl_link_pred.py:195-203, result = per-link Data
+    sequences with CPU tensors, then the caller's `pos_list + neg_list`.  D2H included."""
+    import torch
+
+    from s3grl_amd import tuned_SIGN as ts
+
+    xt = torch.from_numpy(w.X)
+    kw = {"sign_k": w.sign_k, "use_feature": True, "sign_type": "PoS" if w.mode != "sop" else "SoP",
+          "optimize_sign": True, "k_heuristic": 1 if w.mode == "pos_plus" else 0,
+          "k_node_set_strategy": "intersection"}
+    calls = []
+    for s in ("train", "valid", "test"):
+        pos, neg = w.split.links[s]
+        calls += [(torch.from_numpy(pos), 1), (torch.from_numpy(neg), 0)]
+
+    def one(li, yy):
+        if w.mode == "sop":
+            return ts.OptimizedSignOperations.get_SoP_prepped_ds([None] * w.sign_k, li, w.A, xt, yy)
+        fn = ts.OptimizedSignOperations.get_PoS_Plus_prepped_ds if w.mode == "pos_plus" \
+            else ts.OptimizedSignOperations.get_PoS_prepped_ds
+        return fn(li, w.num_hops, w.A, 1.0, None, False, None, xt, yy, kw, None)
+
+    import contextlib
+    import io
+
+    best = None
+    for _ in range(2):          # first pass uploads A and x and sizes the pinned staging buffer
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        total, lists = 0, []
+        with contextlib.redirect_stdout(io.StringIO()):    # the operators print their flow name
+            for li, yy in calls:
+                if li.shape[1] == 0:
+                    continue
+                lst = one(li, yy)
+                total += len(lst)
+                lists.append(lst)
+            for i in range(0, len(lists) - 1, 2):
+                _ = lists[i] + lists[i + 1]                 # sgrl_link_pred.py:204
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        first = lists[0][0]
+        _ = first.x.shape, first[f"x{w.sign_k}"].shape
+        del lists
+    ts.clear_cache()
+    return {"value": total / best, "unit": "link pairs/s", "seconds": best, "links": total,
+            "what": "OptimizedSignOperations.get_*_prepped_ds of s3grl_amd.tuned_SIGN over the 6 "
+                    "(split, pos/neg) calls + the caller's list concatenation; per-link objects "
+                    "with CPU tensors (D2H through pinned staging included)"}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher: start the N ranks as fresh child processes.
+    Nothing in this (parent) process has touched the GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    import torch   # device_count() does not initialise the GPU on this image
+
+    ndev = torch.cuda.device_count()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        if ndev < args.gpus:                 # rehearsal on a box with fewer GPUs: share them, gloo
+            env.setdefault("S3GRL_BENCH_BACKEND", "gloo")
+        procs.append(subprocess.Popen([sys.executable, str(REPO / "bench.py")] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        for p in procs:
+            rc = p.wait() or rc
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,8 +269,20 @@ def main():
     ap.add_argument("--cpu-links", type=int, default=2000)
     ap.add_argument("--cpu-native-links", type=int, default=40000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-api", action="store_true", help="skip the end_to_end_api measurement")
+    ap.add_argument("--collect-pmc", action="store_true",
+                    help="collect FETCH_SIZE / WRITE_SIZE / L2 hit rate of this command in child rocprofv3 passes")
     ap.add_argument("--max-links", type=int, default=0, help="truncate the link list (debug)")
+    ap.add_argument("--chunks", type=int, default=4,
+                    help="N > 1: pieces per rank (all-gather of piece c overlaps the compute of c+1)")
+    ap.add_argument("--no-allgather", action="store_true",
+                    help="N > 1: every rank keeps its shard (data-parallel consumer); no collective")
+    ap.add_argument("--verify", action="store_true",
+                    help="N > 1: check the reassembled tensor bit for bit against an unsharded run")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     import torch
 
@@ -132,8 +307,11 @@ def main():
 
     import __graft_entry__ as ge
 
-    ge.build()
-    from s3grl_amd import workloads
+    if rank == 0:
+        ge.build()
+    if dist is not None:
+        dist.barrier()
+    from s3grl_amd import parallel, workloads
     from s3grl_amd.engine import Engine
 
     w = workloads.make(args.workload)
@@ -147,10 +325,12 @@ def main():
     g = eng.graph(w.A)
     x = eng.features(w.X)
     links = eng.links(link_index)
+    fixed_rows = w.mode in ("pos", "sop")
 
     out = None
+    traffic_req = None
 
-    def step():
+    def step_single():
         nonlocal out
         if w.mode == "sop":
             res = eng.precompute(g, x, links, mode="sop", sign_k=K, out=out)
@@ -165,13 +345,45 @@ def main():
         plan.close()
         return st
 
+    # ---- N > 1: shard, compute, all-gather ---------------------------------------------------
+    shard_info = {}
+    if world > 1:
+        cost = parallel.khop_cost(w.A, link_index, w.num_hops) if w.mode != "sop" \
+            else parallel.link_cost(w.A, link_index)
+        li_dev = torch.as_tensor(link_index).to(eng.device)
+        gather = not args.no_allgather
+        timers = {}
+        if fixed_rows:
+            compute = parallel.engine_compute(eng, g, x, mode=w.mode, num_hops=w.num_hops, sign_k=K)
+
+            def step_sharded():
+                return parallel.sharded_precompute(
+                    compute, li_dev, rank=rank, world_size=world, cost=cost, gather=gather,
+                    rows_per_link=2, chunks=args.chunks if gather else 1, row_shape=(K + 1, F + 1),
+                    device=eng.device, timers=timers)
+        else:
+            def compute_ragged(shard):
+                res = eng.precompute(g, x, eng.links(shard), mode=w.mode, num_hops=w.num_hops, sign_k=K)
+                return res.rows, res.row_ptr
+
+            def step_sharded():
+                return parallel.sharded_precompute(compute_ragged, li_dev, rank=rank, world_size=world,
+                                                   cost=cost, gather=gather)
+        b = parallel.shard_bounds(L, world, cost)
+        shard_info = {"bounds": b, "links_per_rank": [b[r + 1] - b[r] for r in range(world)]}
+
+    def step():
+        if world > 1:
+            return step_sharded()
+        return step_single()
+
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
     stats = None
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 0)):
         stats = step()
     barrier()
     eng.set_profiling(True)
@@ -179,66 +391,236 @@ def main():
     for _ in range(args.steps):
         stats = step()
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
     tm = eng.timings()
     eng.set_profiling(False)
+    if world == 1 and w.mode != "sop" and not x.is_sparse and rank == 0:
+        # measurement, outside the timed region: the bytes the gather launch requests (exact)
+        plan = eng.plan(g, links, mode=w.mode, num_hops=w.num_hops, sign_k=K)
+        traffic_req = plan.gather_traffic(x)
+        plan.close()
+    dt = dt_local
+    per_rank = None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=eng.device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        mine = {"rank": rank, "step_ms": dt_local / args.steps * 1e3,
+                "structure_ms": tm["structure_ms"] / args.steps, "propagate_ms": tm["propagate_ms"] / args.steps,
+                "gather_ms": tm["gather_ms"] / args.steps,
+                "sop_ms": (tm["sop_setup_ms"] + tm["sop_run_ms"]) / args.steps,
+                "plans_per_step": tm["plans"] / args.steps}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+
+    verify = None
+    if world > 1 and args.verify:
+        rows_sh, ptr_sh, _ = step()
+        if fixed_rows:
+            ref = torch.empty((2 * L, K + 1, F + 1), dtype=torch.float32, device=eng.device)
+            parallel.engine_compute(eng, g, x, mode=w.mode, num_hops=w.num_hops, sign_k=K)(li_dev, ref)
+        else:
+            ref = eng.precompute(g, x, links, mode=w.mode, num_hops=w.num_hops, sign_k=K).rows
+        if args.no_allgather:
+            lo, hi = shard_info["bounds"][rank], shard_info["bounds"][rank + 1]
+            ok = fixed_rows and torch.equal(rows_sh, ref[2 * lo:2 * hi])
+        else:
+            ok = rows_sh.shape == ref.shape and torch.equal(rows_sh, ref)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int64,
+                            device=eng.device if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        verify = bool(flag.item())
+        del ref
+
+    # one all-gather of the whole padded tensor on its own, outside the timed region: what the
+    # collective costs when nothing overlaps it
+    allgather_alone = None
+    if world > 1 and fixed_rows and not args.no_allgather and backend == "nccl":
+        rmax = 2 * max(shard_info["links_per_rank"])
+        buf = torch.empty((world * rmax, K + 1, F + 1), dtype=torch.float32, device=eng.device)
+        torch.cuda.synchronize()
+        dist.barrier()
+        ts = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_gather_into_tensor(buf, buf[rank * rmax:(rank + 1) * rmax])
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        nbytes = buf.numel() * 4
+        allgather_alone = {"ms": min(ts), "bytes": nbytes,
+                           "algbw_GBps": nbytes / (min(ts) * 1e-3) / 1e9,
+                           "busbw_GBps": nbytes * (world - 1) / world / (min(ts) * 1e-3) / 1e9}
+        del buf
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = world * L * args.steps / dt
+        value = L * args.steps / dt
         line = {
             "metric": "link-pair precomputes/sec", "value": value, "unit": "link pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64" if w.mode == "sop" else "f32", "data": "synthetic",
             "config": {"workload": args.workload, "mode": w.mode, "sign_k": K, "num_hops": w.num_hops,
-                       "links_per_step_per_gpu": L, "num_nodes": w.split.num_nodes,
+                       "links_per_step": L, "num_nodes": w.split.num_nodes,
                        "features": F, "graph": "real topology, synthetic features (BASELINE.md §3)"},
         }
-        if w.mode != "sop" and stats:
+        if world > 1:
+            comp = [r["structure_ms"] + r["propagate_ms"] + r["gather_ms"] + r["sop_ms"] for r in per_rank]
+            line["multi_gpu"] = {
+                "sharding": "contiguous link ranges balanced by the number of walks of length <= num_hops "
+                            "from src and dst (parallel.khop_cost); graph + X replicated",
+                "collective": None if args.no_allgather else
+                              ("%d padded all_gather_into_tensor per step (pieces of a range are gathered on "
+                               "RCCL's stream while the next piece is computed) + compaction" % args.chunks
+                               if fixed_rows else "sizes + one padded all_gather_into_tensor + compaction"),
+                "backend": backend, "links_per_rank": shard_info["links_per_rank"],
+                "per_rank": per_rank,
+                "compute_ms_per_rank": comp,
+                "imbalance_max_over_mean": max(comp) / (sum(comp) / len(comp)) if sum(comp) > 0 else None,
+                "exposed_comm_and_host_ms": ms_per_step - max(comp),
+                "allgather_alone": allgather_alone,
+                "verified_bit_equal_to_unsharded": verify,
+                "note": "value counts the links of the WHOLE list once (strong scaling); with "
+                        "--no-allgather every rank keeps its shard (what a data-parallel trainer "
+                        "consumes) and no collective runs",
+            }
+        if world == 1 and w.mode != "sop" and stats:
             path_bytes, gather_all, gather_bytes = algorithmic_bytes(stats, F, K)
             launches = max(tm["gather_launches"], 1.0)
             gather_ms = tm["gather_ms"] / launches
-            achieved = gather_bytes / (gather_ms * 1e-3) / 1e9 if gather_ms > 0 else 0.0
-            traffic = None
-            pmc = REPO / "profiles" / "pmc_latest.json"
-            if pmc.exists():
-                try:
-                    rec = json.loads(pmc.read_text())
-                    if rec.get("workload") == args.workload and rec.get("links") == L:
-                        traffic = rec.get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
+            kname = "gather_packed_kernel" if x.is_packed else "gather_kernel"
+            traffic, traffic_source, l2_hit = None, None, None
+            if args.collect_pmc:
+                rec = collect_pmc(args, kname)
+                if rec:
+                    traffic, l2_hit = rec["hbm_bytes_per_launch"], rec.get("l2_hit_rate")
+                    traffic_source = "collected by this run: child rocprofv3 --pmc passes of the same command"
+                    line["pmc"] = {k: rec[k] for k in rec if k != "counters"}
+                    line["pmc_counters"] = rec["counters"]
+            if traffic is None:
+                rec, name = committed_pmc(args.workload, L)
+                if rec:
+                    traffic, l2_hit = rec["hbm_bytes_per_launch"], rec.get("l2_hit_rate")
+                    traffic_source = f"profiles/{name} (an earlier run of this workload, NOT this run)"
+            req = traffic_req or {}
+            operand_bytes = (x.nnz * 16 + 32 * w.X.shape[0] * ((F + 511) // 512)) if x.is_packed \
+                else 4 * w.X.shape[0] * ((F + 3) // 4 * 4)
+            requested = sum(req.get(k, 0) for k in ("ids", "headers", "features", "coefficients", "output",
+                                                    "x_rows", "job_meta"))
+            stream = sum(req.get(k, 0) for k in ("ids", "coefficients", "output"))
+            mall_peak = MALL_ROWS_GBS if operand_bytes <= (64 << 20) else \
+                (MALL_ROWS_BIG_GBS if operand_bytes <= MALL_BYTES else HBM_PEAK_GBS)
+            levels = [
+                ("l2", requested or None, L2_PEAK_GBS,
+                 "every byte the kernel's loads and stores request (exact, from the plan: node ids, "
+                 "row headers, feature chunks, coefficients, operator-0 rows, output) against the "
+                 "aggregate L2 bandwidth"),
+                ("fabric", traffic, mall_peak,
+                 "bytes that leave the L2s (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE: Infinity-Cache hits "
+                 "included; the x2 is the guide's correction for full 16-byte-per-lane reads, an upper "
+                 "bound here) against the Infinity-Cache random-row rate for an operand of %.0f MB"
+                 % (operand_bytes / 1e6)),
+                ("hbm", stream or None, HBM_PEAK_GBS,
+                 "bytes that must cross HBM: the node-id and coefficient lists the link kernels wrote "
+                 "(GBs, read once) and the output (written once); the feature operand itself stays in "
+                 "the Infinity Cache" if operand_bytes <= MALL_BYTES else
+                 "bytes that must cross HBM: id/coefficient lists, output"),
+            ]
+            best, rows = hierarchical_roofline(levels, gather_ms)
             line["roofline"] = {
-                "bound": "hbm", "kernel": "gather_packed_kernel" if getattr(x, "is_packed", False) else "gather_kernel",
-                "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_GBps": (traffic / (gather_ms * 1e-3) / 1e9) if (traffic and gather_ms > 0) else None,
-                "algorithmic_bytes_per_launch": gather_bytes, "kernel_ms": gather_ms,
-                "algorithmic_bytes_all_links": gather_all,
-                "path_algorithmic_bytes_per_step": path_bytes,
-                "path_achieved_GBps": path_bytes / (ms_per_step * 1e-3) / 1e9,
+                "kernel": kname, "kernel_ms": gather_ms,
+                "bound": best["level"], "achieved": best["GBps"], "peak": best["peak_GBps"], "unit": "GB/s",
+                "frac": best["frac"], "levels": rows,
+                "traffic": traffic, "traffic_source": traffic_source, "l2_hit_rate": l2_hit,
+                "requested_bytes": req, "physical_bytes": requested,
+                "feature_operand_bytes": operand_bytes,
+                "algorithmic": {
+                    "bytes_per_launch": gather_bytes, "GBps": gather_bytes / (gather_ms * 1e-3) / 1e9,
+                    "frac_of_hbm_peak": gather_bytes / (gather_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "bytes_all_links": gather_all, "path_bytes_per_step": path_bytes,
+                    "path_GBps": path_bytes / (ms_per_step * 1e-3) / 1e9,
+                    "note": "SURVEY §8(d) contract figure on DENSE fp32 rows of X, every gathered link: "
+                            "4nF + 4R(K+1)(1+F).  It is not traffic: the packed operand stores only the "
+                            "non-zero 16-byte chunks and X sits in the Infinity Cache, so this rate can "
+                            "exceed the HBM peak; `frac` above is computed from physical bytes"},
                 "phase_ms": {"structure": tm["structure_ms"] / max(tm["plans"], 1.0),
                              "propagate": tm["propagate_ms"] / max(tm["plans"], 1.0),
                              "gather": gather_ms},
+                "link_kernels": {
+                    "ms": tm["propagate_ms"] / max(tm["plans"], 1.0),
+                    "algorithmic_bytes": 8 * stats["extracted_nodes"] + 4 * stats["total_volume"],
+                    "note": "8n + 4 vol(S) once per extracted link (SURVEY §8d CSR terms); bound by VALU "
+                            "issue / dependent-load latency, not bytes (DESIGN §4)"},
                 "mean_subgraph_nodes": stats["total_nodes"] / max(L, 1),
                 "folded_links": stats.get("folded_links", 0),
-                "note": "achieved = algorithmic bytes of the links the gather launch processes / its "
-                        "HIP-event duration; links that are the reversed duplicate of an earlier link "
-                        "(both directions of a train edge) are served by that link's extraction and "
-                        "are NOT counted here (path_* figures count every link, SURVEY 8d). The figure is "
-                        "ALGORITHMIC bytes (dense fp32 rows of X, SURVEY 8d) per second, not physical "
-                        "traffic: X sits in the 256 MB Infinity Cache, and when X is sparse (TF-IDF / "
-                        "bag-of-words rows) the packed-row kernel fetches only its non-zero 16-byte chunks "
-                        "(`traffic` = measured fabric bytes per launch), so achieved can exceed the HBM peak",
                 "feature_operand": ("packed rows: %d non-zero 16-byte chunks of %d" % (x.nnz, w.X.shape[0] * ((F + 3) // 4)))
-                                   if getattr(x, "is_packed", False) else "dense rows",
+                                   if x.is_packed else "dense rows",
             }
-        if not args.no_cpu_baseline:
+        if world == 1 and w.mode == "sop":
+            runs = max(tm["sop_runs"], 1.0)
+            rows_ms = tm["sop_rows_ms"] / runs
+            N = w.split.num_nodes
+            ldy = (F + 1) // 2 * 2
+            req_read = L * (2 * (K + 1) * 8 * F + 3 * 8 * K + 16)
+            out_bytes = L * 2 * (K + 1) * 4 * (F + 1)
+            table = (K + 1) * N * ldy * 8
+            traffic, traffic_source, l2_hit = None, None, None
+            if args.collect_pmc:
+                rec = collect_pmc(args, "sop_rows_kernel")
+                if rec:
+                    traffic, l2_hit = rec["hbm_bytes_per_launch"], rec.get("l2_hit_rate")
+                    traffic_source = "collected by this run: child rocprofv3 --pmc passes of the same command"
+                    line["pmc"] = {k: rec[k] for k in rec if k != "counters"}
+                    line["pmc_counters"] = rec["counters"]
+            if traffic is None:
+                rec, name = committed_pmc(args.workload, L)
+                if rec:
+                    traffic, l2_hit = rec["hbm_bytes_per_launch"], rec.get("l2_hit_rate")
+                    traffic_source = f"profiles/{name} (an earlier run of this workload, NOT this run)"
+            levels = [
+                ("l2", req_read + out_bytes, L2_PEAK_GBS,
+                 "bytes requested: f64 rows Y_i[src], Y_i[dst], i = 0..K, + scalars, + the f32 output"),
+                ("hbm", traffic if traffic else out_bytes + min(table, req_read), HBM_PEAK_GBS,
+                 ("measured bytes beyond L2 (FETCH_SIZE x2 + WRITE_SIZE)" if traffic else
+                  "lower bound of the bytes that cross HBM: the output once + every row of the f64 "
+                  "Y table once") + "; the table (%.0f MB) exceeds the 256 MB Infinity Cache" % (table / 1e6)),
+            ]
+            best, rws = hierarchical_roofline(levels, rows_ms)
+            setup_ms = tm["sop_setup_ms"] / max(tm["sop_setups"], 1.0)
+            spmm_ms = tm["sop_spmm_ms"] / max(tm["sop_setups"], 1.0)
+            nnz = int(w.A.nnz)
+            spmm_alg = K * (4 * nnz + 16 * N * F)
+            alg_link = 4 * F * (2 * K + 2) + 8 * (K + 1) * (F + 1)
+            line["roofline"] = {
+                "kernel": "sop_rows_kernel", "kernel_ms": rows_ms,
+                "bound": best["level"], "achieved": best["GBps"], "peak": best["peak_GBps"], "unit": "GB/s",
+                "frac": best["frac"], "levels": rws,
+                "traffic": traffic, "traffic_source": traffic_source, "l2_hit_rate": l2_hit,
+                "algorithmic": {
+                    "bytes_per_link": alg_link, "bytes_per_launch": alg_link * L,
+                    "GBps": alg_link * L / (rows_ms * 1e-3) / 1e9 if rows_ms > 0 else None,
+                    "note": "SURVEY §8(d) SoP figure in fp32 terms: 4F(2K+2) + 8(K+1)(1+F) per link "
+                            "(the scalar-ball CSR term is reported with the scalar phase); the kernel "
+                            "reads the Y rows in f64 (exact cancellation, DESIGN §2), twice those bytes"},
+                "phase_ms": {"setup_total": setup_ms, "setup_spmm": spmm_ms,
+                             "run_total": tm["sop_run_ms"] / runs, "rows_kernel": rows_ms,
+                             "ball_scalars": tm["sop_run_ms"] / runs - rows_ms},
+                "setup": {"kernel": "spmm_norm_kernel x K", "ms": spmm_ms,
+                          "algorithmic_bytes": spmm_alg,
+                          "GBps": spmm_alg / (spmm_ms * 1e-3) / 1e9 if spmm_ms > 0 else None,
+                          "frac_of_hbm_peak": spmm_alg / (spmm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if spmm_ms > 0 else None,
+                          "note": "K (4 nnz + 16 N F): f64 Y read and written once per operator "
+                                  "(SURVEY §8d setup term, f64); included in value like the reference's "
+                                  "timed region includes its global powers"},
+            }
+        if world == 1 and not args.no_api:
+            try:
+                line["end_to_end_api"] = end_to_end_api(w, link_index, y)
+            except Exception as e:   # the bench line must not die on the optional leg
+                line["end_to_end_api"] = {"error": repr(e)}
+        if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w, link_index, y, args.cpu_seconds, args.cpu_links)
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
             if w.mode != "sop":

@@ -32,21 +32,25 @@
 extern "C" {
 #endif
 
-#define S3GRL_ABI_VERSION 2
+#define S3GRL_ABI_VERSION 3
 
 typedef enum s3grl_status {
   S3GRL_OK = 0,
-  S3GRL_ERR_INVALID_ARGUMENT = 1, /* null pointer, negative size, sign_k < 1, link id out of range */
+  S3GRL_ERR_INVALID_ARGUMENT = 1, /* null pointer, negative size, sign_k < 1, link id out of range,
+                                     malformed CSR (indptr not monotone, column id outside
+                                     [0,N), a row not strictly ascending) */
   S3GRL_ERR_NOT_IMPLEMENTED = 2,  /* maps to the reference's NotImplementedError:
                                      k_node_set_strategy other than "intersection"
                                      (tuned_SIGN.py:235; "union" is unusable as shipped),
-                                     directed graphs, per-hop sampling */
+                                     directed graphs (A_csc) */
   S3GRL_ERR_NO_FEATURES = 3,      /* X == NULL: the reference's `assert subgraph_features is not
                                      None` (tuned_SIGN.py:166,221) */
   S3GRL_ERR_OUT_OF_MEMORY = 4,
   S3GRL_ERR_HIP = 5,              /* a HIP runtime call failed; see s3grl_last_error() */
   S3GRL_ERR_NO_DEVICE = 6,        /* no gfx950 device visible */
-  S3GRL_ERR_GRAPH_TOO_LARGE = 7,  /* num_nodes above the LDS-bitmap limit of this build */
+  S3GRL_ERR_GRAPH_TOO_LARGE = 7,  /* nnz or num_nodes >= 2^31; per-hop sampling or SoP on a graph
+                                     whose N-bit LDS bitmaps exceed 160 KiB (num_nodes > 327 680);
+                                     a SoP ball that does not fit LDS */
   S3GRL_ERR_SELF_LINK = 8         /* src == dst: the reference duplicates the node; unsupported */
 } s3grl_status;
 
@@ -125,8 +129,12 @@ s3grl_status s3grl_context_create(int32_t device, void* stream, s3grl_context** 
 s3grl_status s3grl_context_destroy(s3grl_context* ctx);
 
 /* CSR of A as scipy holds it (reference sgrl_link_pred.py:111-114): indptr [N+1], indices
- * [nnz] sorted within a row; the matrix must be structurally symmetric (undirected train
- * graph).  The arrays are copied; the caller may free them afterwards. */
+ * [nnz] strictly ascending within a row (canonical format: sorted, duplicates summed); the
+ * matrix must be structurally symmetric (undirected train graph).  The arrays are copied; the
+ * caller may free them afterwards.  The structure is validated on the device (indptr[0] == 0,
+ * indptr monotone and ending at nnz, ids in [0,N), rows strictly ascending):
+ * S3GRL_ERR_INVALID_ARGUMENT otherwise.  Symmetry is the caller's promise (the Python binding
+ * checks it). */
 s3grl_status s3grl_graph_create(s3grl_context* ctx, int64_t num_nodes, const int64_t* indptr,
                                 const int32_t* indices, int64_t nnz, s3grl_graph** out);
 s3grl_status s3grl_graph_destroy(s3grl_graph* g);
@@ -193,7 +201,8 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
  * operator_diff), rows of link b = row_ptr[b]..row_ptr[b+1], the first two being src, dst.
  * mode 0 (k_heuristic == 0): out [B, H] = h[src] * h[dst];  mode 1 / 2 (k_pool_strategy 'mean' /
  * 'sum'): out [B, 2H] = [h[src] * h[dst] | mean or sum of the remaining rows], zeros when a link
- * has none (the reference's `size=B`).  'concat' is not implemented.  No host sync (the
+ * has none (the reference's `size=B`).  'concat' (models.py:363-367) is mode 0 plus a strided
+ * view of the k rows, done by the Python binding (s3grl_amd/pool.py).  No host sync (the
  * reference does np.unique on the CPU per batch, models.py:341).  backward: grad_h [total_rows,
  * H] is fully overwritten. */
 s3grl_status s3grl_centre_pool_forward(s3grl_context* ctx, const float* h, const int64_t* row_ptr,
@@ -206,10 +215,30 @@ s3grl_status s3grl_centre_pool_backward(s3grl_context* ctx, const float* h, cons
  * from HIP events recorded on the context's stream around the kernels themselves:
  * what[0]=structure (count+scan+build+jobs), [1]=propagate, [2]=gather (the dominant kernel),
  * [3]=sop setup, [4]=sop run, [5]=number of gather launches in [2], [6]=number of plans in
- * [0],[1], [7]=number of sop runs in [4].  Host array of 8 doubles. */
+ * [0],[1], [7]=number of sop runs in [4], [8]=sop_rows_kernel alone (part of [4]),
+ * [9]=the spmm_norm_kernel launches alone (part of [3]), [10]=number of sop setups in [3],
+ * [11..15] reserved (0).  Host array of 16 doubles. */
 s3grl_status s3grl_context_timings(s3grl_context* ctx, double* what);
 /* switch the HIP-event timing on/off and zero the accumulators (off by default) */
 s3grl_status s3grl_context_set_profiling(s3grl_context* ctx, int32_t enabled);
+
+/* Gives the workspace blocks the context caches between calls (plans, stashes, scratch: several
+ * GB after a PubMed-scale plan) back to the HIP allocator; blocks of live handles stay.  Call it
+ * when the precompute phase is over and the training step needs the memory. *released (host,
+ * may be NULL) = bytes freed. */
+s3grl_status s3grl_context_trim(s3grl_context* ctx, int64_t* released);
+
+/* Measurement: the bytes the gather launch of `p` on operand `f` REQUESTS, computed exactly from
+ * the plan (no timing, no sampling): what[0] = node-id bytes (4 per list entry and column tile),
+ * [1] = packed-row header bytes (32 per entry and tile; 0 for a dense operand), [2] = feature
+ * bytes (packed: 16 per non-zero chunk of every gathered row; dense: the 16-byte lane loads that
+ * fall inside the row), [3] = coefficient bytes (8 per entry, operator and tile actually read:
+ * the packed kernel reads only the last operator beyond the prefix the others can reach),
+ * [4] = output bytes written (folded reversed duplicates included), [5] = operator-0 rows of X
+ * read for the output, [6] = per-job metadata bytes, [7] = wavefronts launched.
+ * Host array of 8 int64.  Synchronises the context's stream. */
+s3grl_status s3grl_plan_gather_traffic(s3grl_context* ctx, const s3grl_plan* p,
+                                       const s3grl_features* f, int64_t* what);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,7 @@ STRATEGY = {"intersection": 0, "union": 1}
 SYMBOLS = [
     "s3grl_abi_version", "s3grl_status_string", "s3grl_last_error",
     "s3grl_context_create", "s3grl_context_destroy", "s3grl_context_timings",
-    "s3grl_context_set_profiling",
+    "s3grl_context_set_profiling", "s3grl_context_trim", "s3grl_plan_gather_traffic",
     "s3grl_graph_create", "s3grl_graph_destroy",
     "s3grl_plan_create", "s3grl_plan_destroy", "s3grl_plan_get_stats", "s3grl_plan_row_ptr",
     "s3grl_plan_row_nodes", "s3grl_plan_export_subgraphs", "s3grl_run",
@@ -47,7 +47,7 @@ class Cfg(C.Structure):
                 ("reserved", C.c_int32 * 4)]
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 FLAG_FULL_STATS, FLAG_NO_FOLD = 1, 2
 
 
@@ -96,6 +96,8 @@ def lib():
         "s3grl_context_destroy": [vp],
         "s3grl_context_timings": [vp, C.POINTER(C.c_double)],
         "s3grl_context_set_profiling": [vp, i32],
+        "s3grl_context_trim": [vp, C.POINTER(i64)],
+        "s3grl_plan_gather_traffic": [vp, vp, vp, C.POINTER(i64)],
         "s3grl_graph_create": [vp, i64, vp, vp, i64, C.POINTER(vp)],
         "s3grl_graph_destroy": [vp],
         "s3grl_plan_create": [vp, vp, vp, i64, C.POINTER(Cfg), C.POINTER(vp)],

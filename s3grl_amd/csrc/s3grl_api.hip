@@ -49,6 +49,17 @@ s3grl_status Arena::alloc(size_t bytes, void** out) {
   return S3GRL_OK;
 }
 
+size_t Arena::trim() {
+  size_t freed = 0;
+  for (auto& kv : free_) {
+    (void)hipFree(kv.second);
+    freed += kv.first;
+  }
+  free_.clear();
+  held_ -= freed;
+  return freed;
+}
+
 void Arena::release(void* p) {
   if (!p) return;
   auto it = live_.find(p);
@@ -63,6 +74,30 @@ __global__ void indptr_to_i32_kernel(const int64_t* __restrict__ in, int64_t n,
                                      int32_t* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (int32_t)in[i];
+}
+
+// structure check of a caller's CSR: bit 0 indptr not monotone / not ending at nnz / not starting
+// at 0, bit 1 a column id outside [0,N), bit 2 a row not strictly ascending (unsorted or duplicate)
+__global__ void validate_csr_kernel(const int32_t* __restrict__ indptr,
+                                    const int32_t* __restrict__ indices, int64_t n, int64_t nnz,
+                                    int64_t* __restrict__ flags) {
+  int bad = 0;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n;
+       v += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = indptr[v], e = indptr[v + 1];
+    if (b > e || b < 0 || e > nnz || (v == 0 && b != 0) || (v == n - 1 && e != nnz)) {
+      bad |= 1;
+      continue;
+    }
+    int prev = -1;
+    for (int64_t c = b; c < e; ++c) {
+      const int u = indices[c];
+      if (u < 0 || u >= n) bad |= 2;
+      if (u <= prev) bad |= 4;
+      prev = u;
+    }
+  }
+  if (bad) atomicOr(reinterpret_cast<unsigned long long*>(flags), (unsigned long long)bad);
 }
 
 __global__ void max_degree_kernel(const int32_t* __restrict__ indptr, int64_t n, int64_t* out) {
@@ -224,7 +259,21 @@ s3grl_status s3grl_graph_create(s3grl_context* ctx, int64_t num_nodes, const int
   if (nnz)
     S3GRL_HIP_TRY(hipMemcpyAsync(g->indices, indices, (size_t)nnz * 4, hipMemcpyDeviceToDevice,
                                  ctx->stream));
-  S3GRL_HIP_TRY(hipMemsetAsync(ctx->d_scalars, 0, 8, ctx->stream));
+  S3GRL_HIP_TRY(hipMemsetAsync(ctx->d_scalars, 0, 16, ctx->stream));
+  // the kernels index LDS bitmaps with the column ids and search rows by bisection: a malformed
+  // CSR would corrupt memory or give silently wrong rows, so it is rejected here
+  hipLaunchKernelGGL(validate_csr_kernel, dim3(512), dim3(256), 0, ctx->stream, g->indptr, g->indices,
+                     num_nodes, nnz, ctx->d_scalars + 1);
+  S3GRL_HIP_TRY(hipGetLastError());
+  S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_scalars + 1, ctx->d_scalars + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (const int64_t bad = ctx->h_scalars[1]) {
+    set_last_error(std::string("malformed CSR:") + ((bad & 1) ? " indptr is not monotone from 0 to nnz;" : "") +
+                   ((bad & 2) ? " a column id is outside [0, num_nodes);" : "") +
+                   ((bad & 4) ? " a row is not strictly ascending (unsorted or duplicate entries);" : ""));
+    s3grl_graph_destroy(g);
+    return S3GRL_ERR_INVALID_ARGUMENT;
+  }
   hipLaunchKernelGGL(max_degree_kernel, dim3(256), dim3(256), 0, ctx->stream, g->indptr, num_nodes,
                      ctx->d_scalars);
   S3GRL_HIP_TRY(hipGetLastError());
@@ -486,6 +535,33 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
     ctx->timings[6] += 1.0;
   }
   *out = plan.release();
+  return S3GRL_OK;
+}
+
+s3grl_status s3grl_context_trim(s3grl_context* ctx, int64_t* released) {
+  if (!ctx) return S3GRL_ERR_INVALID_ARGUMENT;
+  S3GRL_HIP_TRY(hipSetDevice(ctx->device));
+  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));   // cached blocks may still be read by queued work
+  for (auto& st : ctx->side)
+    if (st) S3GRL_HIP_TRY(hipStreamSynchronize(st));
+  const size_t freed = ctx->arena.trim();
+  if (released) *released = (int64_t)freed;
+  return S3GRL_OK;
+}
+
+s3grl_status s3grl_plan_gather_traffic(s3grl_context* ctx, const s3grl_plan* p,
+                                       const s3grl_features* f, int64_t* what) {
+  if (!ctx || !p || !f || !what) return S3GRL_ERR_INVALID_ARGUMENT;
+  S3GRL_HIP_TRY(hipSetDevice(ctx->device));
+  for (int i = 0; i < 8; ++i) what[i] = 0;
+  if (p->njobs == 0) return S3GRL_OK;
+  if (f->N != p->graph->num_nodes) return S3GRL_ERR_INVALID_ARGUMENT;
+  S3GRL_HIP_TRY(hipMemsetAsync(ctx->d_scalars, 0, 8 * sizeof(int64_t), ctx->stream));
+  S3GRL_TRY(launch_gather_traffic(ctx, p, f, reinterpret_cast<unsigned long long*>(ctx->d_scalars)));
+  S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 8 * sizeof(int64_t), hipMemcpyDeviceToHost,
+                               ctx->stream));
+  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 8; ++i) what[i] = ctx->h_scalars[i];
   return S3GRL_OK;
 }
 

@@ -75,6 +75,7 @@ class Arena {
   ~Arena();
   s3grl_status alloc(size_t bytes, void** out);
   void release(void* p);
+  size_t trim();   // hipFree every cached (not live) block; returns the bytes given back
   size_t bytes_held() const { return held_; }
 
  private:
@@ -91,8 +92,8 @@ struct s3grl_context {
   s3grl::Arena arena;
   bool profiling = false;
   bool gather_pending = false;  // ev[3], ev[4] recorded but not yet read
-  double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double timings[16] = {0};
+  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // side streams for launches that do not depend on each other (the link kernels of the LDS
   // classes): forked from and joined back into `stream` with events, created on first use
   static constexpr int kSide = 3;
@@ -232,6 +233,8 @@ s3grl_status launch_gather(s3grl_context* ctx, const Job* jobs, int64_t njobs, c
 s3grl_status build_packed_rows(s3grl_context* ctx, s3grl_features* f, double max_density);
 s3grl_status launch_gather_packed(s3grl_context* ctx, const s3grl_plan* p, const s3grl_features* f,
                                   float* rows);
+s3grl_status launch_gather_traffic(s3grl_context* ctx, const s3grl_plan* p, const s3grl_features* f,
+                                   unsigned long long* d_out /* [8] device, zeroed */);
 s3grl_status launch_gather_sparse(s3grl_context* ctx, const s3grl_plan* p, const s3grl_features* f,
                                   float* rows);
 s3grl_status launch_copy_pad(s3grl_context* ctx, const float* X, int64_t ldx, int64_t N, int64_t F,

@@ -337,6 +337,61 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
                                                      blockIdx.y == 0);
 }
 
+// Measurement only (s3grl_plan_gather_traffic): the bytes the gather launch of a plan requests,
+// summed exactly over its jobs with the same phase arithmetic the kernels use.  One wavefront per
+// job; out[0..7] as documented in include/s3grl.h.
+__global__ __launch_bounds__(256) void gather_traffic_kernel(
+    const Job* __restrict__ jobs, int njobs, const int32_t* __restrict__ c_ids,
+    const int32_t* __restrict__ job_lim, int K, int packed, const PackedHdr* __restrict__ hdr,
+    int64_t N, int F, unsigned long long* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int jid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (jid >= njobs) return;
+  const Job job = jobs[jid];
+  const int cnt = job.support;
+  const int32_t* __restrict__ ids = c_ids + job.ids_off;
+  const int tile_cols = packed ? kTile : (F <= 256 ? 256 : 512);
+  const int tiles = (F + tile_cols - 1) / tile_cols;
+  const unsigned long long chunks_row = (unsigned long long)((F + 3) / 4);   // 16-byte loads inside a row
+  unsigned long long feat = 0;
+  if (packed) {
+    for (int j = lane; j < cnt; j += 64) {
+      const int id = ids[j];
+      for (int t = 0; t < tiles; ++t) {
+        const PackedHdr h = hdr[(int64_t)t * N + id];
+        feat += 16ull * (unsigned long long)(__popcll(h.m0) + __popcll(h.m1));
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) feat += __shfl_xor(feat, o);
+  } else {
+    feat = 16ull * chunks_row * (unsigned long long)cnt;
+  }
+  if (lane != 0) return;
+  // coefficient entries read per tile: the packed kernel applies every operator to the phase-A
+  // prefix and only the last one beyond it (see gather_packed_kernel); the dense kernel all K
+  unsigned long long coef_entries = (unsigned long long)K * cnt;
+  if (packed) {
+    constexpr int U = 4;
+    const int ngf = cnt / U;
+    const int limA = K >= 2 ? job_lim[(int64_t)jid * K + (K - 2)] : 0;
+    const int gA = min(ngf, (limA + U - 1) / U);
+    const bool tail_in_A = limA > ngf * U;
+    const int nA = tail_in_A ? cnt : gA * U;
+    coef_entries = (unsigned long long)K * nA + (unsigned long long)(cnt - nA);
+  }
+  const int nrow = job.node_b >= 0 ? 2 : 1;
+  const int ncopy = job.mirror_row >= 0 ? 2 : 1;
+  atomicAdd(&out[0], 4ull * cnt * tiles);
+  atomicAdd(&out[1], packed ? 32ull * cnt * tiles : 0ull);
+  atomicAdd(&out[2], feat);
+  atomicAdd(&out[3], 8ull * coef_entries * tiles);
+  atomicAdd(&out[4], 4ull * nrow * ncopy * (K + 1) * (unsigned long long)(F + 1));
+  atomicAdd(&out[5], 16ull * chunks_row * nrow);
+  atomicAdd(&out[6], (unsigned long long)tiles * (sizeof(Job) + 4ull * K + 4ull) + 8ull * K);
+  atomicAdd(&out[7], (unsigned long long)tiles);
+}
+
 template <int K>
 s3grl_status launch_packed_k(s3grl_context* ctx, const s3grl_plan* p, const s3grl_features* f,
                              float* rows) {
@@ -392,6 +447,20 @@ s3grl_status build_packed_rows(s3grl_context* ctx, s3grl_features* f, double max
   f->pk_hdr = hdr;
   f->pk_data = data;
   f->packed = true;
+  return S3GRL_OK;
+}
+
+s3grl_status launch_gather_traffic(s3grl_context* ctx, const s3grl_plan* p, const s3grl_features* f,
+                                   unsigned long long* d_out) {
+  if (p->njobs == 0) return S3GRL_OK;
+  if (f->sparse) {
+    set_last_error("gather traffic accounting covers the dense and the packed operand");
+    return S3GRL_ERR_NOT_IMPLEMENTED;
+  }
+  hipLaunchKernelGGL(gather_traffic_kernel, dim3((unsigned)((p->njobs + 3) / 4)), dim3(256), 0, ctx->stream,
+                     p->jobs, (int)p->njobs, p->c_ids, p->job_lim, p->cfg.sign_k, f->packed ? 1 : 0,
+                     static_cast<const PackedHdr*>(f->pk_hdr), f->N, (int)f->F, d_out);
+  S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
 

@@ -312,6 +312,7 @@ s3grl_status s3grl_sop_create(s3grl_context* ctx, const s3grl_graph* g, const fl
   const int64_t total = N * s->ldy;
   hipLaunchKernelGGL(to_f64_pad_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 8192)),
                      dim3(256), 0, ctx->stream, X, ldx, N, F, s->Y, s->ldy);
+  if (ctx->profiling) S3GRL_HIP_TRY(hipEventRecord(ctx->ev[5], ctx->stream));
   for (int i = 1; i <= K; ++i)
     hipLaunchKernelGGL(spmm_norm_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ctx->stream,
                        g->indptr, g->indices, s->dinv, s->Y + (int64_t)(i - 1) * N * s->ldy,
@@ -323,6 +324,9 @@ s3grl_status s3grl_sop_create(s3grl_context* ctx, const s3grl_graph* g, const fl
     float ms = 0;
     S3GRL_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
     ctx->timings[3] += ms;
+    S3GRL_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[1]));
+    ctx->timings[9] += ms;
+    ctx->timings[10] += 1.0;
   }
   *out = s.release();
   return S3GRL_OK;
@@ -429,6 +433,7 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
 #undef S3GRL_SOP_LAUNCH
     S3GRL_HIP_TRY(hipGetLastError());
   }
+  if (ctx->profiling) S3GRL_HIP_TRY(hipEventRecord(ctx->ev[5], ctx->stream));
   hipLaunchKernelGGL(sop_rows_kernel, dim3((unsigned)((L + 3) / 4)), dim3(256), 0, ctx->stream, links,
                      L, s->Y, g->num_nodes, s->ldy, (int)s->F, K, scal, rows);
   S3GRL_HIP_TRY(hipGetLastError());
@@ -439,6 +444,8 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
     S3GRL_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
     ctx->timings[4] += ms;
     ctx->timings[7] += 1.0;
+    S3GRL_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[1]));
+    ctx->timings[8] += ms;
   }
   return S3GRL_OK;
 }

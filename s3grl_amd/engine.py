@@ -158,6 +158,15 @@ class Plan:
                     "s3grl_run")
         return out
 
+    def gather_traffic(self, feat):
+        """Bytes the gather launch of this plan on the prepared operand `feat` requests, exact
+        (measurement only; see s3grl_plan_gather_traffic in include/s3grl.h)."""
+        buf = (C.c_int64 * 8)()
+        N.check(N.lib().s3grl_plan_gather_traffic(self.engine._ctx, self._h, feat._h, buf),
+                "s3grl_plan_gather_traffic")
+        keys = ["ids", "headers", "features", "coefficients", "output", "x_rows", "job_meta", "waves"]
+        return {k: int(buf[i]) for i, k in enumerate(keys)}
+
     def close(self):
         if getattr(self, "_h", None):
             if self.engine._ctx:          # the context owns the arena the handle points into
@@ -350,11 +359,18 @@ class Engine:
         N.check(N.lib().s3grl_context_set_profiling(self._ctx, int(bool(on))), "set_profiling")
 
     def timings(self):
-        buf = (C.c_double * 8)()
+        buf = (C.c_double * 16)()
         N.check(N.lib().s3grl_context_timings(self._ctx, buf), "s3grl_context_timings")
         keys = ["structure_ms", "propagate_ms", "gather_ms", "sop_setup_ms", "sop_run_ms",
-                "gather_launches", "plans", "sop_runs"]
+                "gather_launches", "plans", "sop_runs", "sop_rows_ms", "sop_spmm_ms", "sop_setups"]
         return {k: float(buf[i]) for i, k in enumerate(keys)}
+
+    def trim(self):
+        """Give the workspace blocks cached between calls back to the HIP allocator (call it when
+        the precompute phase is over and training needs the memory); returns the bytes freed."""
+        n = C.c_int64()
+        N.check(N.lib().s3grl_context_trim(self._ctx, C.byref(n)), "s3grl_context_trim")
+        return int(n.value)
 
     def close(self):
         if getattr(self, "_ctx", None):

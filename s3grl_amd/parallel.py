@@ -2,13 +2,24 @@
 
 One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI).  Graph and X are
 replicated on every rank; each rank runs the engine on a contiguous, cost-balanced range of the
-link list.  A collective is only needed when the consumer wants the whole result on every rank:
-`sharded_precompute(..., gather=True)` then does one small all-gather of the per-rank row counts
-and ONE padded `all_gather_into_tensor` of the rows (equal-sized shards; each shard crosses each
-xGMI link once).  The compute callable is injected so the sharding/collective logic can be tested
-on CPU with gloo.
+link list (reference tuned_SIGN.py:147-187: the loop bodies share no state).  The one exchange
+step is the reassembly of the result on every rank: padded `all_gather_into_tensor` calls (equal
+sized contributions: a single RCCL all-gather, each rank's slice crossing each xGMI link once)
+followed by a compaction of the padded slices into the reference's order.
+
+Two flavours:
+
+* fixed rows per link (PoS, SoP, hybrid: 2 rows) — every size is known from the shard bounds, so
+  nothing is exchanged but the rows themselves, and a rank's range can be cut into `chunks`
+  pieces whose all-gathers run on RCCL's stream while the next piece is being computed;
+* ragged (PoS Plus) — one small all-gather of the per-rank row counts first.
+
+The compute callable is injected, so the sharding / collective logic is tested on CPU with gloo
+and the same code runs the engine on the GPU (`engine_compute`).
 """
 from __future__ import annotations
+
+import time
 
 import numpy as np
 import torch
@@ -26,7 +37,7 @@ def shard_bounds(num_links, world_size, cost=None):
     for r in range(1, world_size):
         b.append(int(np.searchsorted(c, total * r / world_size, side="left")))
     b.append(num_links)
-    return [min(max(x, 0), num_links) for x in np.maximum.accumulate(b)]
+    return [int(min(max(x, 0), num_links)) for x in np.maximum.accumulate(b)]
 
 
 def link_cost(A, link_index):
@@ -36,18 +47,65 @@ def link_cost(A, link_index):
     return deg[li[0]] + deg[li[1]] + 1
 
 
-def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, group=None, gather=True):
-    """`compute(link_index_shard) -> (rows [R_r, ...], row_ptr [L_r + 1])` on this rank's device.
+def khop_cost(A, link_index, num_hops):
+    """Better proxy for num_hops >= 2: the number of walks of length <= num_hops leaving src and
+    dst (powers of the degree vector, O(num_hops * nnz) once) — an upper bound of the subgraph's
+    node count that tracks it far better than the endpoint degrees on graphs with hubs."""
+    B = (A != 0).astype(np.float64)
+    w = np.ones(A.shape[0])
+    tot = np.ones(A.shape[0])
+    for _ in range(max(int(num_hops), 1)):
+        w = B @ w
+        tot += w
+    li = np.asarray(link_index)
+    return tot[li[0]] + tot[li[1]]
 
-    Returns (rows, row_ptr) of the WHOLE list on every rank when `gather`, else the local shard
-    plus its (begin, end) range.
-    """
+
+def chunk_bounds(lo, hi, chunks, cost=None):
+    """Cut [lo, hi) into `chunks` contiguous cost-balanced pieces (empty pieces allowed)."""
+    c = None if cost is None else np.asarray(cost)[lo:hi]
+    return [lo + x for x in shard_bounds(hi - lo, chunks, c)]
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def _all_gather(out, inp, group, async_op=False):
     import torch.distributed as dist
 
+    if out.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal only (more ranks than GPUs on one box, bench.py S3GRL_BENCH_BACKEND=gloo): gloo
+        # moves host memory, so the contribution is staged through the host, synchronously
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h_out, inp.cpu(), group=group)
+        out.copy_(h_out)
+        return _Done()
+    return dist.all_gather_into_tensor(out, inp, group=group, async_op=async_op)
+
+
+def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, group=None, gather=True,
+                       rows_per_link=None, chunks=1, row_shape=None, dtype=torch.float32,
+                       device=None, timers=None):
+    """Shard `link_index` ([2, L]) over the ranks and (when `gather`) reassemble the whole result
+    on every rank.
+
+    Ragged flavour (`rows_per_link is None`):
+        `compute(link_index_shard) -> (rows [R_r, ...], row_ptr [L_r + 1])` on this rank's device.
+    Fixed flavour (`rows_per_link = 2` for PoS / SoP / hybrid; needs `row_shape`, `device`):
+        `compute(link_index_piece, out)` fills `out` ([piece links * rows_per_link, *row_shape]).
+
+    Returns (rows, row_ptr, (lo, hi)): the WHOLE list on every rank when `gather`, else the local
+    shard.  `timers` (dict, optional) receives host-side timestamps for the benchmark.
+    """
     li = torch.as_tensor(link_index)
-    L = li.shape[1]
+    L = int(li.shape[1])
     b = shard_bounds(L, world_size, cost)
     lo, hi = b[rank], b[rank + 1]
+    if rows_per_link is not None:
+        return _fixed(compute, li, b, rank, world_size, cost, group, gather, int(rows_per_link),
+                      max(int(chunks), 1), tuple(row_shape), dtype, device, timers)
     rows, row_ptr = compute(li[:, lo:hi])
     if not gather or world_size == 1:
         return rows, row_ptr, (lo, hi)
@@ -55,7 +113,7 @@ def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, grou
     # 1) sizes
     mine = torch.tensor([rows.shape[0], hi - lo], dtype=torch.int64, device=dev)
     sizes = torch.empty(world_size * 2, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(sizes, mine, group=group)
+    _all_gather(sizes, mine, group)
     sizes = sizes.cpu().view(world_size, 2)
     rmax, lmax = int(sizes[:, 0].max()), int(sizes[:, 1].max())
     # 2) one padded all-gather of the rows, one of the per-link row counts
@@ -63,13 +121,99 @@ def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, grou
     pad = torch.zeros((rmax,) + tuple(tail), dtype=rows.dtype, device=dev)
     pad[:rows.shape[0]] = rows
     allrows = torch.empty((world_size * rmax,) + tuple(tail), dtype=rows.dtype, device=dev)
-    dist.all_gather_into_tensor(allrows, pad, group=group)
+    _all_gather(allrows, pad, group)
     cnt = torch.zeros(lmax, dtype=torch.int64, device=dev)
     cnt[:hi - lo] = (row_ptr[1:] - row_ptr[:-1]).to(dev)
     allcnt = torch.empty(world_size * lmax, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(allcnt, cnt, group=group)
+    _all_gather(allcnt, cnt, group)
     out_rows = torch.cat([allrows[r * rmax: r * rmax + int(sizes[r, 0])] for r in range(world_size)])
     counts = torch.cat([allcnt[r * lmax: r * lmax + int(sizes[r, 1])] for r in range(world_size)])
     out_ptr = torch.zeros(L + 1, dtype=torch.int64, device=dev)
     out_ptr[1:] = torch.cumsum(counts, 0)
     return out_rows, out_ptr, (lo, hi)
+
+
+class _Buffers:
+    """Reused across calls (a benchmark step must not allocate GBs): final rows + the padded
+    all-gather slots, two of them so that piece c+1 is computed while piece c is in flight."""
+    cache = {}
+
+    @classmethod
+    def get(cls, key, shape, dtype, device):
+        t = cls.cache.get(key)
+        if t is None or t.shape != tuple(shape) or t.dtype != dtype or t.device != torch.device(device):
+            t = torch.empty(shape, dtype=dtype, device=device)
+            cls.cache[key] = t
+        return t
+
+    @classmethod
+    def clear(cls):
+        cls.cache.clear()
+
+
+def _fixed(compute, li, b, rank, world, cost, group, gather, rpl, chunks, row_shape, dtype, device,
+           timers):
+    L = int(li.shape[1])
+    lo, hi = b[rank], b[rank + 1]
+    row_ptr = torch.arange(0, rpl * L + 1, rpl, dtype=torch.int64, device=device)
+    if not gather or world == 1:
+        rows = _Buffers.get(("local", rank), (rpl * (hi - lo),) + row_shape, dtype, device)
+        compute(li[:, lo:hi], rows)
+        return rows, row_ptr[lo:hi + 1] - rpl * lo, (lo, hi)
+    # piece c of rank r = links [pb[r][c], pb[r][c+1]); every rank derives every rank's bounds
+    pb = [chunk_bounds(b[r], b[r + 1], chunks, cost) for r in range(world)]
+    final = _Buffers.get(("final", rank), (rpl * L,) + row_shape, dtype, device)
+    works = [None] * chunks
+    slots = [None] * chunks
+    pmaxes = [rpl * max(pb[r][c + 1] - pb[r][c] for r in range(world)) for c in range(chunks)]
+    cap = max(max(pmaxes), 1)
+
+    def compact(c):
+        slot, pmax = slots[c]
+        for r in range(world):
+            n = rpl * (pb[r][c + 1] - pb[r][c])
+            if n:
+                final[rpl * pb[r][c]: rpl * pb[r][c] + n].copy_(slot[r, :n], non_blocking=True)
+
+    t_comm = 0.0
+    for c in range(chunks):
+        pmax = max(pmaxes[c], 1)
+        buf = _Buffers.get(("slot", rank, c % 2), (world * cap,) + row_shape, dtype, device)
+        slot = buf[:world * pmax].view((world, pmax) + row_shape)
+        slots[c] = (slot, pmax)
+        p0, p1 = pb[rank][c], pb[rank][c + 1]
+        if p1 > p0:
+            compute(li[:, p0:p1], slot[rank, :rpl * (p1 - p0)])
+        t0 = time.perf_counter()
+        # in place: this rank's contribution already sits in its slice of the output
+        works[c] = _all_gather(slot.view((world * slot.shape[1],) + row_shape), slot[rank], group,
+                               async_op=True)
+        if c >= 1:
+            works[c - 1].wait()
+            compact(c - 1)
+        t_comm += time.perf_counter() - t0
+    t0 = time.perf_counter()
+    works[chunks - 1].wait()
+    compact(chunks - 1)
+    t_comm += time.perf_counter() - t0
+    if timers is not None:
+        timers["comm_host_s"] = timers.get("comm_host_s", 0.0) + t_comm
+    return final, row_ptr, (lo, hi)
+
+
+def engine_compute(engine, graph, x, *, mode="pos", num_hops=1, sign_k=3, **kw):
+    """The fixed-flavour compute callable running the HIP engine on this rank's device:
+    `compute(link_index_piece [2, n] (host or device), out)`."""
+
+    def compute(piece, out):
+        links = engine.links(piece)
+        if mode == "sop":
+            engine.precompute(graph, x, links, mode="sop", sign_k=sign_k, out=out)
+            return
+        plan = engine.plan(graph, links, mode=mode, num_hops=num_hops, sign_k=sign_k, **kw)
+        try:
+            plan.run(x, out)
+        finally:
+            plan.close()
+
+    return compute

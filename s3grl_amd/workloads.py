@@ -108,12 +108,53 @@ def edge_split(n, edges, seed=0, val_ratio=0.05, test_ratio=0.1):
     return Split(n, train, csr_from_undirected(n, train), links)
 
 
-def row_normalize(X):
-    """PyG NormalizeFeatures: rows divided by their sum, all-zero rows left zero
-    (reference sgrl_link_pred.py:851,1000-1003)."""
-    s = X.sum(axis=1, keepdims=True)
-    s[s == 0] = 1
+def normalize_features(X):
+    """PyG `NormalizeFeatures` as the reference applies it (Planetoid transform
+    sgrl_link_pred.py:851 and again :1000-1003 after `init_features`):
+    `value = value - value.min(); value.div_(value.sum(dim=-1, keepdim=True).clamp_(min=1.))` *(3p)*
+    — the GLOBAL minimum is subtracted (a no-op for the non-negative bag-of-words / one-hot
+    matrices), then every row is divided by its sum clamped from below at 1, so all-zero rows
+    stay zero and rows whose sum is below 1 are left unscaled.  fp32 like the reference."""
+    X = np.asarray(X, dtype=np.float32)
+    X = X - X.min() if X.size else X
+    s = np.maximum(X.sum(axis=1, keepdims=True, dtype=np.float32), np.float32(1.0))
     return (X / s).astype(np.float32)
+
+
+def row_normalize(X):
+    """Kept name of `normalize_features` (the synthetic twins' feature step)."""
+    return normalize_features(X)
+
+
+def read_seal_edges(path):
+    """Reader of the SEAL txt datasets (USAir, NS, PB, Yeast, ...; reference data_utils.py:76-93,
+    used at sgrl_link_pred.py:868-875): `edges.txt` under `path` (or `path` itself when it is a
+    file), the first two whitespace-separated columns of every line are node names; ids are the
+    rank of the name in the SORTED LIST OF STRINGS ('10' < '2').  Returns (num_nodes,
+    edges int64 [E, 2]) in file order, duplicates and self-loops kept exactly as the reference's
+    `read_edges` returns them; `undirected_unique` gives the simple-graph topology."""
+    from pathlib import Path as _P
+
+    p = _P(path)
+    if p.is_dir():
+        p = p / "edges.txt"
+    rows = []
+    with open(p) as f:
+        for line in f.readlines():
+            a, b = line.strip().split()[:2]
+            rows.append((a, b))
+    names = sorted(set(x for ab in rows for x in ab))
+    idx = {name: i for i, name in enumerate(names)}
+    edges = np.array([[idx[a], idx[b]] for a, b in rows], dtype=np.int64).reshape(-1, 2)
+    return len(names), edges
+
+
+def undirected_unique(edges):
+    """u < v, sorted, duplicates and self-loops dropped (PyG `to_undirected` + coalesce, upper half)."""
+    e = np.asarray(edges, dtype=np.int64).reshape(-1, 2)
+    e = e[e[:, 0] != e[:, 1]]
+    e = np.unique(np.sort(e, axis=1), axis=0)
+    return e
 
 
 def sparse_uniform_features(n, dim, nnz_per_row, seed):
@@ -125,10 +166,26 @@ def sparse_uniform_features(n, dim, nnz_per_row, seed):
 
 
 def one_hot_degree(A, max_degree=1024):
-    deg = np.minimum(np.diff(A.indptr), max_degree)
+    """PyG `OneHotDegree(max_degree=1024)` on the TRAIN graph (reference sgrl_link_pred.py:961-963;
+    `data.edge_index` holds the train edges only at that point, :852-855): out-degree = stored
+    entries of the row, one-hot over max_degree + 1 = 1 025 classes.  A degree above max_degree
+    makes PyG's `F.one_hot(deg, num_classes=max_degree + 1)` raise; so does this.  The caller
+    concatenates it to x (`cat=True`): `init_degree_features`."""
+    deg = np.diff(A.indptr)
+    if len(deg) and deg.max() > max_degree:
+        raise RuntimeError("Class values must be smaller than num_classes.")   # torch's message
     oh = np.zeros((A.shape[0], max_degree + 1), dtype=np.float32)
     oh[np.arange(A.shape[0]), deg] = 1
     return oh
+
+
+def init_degree_features(X, A, max_degree=1024):
+    """`init_features == "degree"` (sgrl_link_pred.py:961-963 + :1000-1003): the one-hot degree is
+    appended to the existing x (PyG `cat=True`; x alone when the dataset has no features), then
+    NormalizeFeatures."""
+    oh = one_hot_degree(A, max_degree)
+    X = oh if X is None else np.hstack([np.asarray(X, dtype=np.float32).reshape(A.shape[0], -1), oh])
+    return normalize_features(X)
 
 
 @dataclass
@@ -151,6 +208,12 @@ def make(name):
         n, e = load_topology("pubmed")
         return Workload(name, edge_split(n, e, seed=2), sparse_uniform_features(n, 500, 50, 2),
                         "pos", 3, 3)
+    if name == "pubmed_pos_k3_dense":   # control: node2vec-like DENSE features (sgrl_link_pred.py:966-971
+        # produces such an x for init_features=n2v), same graph / links / F as the headline, so that
+        # SURVEY §8(d)'s B_link IS the traffic (no zero chunks to skip)
+        n, e = load_topology("pubmed")
+        X = np.random.default_rng(7).standard_normal((n, 500)).astype(np.float32)
+        return Workload(name, edge_split(n, e, seed=2), normalize_features(X), "pos", 3, 3)
     if name == "pubmed_pos_k5":      # config 4
         n, e = load_topology("pubmed")
         return Workload(name, edge_split(n, e, seed=2), sparse_uniform_features(n, 500, 50, 2),
@@ -158,8 +221,8 @@ def make(name):
     if name == "pubmed_sop_k3":      # config 3: degree features appended (F = 1525)
         n, e = load_topology("pubmed")
         sp = edge_split(n, e, seed=2)
-        X = np.hstack([sparse_uniform_features(n, 500, 50, 2), one_hot_degree(sp.A)])
-        return Workload(name, sp, row_normalize(X), "sop", 2, 3)
+        return Workload(name, sp, init_degree_features(sparse_uniform_features(n, 500, 50, 2), sp.A),
+                        "sop", 2, 3)
     if name == "cora_posplus_k3":    # config 2
         n, e = load_topology("cora")
         rng = np.random.default_rng(1)

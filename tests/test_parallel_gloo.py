@@ -51,6 +51,70 @@ def _worker(rank, world, port, plus, q):
     dist.destroy_process_group()
 
 
+def _worker_fixed(rank, world, port, chunks, q):
+    """Fixed-rows flavour (PoS / SoP: 2 rows per link), pipelined pieces, in-place padded
+    all-gather.  The oracle stands in for the engine; the check is bit-equality with the unsharded
+    result on every rank — the same assertion tests/test_gpu_parity.py makes with the engine."""
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = load_extract("usair")
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = np.random.default_rng(0).random((n, 6))
+    links = g["links"].T
+    kw = {"sign_k": 2, "k_node_set_strategy": "intersection"}
+
+    def rows_of(li):
+        rows, _, _ = oracle.collate_rows(oracle.get_PoS_prepped_ds(li, 1, A, X, 1, kw, dtype=np.float64), 2)
+        return rows.reshape(-1, 3, 7)
+
+    calls = []
+
+    def compute(piece, out):
+        calls.append(int(piece.shape[1]))
+        out.copy_(torch.from_numpy(rows_of(piece.numpy())))
+
+    ok = True
+    for _ in range(2):          # second call reuses the cached buffers
+        rows, ptr, (lo, hi) = parallel.sharded_precompute(
+            compute, links, rank=rank, world_size=world, cost=parallel.link_cost(A, links),
+            rows_per_link=2, chunks=chunks, row_shape=(3, 7), dtype=torch.float64, device="cpu")
+        full = rows_of(links)
+        ok = ok and np.array_equal(rows.numpy(), full) and \
+            np.array_equal(ptr.numpy(), np.arange(0, 2 * links.shape[1] + 1, 2))
+    ok = ok and sum(calls) == 2 * (hi - lo)
+    # gather=False hands back the local shard only
+    rows_l, ptr_l, _ = parallel.sharded_precompute(
+        compute, links, rank=rank, world_size=world, cost=parallel.link_cost(A, links),
+        rows_per_link=2, row_shape=(3, 7), dtype=torch.float64, device="cpu", gather=False)
+    ok = ok and np.array_equal(rows_l.numpy(), rows_of(links[:, lo:hi])) and int(ptr_l[0]) == 0 \
+        and int(ptr_l[-1]) == 2 * (hi - lo)
+    q.put((rank, ok, lo, hi))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,chunks", [(2, 1), (2, 3), (3, 2)])
+def test_sharded_fixed_rows_pipelined(world, chunks):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fixed, args=(r, world, port, chunks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in res)
+    spans = sorted((lo, hi) for _, _, lo, hi in res)
+    assert spans[0][0] == 0 and spans[-1][1] == 34
+    assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+
+
 @pytest.mark.parametrize("plus", [False, True])
 def test_sharded_precompute_world2(plus):
     ctx = mp.get_context("spawn")
@@ -74,3 +138,18 @@ def test_shard_bounds_balanced_and_contiguous():
     assert b[0] == 0 and b[-1] == 8 and b == sorted(b)
     assert parallel.shard_bounds(10, 4) == [0, 2, 5, 7, 10]
     assert parallel.shard_bounds(0, 3) == [0, 0, 0, 0]
+    # pieces of a shard: contiguous, cover it, empty pieces allowed
+    assert parallel.chunk_bounds(5, 9, 2) == [5, 7, 9]
+    assert parallel.chunk_bounds(5, 6, 3, cost=np.ones(10))[0] == 5
+    assert parallel.chunk_bounds(5, 6, 3, cost=np.ones(10))[-1] == 6
+
+
+def test_khop_cost_tracks_ball_size():
+    g = load_extract("usair")
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    links = g["links"].T
+    c1 = parallel.khop_cost(A, links, 1)
+    assert np.array_equal(c1, parallel.link_cost(A, links) + 1)   # 1 + deg per endpoint
+    c2 = parallel.khop_cost(A, links, 2)
+    assert (c2 >= c1).all()

@@ -18,7 +18,8 @@ from collections import defaultdict
 from pathlib import Path
 
 REPO = Path(__file__).resolve().parent.parent
-FAMILIES = ["gather_packed_kernel", "gather_sparse_kernel", "gather_kernel", "link_kernel", "count_kernel"]
+FAMILIES = ["gather_packed_kernel", "gather_sparse_kernel", "gather_kernel", "link_kernel", "count_kernel",
+            "sop_rows_kernel", "sop_scalar_kernel", "spmm_norm_kernel"]
 
 
 def family(name):
@@ -68,9 +69,9 @@ def main():
         for fam, cs in vals.items():
             merged[fam].update(cs)
         dispatches.update(disp)
-    gather = next((f for f in FAMILIES[:3] if f in merged), None)
+    gather = next((f for f in FAMILIES[:3] + ["sop_rows_kernel"] if f in merged), None)
     if gather is None:
-        sys.exit("no gather kernel in the counter files")
+        sys.exit("no gather / sop_rows kernel in the counter files")
     g = merged[gather]
     out = {"workload": args.workload, "links": args.links, "build": args.build, "kernel": gather,
            "dispatches_in_run": dispatches,
@@ -88,7 +89,7 @@ def main():
         out["l2_hit_rate"] = g["TCC_HIT_sum"] / max(g["TCC_HIT_sum"] + g["TCC_MISS_sum"], 1.0)
     if args.bench_json:
         b = json.loads(Path(args.bench_json).read_text().strip().splitlines()[-1])
-        out["algorithmic_bytes_per_launch"] = b["roofline"]["algorithmic_bytes_per_launch"]
+        out["algorithmic_bytes_per_launch"] = b["roofline"]["algorithmic"]["bytes_per_launch"]
         out["bench_kernel_ms"] = b["roofline"]["kernel_ms"]
     out["note"] = ("FETCH_SIZE counts fabric-side requests, Infinity-Cache hits included: with X resident in "
                    "the 256 MB Infinity Cache this is cache-served fabric traffic, not DRAM traffic.")
