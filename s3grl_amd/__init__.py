@@ -13,3 +13,17 @@ def precompute(*args, **kwargs):
     from .engine import precompute as _p
 
     return _p(*args, **kwargs)
+
+
+def extract_enclosing_subgraphs(*args, **kwargs):
+    """See `s3grl_amd.dataset.extract_enclosing_subgraphs` (reference utils.py:446-554)."""
+    from .dataset import extract_enclosing_subgraphs as _f
+
+    return _f(*args, **kwargs)
+
+
+def process_split(*args, **kwargs):
+    """See `s3grl_amd.dataset.process_split` (reference sgrl_link_pred.py:96-220)."""
+    from .dataset import process_split as _f
+
+    return _f(*args, **kwargs)

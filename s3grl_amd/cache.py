@@ -87,16 +87,22 @@ def save(path, rows, row_ptr, y, meta=None):
         raise ValueError("row_ptr / y do not describe rows")
     header = {"version": 1, "meta": dict(meta or {}), "arrays": {}}
     header["meta"].setdefault("num_links", int(L))
-    # two passes: the header's own length moves the first blob
-    off = 0
-    for _ in range(2):
+    # the header's own length moves the first blob, and the offsets it then records can lengthen it
+    # again: iterate until the header that is written is the one the offsets were computed from
+    off, first = 0, -1
+    for _ in range(8):
         blob = json.dumps(header, sort_keys=True).encode()
-        off = -(-(len(MAGIC) + 8 + len(blob)) // ALIGN) * ALIGN
+        start = -(-(len(MAGIC) + 8 + len(blob)) // ALIGN) * ALIGN
+        if start == first:
+            break
+        first = off = start
         for k, a in arrays.items():
             header["arrays"][k] = {"dtype": str(a.dtype), "shape": list(a.shape), "offset": off,
                                    "nbytes": int(a.nbytes)}
             off = -(-(off + a.nbytes) // ALIGN) * ALIGN
     blob = json.dumps(header, sort_keys=True).encode()
+    if len(MAGIC) + 8 + len(blob) > header["arrays"]["rows"]["offset"]:
+        raise RuntimeError("bundle header overlaps the first blob")
     tmp = path.with_name(path.name + f".tmp{os.getpid()}")
     with open(tmp, "wb") as f:
         f.write(MAGIC)

@@ -25,7 +25,14 @@ class SIGNNetTwin(nn.Module):
         self.k_heuristic, self.k_pool_strategy = k_heuristic, k_pool_strategy
         self.operator_diff = nn.Sequential(nn.Linear(in_width, hidden), nn.ELU(),
                                            nn.BatchNorm1d(hidden), nn.Dropout(dropout))
-        ch = 2 if k_heuristic else 1
+        # reference models.py:327-337: hidden x 2 for mean / sum pooling of the common-neighbour rows,
+        # hidden x (1 + k_heuristic) when they are concatenated, hidden alone without the heuristic
+        if not k_heuristic:
+            ch = 1
+        elif k_pool_strategy == "concat":
+            ch = 1 + int(k_heuristic)
+        else:
+            ch = 2
         self.link_pred_mlp = nn.Sequential(nn.Linear(hidden * ch, hidden), nn.ReLU(),
                                            nn.BatchNorm1d(hidden), nn.Dropout(dropout),
                                            nn.Linear(hidden, 1))

@@ -17,6 +17,7 @@ there, utils.py:66-70), the latter seeded by `SAMPLING_SEED`.
 from __future__ import annotations
 
 import os
+from collections.abc import Sequence as _Sequence
 
 import torch
 
@@ -77,63 +78,268 @@ def _make_data(**kw):
 
 
 # A and x are the same objects across the 6 operator calls of one run
-# (reference sgrl_link_pred.py:195-203): upload once.
+# (reference sgrl_link_pred.py:195-203): upload once.  An entry keeps a STRONG reference to the
+# object it was built from and is reused only for that very object (`is`) with unchanged content —
+# A by a hash of its structure arrays, a torch x by its version counter (bumped by every in-place
+# op), a numpy x by a hash of its bytes.  (Keying on id() alone let a new matrix that reused a
+# freed matrix's id, with equal shape and nnz, silently hit the stale device copy.)
 _cache = {}
+
+
+def _hash_bytes(*arrays):
+    try:
+        import xxhash
+
+        h = xxhash.xxh3_64()
+        for a in arrays:
+            h.update(memoryview(a).cast("B"))
+        return h.intdigest()
+    except ImportError:                      # pragma: no cover - xxhash ships with the image
+        import zlib
+
+        v = 0
+        for a in arrays:
+            v = zlib.adler32(memoryview(a).cast("B"), v)
+        return v
+
+
+def _fingerprint_A(A):
+    import numpy as np
+
+    return (A.shape, int(A.nnz), _hash_bytes(np.ascontiguousarray(A.indptr), np.ascontiguousarray(A.indices)))
+
+
+def _fingerprint_x(x):
+    if torch.is_tensor(x):
+        return ("t", tuple(x.shape), x.dtype, x.data_ptr(), x._version)
+    import numpy as np
+
+    a = np.ascontiguousarray(x)
+    return ("n", a.shape, a.dtype.str, _hash_bytes(a))
 
 
 def _device_inputs(A, x):
     eng = _engine.default_engine()
-    kA = ("A", id(A), A.shape, A.nnz)
-    if kA not in _cache:
-        for k in [k for k in _cache if k[0] == "A"]:
-            _cache.pop(k).close()
-        _cache[kA] = eng.graph(A)
-    kx = ("x", id(x), tuple(x.shape), x.data_ptr() if torch.is_tensor(x) else 0)
-    if kx not in _cache:
-        for k in [k for k in _cache if k[0] == "x"]:
-            _cache.pop(k)
-        _cache[kx] = eng.features(x)
-    return eng, _cache[kA], _cache[kx]
+    ent = _cache.get("A")
+    fp = _fingerprint_A(A)
+    if ent is None or ent[0] is not A or ent[1] != fp:
+        if ent is not None:
+            ent[2].close()
+        ent = (A, fp, eng.graph(A))
+        _cache["A"] = ent
+    g = ent[2]
+    ent = _cache.get("x")
+    fp = _fingerprint_x(x)
+    if ent is None or ent[0] is not x or ent[1] != fp:
+        if ent is not None:
+            ent[2].close()
+        ent = (x, fp, eng.features(x))
+        _cache["x"] = ent
+    return eng, g, ent[2]
 
 
-def clear_cache():
+def clear_cache(trim=True):
+    """Drop the cached device copies of A and x, the pinned staging pool, and (trim) give the
+    engine's cached workspace back to the HIP allocator — call it when the precompute phase is
+    over (after the last SEALDataset has been built) so that training can use the memory."""
     for k in list(_cache):
         v = _cache.pop(k)
-        if hasattr(v, "close"):
-            v.close()
+        if hasattr(v[2], "close"):
+            v[2].close()
+    _pool.clear()
+    if trim and _engine._default:
+        for eng in _engine._default.values():
+            eng.trim()
 
 
-_pinned = {}
+# ---- host staging ------------------------------------------------------------------------------
+# The caller owns the tensors it gets back (SURVEY 8b), so a staging buffer cannot simply be
+# reused for the next call: the previous list may still be alive (pos_list while neg_list is being
+# computed, sgrl_link_pred.py:195-204).  Page-locking fresh memory for every call costs more than
+# the copy, and a pageable copy runs at a fifth of the DMA rate.  So page-locked blocks are pooled
+# and handed out through an ALIAS tensor with a storage object of its own: the block is reused only
+# once that storage has died, i.e. when the list and every view ever cut from it are gone.
+_pool = []     # [base pinned tensor, StorageWeakRef of the alias handed out last (or None)]
+
+
+def _alloc_pinned(n):
+    return torch.empty(n, dtype=torch.float32, pin_memory=True)
+
+
+def _staging(n):
+    """A CPU float32 tensor of n elements in page-locked memory that nothing else refers to."""
+    from torch.multiprocessing.reductions import StorageWeakRef
+
+    best = None
+    for ent in _pool:
+        if ent[0].numel() >= n and (ent[1] is None or ent[1].expired()):
+            if best is None or ent[0].numel() < best[0].numel():
+                best = ent
+    if best is None:
+        cap = max(int(n), 1)
+        cap = 1 << (cap - 1).bit_length() if cap < (1 << 28) else -(-cap // (1 << 26)) * (1 << 26)
+        try:
+            base = _alloc_pinned(cap)
+        except RuntimeError:                      # page-locking refused
+            return None
+        best = [base, None]
+        _pool.append(best)
+        if len(_pool) > 8:                        # forget the oldest free block
+            for i, ent in enumerate(_pool):
+                if ent is not best and (ent[1] is None or ent[1].expired()):
+                    _pool.pop(i)
+                    break
+    alias = torch.from_numpy(best[0].numpy())     # same memory, its own storage object
+    best[1] = StorageWeakRef(alias.untyped_storage())
+    return alias[:n]
 
 
 def _to_host(rows):
-    """D2H through a cached page-locked staging buffer (the 6 operator calls of a run reuse it):
-    2.6 GB of PubMed rows take 0.05 s this way and 0.27 s through a pageable `.cpu()`."""
-    n = rows.numel()
-    buf = _pinned.get("buf")
-    if buf is None or buf.numel() < n:
-        try:
-            buf = torch.empty(max(n, 1), dtype=torch.float32, pin_memory=True)
-        except RuntimeError:                      # page-locking refused: plain copy
-            return rows.cpu()
-        _pinned["buf"] = buf
-    stage = buf[:n].view(rows.shape)
+    """D2H into pooled page-locked memory (2.6 GB of PubMed rows: 0.05 s; a pageable `.cpu()`
+    0.27 s), handed over without a second copy."""
+    stage = _staging(rows.numel())
+    if stage is None:
+        return rows.cpu()
+    stage = stage.view(rows.shape)
     stage.copy_(rows, non_blocking=True)
     torch.cuda.current_stream(rows.device).synchronize()
-    return stage.clone()                          # the caller owns fresh CPU tensors (SURVEY 8b)
+    return stage
 
 
-def _as_data_list(res, K, y):
-    """Per-link views of the collated rows: x, x1..xK each [R, 1+F].  The views of one operator
-    are cut in one `split` call (a C++ loop), not by 164 000 Python slicings."""
+class LinkDataList(_Sequence):
+    """What the operators return: the reference's `list[Data]` (tuned_SIGN.py:134,187,260) as a
+    lazy sequence over the collated tensor.  `len`, indexing, slicing, iteration, `a + b` (the
+    caller's `pos_list + neg_list`, sgrl_link_pred.py:204) and `zip` behave like the list; a
+    `Data` (x, x1..xK: [R, 1+F] views, y) is only built when an element is asked for, so a call
+    returns at the engine's speed instead of spending a second on 164 000 Python objects.
+    `collate()` gives the (rows, row_ptr, y) tensors; `collate_pyg()` the `(data, slices)` pair
+    PyG's `InMemoryDataset.collate` would build from the materialised list."""
+
+    def __init__(self, chunks, K):
+        # chunk = (rows [ΣR, K+1, 1+F], row_ptr numpy int64 [L+1], y int)
+        self._chunks = list(chunks)
+        self._K = int(K)
+        self._starts = [0]
+        for c in self._chunks:
+            self._starts.append(self._starts[-1] + len(c[1]) - 1)
+
+    def __len__(self):
+        return self._starts[-1]
+
+    def _item(self, i):
+        import bisect
+
+        c = bisect.bisect_right(self._starts, i) - 1
+        rows, ptr, y = self._chunks[c]
+        j = i - self._starts[c]
+        blk = rows[int(ptr[j]):int(ptr[j + 1])]
+        kw = {"x": blk[:, 0, :]}
+        for k in range(1, self._K + 1):
+            kw[f"x{k}"] = blk[:, k, :]
+        return _make_data(y=y, **kw)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._item(j) for j in range(*i.indices(len(self)))]
+        n = len(self)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError("list index out of range")
+        return self._item(i)
+
+    def __iter__(self):
+        for rows, ptr, y in self._chunks:
+            names = ["x"] + [f"x{k}" for k in range(1, self._K + 1)]
+            a = int(ptr[0])
+            for b in ptr[1:].tolist():
+                blk = rows[a:b]
+                yield _make_data(y=y, **{nm: blk[:, k, :] for k, nm in enumerate(names)})
+                a = b
+
+    def __add__(self, other):
+        if isinstance(other, LinkDataList) and other._K == self._K:
+            return LinkDataList(self._chunks + other._chunks, self._K)
+        if isinstance(other, (list, LinkDataList)):
+            return list(self) + list(other)
+        return NotImplemented
+
+    def __radd__(self, other):
+        if isinstance(other, list):
+            return other + list(self)
+        return NotImplemented
+
+    def __repr__(self):
+        return f"LinkDataList({len(self)} links, sign_k={self._K}, {len(self._chunks)} chunk(s))"
+
+    def collate(self):
+        """(rows [ΣR, K+1, 1+F], row_ptr int64 [L+1], y int64 [L]) of the whole sequence."""
+        import numpy as np
+
+        if len(self._chunks) == 1:
+            rows, ptr, y = self._chunks[0]
+            return rows, torch.from_numpy(np.asarray(ptr, dtype=np.int64)), \
+                torch.full((len(ptr) - 1,), int(y), dtype=torch.int64)
+        rows = torch.cat([c[0] for c in self._chunks]) if self._chunks else torch.empty(0)
+        ptrs, ys, base = [np.zeros(1, dtype=np.int64)], [], 0
+        for r, ptr, y in self._chunks:
+            ptrs.append(np.asarray(ptr[1:], dtype=np.int64) + base)
+            base += int(ptr[-1])
+            ys.append(torch.full((len(ptr) - 1,), int(y), dtype=torch.int64))
+        return rows, torch.from_numpy(np.concatenate(ptrs)), torch.cat(ys) if ys else torch.empty(0, dtype=torch.int64)
+
+    def collate_pyg(self):
+        """`(data, slices)` as `InMemoryDataset.collate(list(self))` builds them (sgrl_link_pred.py:204):
+        every key concatenated along dim 0, `slices[key]` its per-link boundaries."""
+        rows, ptr, y = self.collate()
+        kw = {"x": rows[:, 0, :].contiguous()}
+        for k in range(1, self._K + 1):
+            kw[f"x{k}"] = rows[:, k, :].contiguous()
+        data = _make_data(y=y, **kw)
+        slices = {k: ptr for k in kw}
+        slices["y"] = torch.arange(len(self) + 1, dtype=torch.int64)
+        return data, slices
+
+
+def install_pyg_fast_collate():
+    """With PyG present, `InMemoryDataset.collate(LinkDataList)` — what the reference's
+    `SEALDataset.process` calls on `pos_list + neg_list` — takes the collated tensors directly
+    instead of looping over L objects; any other argument goes to PyG's own collate."""
+    try:
+        from torch_geometric.data import InMemoryDataset  # type: ignore
+    except Exception:
+        return False
+    orig = InMemoryDataset.__dict__.get("collate")
+    if getattr(orig, "_s3grl_fast", False):
+        return True
+    orig_fn = orig.__func__ if isinstance(orig, staticmethod) else InMemoryDataset.collate
+
+    def collate(data_list):
+        if isinstance(data_list, LinkDataList):
+            return data_list.collate_pyg()
+        return orig_fn(data_list)
+
+    wrapped = staticmethod(collate)
+    wrapped._s3grl_fast = True
+    InMemoryDataset.collate = wrapped
+    return True
+
+
+install_pyg_fast_collate()
+
+
+def _as_data_list(res, K, y, fixed_rows=None):
+    """The engine's collated rows as the reference's per-link list (lazy, see LinkDataList)."""
+    import numpy as np
+
     out_dev = os.environ.get("S3GRL_OUTPUT_DEVICE", "cpu")
     rows = res.rows if out_dev != "cpu" else _to_host(res.rows)
-    counts = res.row_ptr.cpu().diff().tolist()
-    if not counts:
-        return []
-    ops = [rows[:, i, :].split(counts) for i in range(K + 1)]
-    names = ["x"] + [f"x{i}" for i in range(1, K + 1)]
-    return [_make_data(y=y, **dict(zip(names, per_link))) for per_link in zip(*ops)]
+    L = res.num_links
+    if fixed_rows:                               # PoS / SoP: R = 2 for every link, nothing to fetch
+        ptr = np.arange(0, fixed_rows * L + 1, fixed_rows, dtype=np.int64)
+    else:
+        ptr = res.row_ptr.cpu().numpy()
+    return LinkDataList([(rows, ptr, y)], K)
 
 
 def _rw_of(rw_kwargs):
@@ -150,7 +356,7 @@ def _rw_of(rw_kwargs):
 SAMPLING_SEED = 0
 
 
-def _check_unsupported(ratio_per_hop, max_nodes_per_hop, directed, A_csc, rw_kwargs):
+def _check_unsupported(directed, A_csc):
     if directed or A_csc is not None:
         raise NotImplementedError("directed graphs are not implemented")
 
@@ -172,27 +378,27 @@ class OptimizedSignOperations:
             raise ValueError("powers_of_A is empty")
         eng, g, xd = _device_inputs(A, x)
         res = eng.precompute(g, xd, eng.links(link_index), mode="sop", sign_k=K)
-        return _as_data_list(res, K, y)
+        return _as_data_list(res, K, y, fixed_rows=2)
 
     @staticmethod
     def get_PoS_prepped_ds(link_index, num_hops, A, ratio_per_hop, max_nodes_per_hop, directed, A_csc,
                            x, y, sign_kwargs, rw_kwargs):
         """Reference tuned_SIGN.py:137-189."""
         print("PoS Optimized Flow.")
-        _check_unsupported(ratio_per_hop, max_nodes_per_hop, directed, A_csc, rw_kwargs)
+        _check_unsupported(directed, A_csc)
         K = sign_kwargs['sign_k']
         assert x is not None                                  # tuned_SIGN.py:166
         eng, g, xd = _device_inputs(A, x)
         res = eng.precompute(g, xd, eng.links(link_index), mode="pos", num_hops=num_hops, sign_k=K,
                              rw=_rw_of(rw_kwargs), **_sampling_of(ratio_per_hop, max_nodes_per_hop))
-        return _as_data_list(res, K, y)
+        return _as_data_list(res, K, y, fixed_rows=2)
 
     @staticmethod
     def get_PoS_Plus_prepped_ds(link_index, num_hops, A, ratio_per_hop, max_nodes_per_hop, directed,
                                 A_csc, x, y, sign_kwargs, rw_kwargs):
         """Reference tuned_SIGN.py:192-262."""
         print("PoS Plus Optimized Flow.")
-        _check_unsupported(ratio_per_hop, max_nodes_per_hop, directed, A_csc, rw_kwargs)
+        _check_unsupported(directed, A_csc)
         K = sign_kwargs['sign_k']
         strat = sign_kwargs['k_node_set_strategy']
         if strat not in ('union', 'intersection'):

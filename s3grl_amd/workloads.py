@@ -76,6 +76,17 @@ class Split:
     A: ssp.csr_matrix                # train graph, both directions
     links: dict                      # split -> (pos [2,P], neg [2,Q]) in the reference's layout
 
+    def split_edge(self):
+        """The dict `do_edge_split` returns (reference utils.py:626-633): per split 'edge' [P, 2] and
+        'edge_neg' [Q, 2]."""
+        return {s: {"edge": self.links[s][0].T.copy(), "edge_neg": self.links[s][1].T.copy()}
+                for s in ("train", "valid", "test")}
+
+    def edge_index(self):
+        """`data.edge_index` after the split = the train positives, both directions
+        (sgrl_link_pred.py:852-855)."""
+        return self.links["train"][0]
+
     def all_links(self):
         """Concatenation in the order the reference's driver issues its 6 operator calls
         (train/valid/test x pos,neg; sgrl_link_pred.py:1116-1243, :195-203) -> [2, L], y [L]."""

@@ -85,3 +85,18 @@ def test_get_or_compute_reuses_only_matching_settings(tmp_path):
     p.write_bytes(b"garbage")                                                          # corrupt: recompute
     cache.get_or_compute(p, make(4), expect={"sign_k": 5, "mode": "pos"})
     assert calls == [1, 3, 4]
+
+
+def test_header_length_around_the_alignment_boundary(tmp_path):
+    """The first blob's offset depends on the header's length, which depends on the offsets it
+    records: whatever the meta's size, the written header must not run into the first blob."""
+    rows = np.arange(2 * 2 * 3, dtype=np.float32).reshape(2, 2, 3)
+    ptr, y = np.array([0, 2], dtype=np.int64), np.array([1], dtype=np.int64)
+    for pad in list(range(3600, 4000, 7)) + list(range(7700, 8200, 11)):
+        p = cache.save(tmp_path / "b.s3grl", rows, ptr, y, {"pad": "x" * pad})
+        r, rp, yy, meta = cache.load(p)
+        assert np.array_equal(r, rows) and np.array_equal(rp, ptr) and len(meta["pad"]) == pad
+        hdr = cache.read_header(p)
+        import json as _json
+
+        assert 16 + len(_json.dumps(hdr, sort_keys=True).encode()) <= hdr["arrays"]["rows"]["offset"]

@@ -1,0 +1,178 @@
+"""The lazy per-link list the drop-in operators return (s3grl_amd.tuned_SIGN.LinkDataList) and the
+host-side pieces around it — CPU only: list behaviour the reference's caller relies on
+(sgrl_link_pred.py:195-205, utils.py:472-480), the PyG collate hook, the staging pool, the
+upload cache."""
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from s3grl_amd import tuned_SIGN as ts
+
+
+def _chunk(L, K, F, y, seed, ragged=False):
+    rng = np.random.default_rng(seed)
+    cnt = rng.integers(2, 5, size=L) if ragged else np.full(L, 2)
+    ptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    rows = torch.from_numpy(rng.random((int(ptr[-1]), K + 1, F + 1)).astype(np.float32))
+    return (rows, ptr, y)
+
+
+def _eager(chunks, K):
+    out = []
+    for rows, ptr, y in chunks:
+        for a, b in zip(ptr[:-1], ptr[1:]):
+            out.append({"y": y, **{("x" if k == 0 else f"x{k}"): rows[a:b, k, :] for k in range(K + 1)}})
+    return out
+
+
+def _same(d, e, K):
+    return d.y == e["y"] and all(torch.equal(d[n], e[n]) for n in ["x"] + [f"x{k}" for k in range(1, K + 1)])
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_list_protocol(ragged):
+    K, F = 3, 5
+    c1, c2 = _chunk(7, K, F, 1, 0, ragged), _chunk(4, K, F, 0, 1, ragged)
+    pos, neg = ts.LinkDataList([c1], K), ts.LinkDataList([c2], K)
+    want = _eager([c1, c2], K)
+    assert len(pos) == 7 and len(neg) == 4
+    both = pos + neg                                   # sgrl_link_pred.py:204
+    assert isinstance(both, ts.LinkDataList) and len(both) == 11
+    assert all(_same(d, e, K) for d, e in zip(both, want))            # iteration
+    assert all(_same(both[i], want[i], K) for i in range(11))         # indexing
+    assert _same(both[-1], want[-1], K) and _same(both[-11], want[0], K)
+    with pytest.raises(IndexError):
+        both[11]
+    assert [d.y for d in both[5:9]] == [1, 1, 0, 0]                    # slicing -> plain list
+    assert both[0].x.shape == (int(c1[1][1]), F + 1) and both[0].num_features == F + 1
+    # mixing with real lists degrades to a real list
+    extra = [both[0]]
+    assert isinstance(both + extra, list) and len(both + extra) == 12
+    assert isinstance(extra + both, list) and len(extra + both) == 12
+    # the hybrid flow writes new keys into the elements it iterates over (utils.py:472-480)
+    combined = []
+    for sup, sop in zip(pos, ts.LinkDataList([c1], K)):
+        for k in range(K + 1, 2 * K):
+            sup[f"x{k}"] = sop[f"x{k - K + 1}"]
+        combined.append(sup)
+    assert len(combined) == 7 and torch.equal(combined[3][f"x{K + 1}"], want[3]["x2"])
+    assert "11 links" in repr(both)
+
+
+def test_collate_matches_concatenation():
+    K, F = 2, 4
+    c1, c2 = _chunk(5, K, F, 1, 2, True), _chunk(3, K, F, 0, 3, True)
+    both = ts.LinkDataList([c1], K) + ts.LinkDataList([c2], K)
+    rows, ptr, y = both.collate()
+    assert torch.equal(rows, torch.cat([c1[0], c2[0]]))
+    assert ptr.tolist() == np.concatenate([c1[1], c2[1][1:] + c1[1][-1]]).tolist()
+    assert y.tolist() == [1] * 5 + [0] * 3
+    data, slices = both.collate_pyg()
+    for k, name in enumerate(["x", "x1", "x2"]):
+        assert torch.equal(data[name], rows[:, k, :]) and data[name].is_contiguous()
+        assert torch.equal(slices[name], ptr)
+    assert torch.equal(data.y, y) and slices["y"].tolist() == list(range(9))
+    # a single chunk collates without copying
+    one = ts.LinkDataList([c1], K)
+    assert one.collate()[0].data_ptr() == c1[0].data_ptr()
+
+
+def test_pyg_collate_hook_with_a_stand_in_module(monkeypatch):
+    """PyG is absent from this image: a minimal stand-in with PyG's layout (InMemoryDataset with a
+    static `collate`) checks that the hook routes a LinkDataList to the fast path and leaves every
+    other argument to the original."""
+    calls = []
+
+    class InMemoryDataset:
+        @staticmethod
+        def collate(data_list):
+            calls.append(len(data_list))
+            return "orig", None
+
+    tg = types.ModuleType("torch_geometric")
+    tgd = types.ModuleType("torch_geometric.data")
+    tgd.InMemoryDataset = InMemoryDataset
+    tg.data = tgd
+    monkeypatch.setitem(sys.modules, "torch_geometric", tg)
+    monkeypatch.setitem(sys.modules, "torch_geometric.data", tgd)
+    assert ts.install_pyg_fast_collate() and ts.install_pyg_fast_collate()   # idempotent
+    lst = ts.LinkDataList([_chunk(6, 2, 3, 1, 5)], 2)
+
+    class Sub(InMemoryDataset):                       # the reference calls self.collate(...)
+        pass
+
+    data, slices = Sub().collate(lst + lst)
+    assert calls == [] and data.x.shape == (24, 4) and len(slices["y"]) == 13
+    assert Sub().collate([1, 2, 3]) == ("orig", None) and calls == [3]
+
+
+def test_staging_pool_recycles_only_dead_blocks(monkeypatch):
+    allocs = []
+
+    def fake_pinned(n):
+        allocs.append(n)
+        return torch.empty(n, dtype=torch.float32)
+
+    monkeypatch.setattr(ts, "_alloc_pinned", fake_pinned)
+    ts._pool.clear()
+    a = ts._staging(1000)
+    a.fill_(1.0)
+    view = a[10:20].view(2, 5)                        # a per-link view cut from the list's tensor
+    b = ts._staging(1000)                             # `a` is alive: a second block
+    assert len(allocs) == 2 and a.data_ptr() != b.data_ptr()
+    del a
+    c = ts._staging(500)                              # the view keeps the first block busy
+    assert len(allocs) == 3
+    del view, c
+    d = ts._staging(900)                              # now a dead block is handed out again
+    assert len(allocs) == 3
+    e = ts._staging(100)
+    assert len(allocs) == 3 and e.data_ptr() != d.data_ptr()
+    ts._pool.clear()
+
+
+def test_upload_cache_detects_new_and_mutated_inputs(monkeypatch):
+    import scipy.sparse as ssp
+
+    made = []
+
+    class Handle:
+        def __init__(self, kind):
+            self.kind, self.closed = kind, False
+            made.append(self)
+
+        def close(self):
+            self.closed = True
+
+    class FakeEngine:
+        def graph(self, A):
+            return Handle("g")
+
+        def features(self, x):
+            return Handle("x")
+
+    monkeypatch.setattr(ts._engine, "default_engine", lambda *a: FakeEngine())
+    ts._cache.clear()
+    A = ssp.csr_matrix(np.array([[0, 1, 0], [1, 0, 1], [0, 1, 0]]))
+    x = torch.ones(3, 2)
+    _, g1, x1 = ts._device_inputs(A, x)
+    _, g2, x2 = ts._device_inputs(A, x)
+    assert g1 is g2 and x1 is x2 and len(made) == 2
+    B = ssp.csr_matrix(np.array([[0, 0, 1], [0, 0, 1], [1, 1, 0]]))    # same shape, same nnz
+    _, g3, _ = ts._device_inputs(B, x)
+    assert g3 is not g1 and g1.closed
+    B.indices[:] = B.indices[::-1].copy()                              # mutated in place
+    _, g4, _ = ts._device_inputs(B, x)
+    assert g4 is not g3
+    x.add_(1.0)                                                        # in-place change of x
+    _, _, x3 = ts._device_inputs(B, x)
+    assert x3 is not x1 and x1.closed
+    xn = np.ones((3, 2), dtype=np.float32)
+    _, _, x4 = ts._device_inputs(B, xn)
+    xn[0, 0] = 5
+    _, _, x5 = ts._device_inputs(B, xn)
+    assert x5 is not x4
+    ts._cache.clear()
