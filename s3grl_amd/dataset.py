@@ -99,8 +99,9 @@ def train_graph(edge_index, num_nodes, edge_weight=None):
 
 def pos_neg_edges(split, split_edge, percent=100):
     """utils.py:637-659 for splits that carry pre-sampled negatives (`do_edge_split` always writes
-    'edge_neg'): [2, P] positives, [2, Q] negatives, optionally sub-sampled with numpy's global
-    generator exactly like the reference (`np.random.permutation`, pos first, then neg)."""
+    'edge_neg'): [2, P] positives, [2, Q] negatives, permuted — and cut to `percent` — with numpy's
+    global generator exactly like the reference (`np.random.permutation`, pos first, then neg; the
+    shuffle happens at percent = 100 too)."""
     pos_edge = torch.as_tensor(split_edge[split]['edge']).t()
     if 'edge_neg' not in split_edge['train']:
         raise NotImplementedError("on-the-fly negative sampling (PyG negative_sampling) is the "
