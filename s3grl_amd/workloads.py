@@ -87,12 +87,23 @@ class Split:
         (sgrl_link_pred.py:852-855)."""
         return self.links["train"][0]
 
-    def all_links(self):
+    def all_links(self, shuffle=True, seed=12345):
         """Concatenation in the order the reference's driver issues its 6 operator calls
-        (train/valid/test x pos,neg; sgrl_link_pred.py:1116-1243, :195-203) -> [2, L], y [L]."""
+        (train/valid/test x pos,neg; sgrl_link_pred.py:1116-1243, :195-203) -> [2, L], y [L].
+        Every list is permuted first, as `get_pos_neg_edges` does with `np.random.permutation`
+        even at percent = 100 (utils.py:650-657): the operators never see the coalesced
+        (row, col) order of the split.  `shuffle=False` keeps that order (locality experiments)."""
+        import os
+
+        if os.environ.get("S3GRL_SORTED_LINKS"):
+            shuffle = False
+        rng = np.random.default_rng(seed)
         parts, ys = [], []
         for s in ("train", "valid", "test"):
             pos, neg = self.links[s]
+            if shuffle:
+                pos = pos[:, rng.permutation(pos.shape[1])]
+                neg = neg[:, rng.permutation(neg.shape[1])]
             parts += [pos, neg]
             ys += [np.ones(pos.shape[1], dtype=np.int64), np.zeros(neg.shape[1], dtype=np.int64)]
         return np.concatenate(parts, axis=1), np.concatenate(ys)

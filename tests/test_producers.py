@@ -76,10 +76,16 @@ def test_edge_split_semantics(name, seed):
     for held in (pos_v, pos_t):
         assert A[held[0], held[1]].sum() == 0, "held-out positives are not in the train graph"
     # the 6 operator calls: positives then negatives, per split (sgrl_link_pred.py:195-203)
-    li, y = sp.all_links()
+    li, y = sp.all_links(shuffle=False)
     assert li.shape[1] == 2 * (pos_tr.shape[1] + n_v + n_t)
     assert np.array_equal(li[:, :pos_tr.shape[1]], pos_tr) and y[:pos_tr.shape[1]].all()
     assert not y[pos_tr.shape[1]:2 * pos_tr.shape[1]].any()
+    # each list is permuted like get_pos_neg_edges does (utils.py:650-657), the blocks stay in place
+    ls, ys = sp.all_links()
+    assert np.array_equal(ys, y) and not np.array_equal(ls, li)
+    Ptr = pos_tr.shape[1]
+    assert np.array_equal(np.sort(key(ls[:, :Ptr])), ktr)
+    assert np.array_equal(np.sort(key(ls[:, Ptr:2 * Ptr])), np.sort(key(neg_tr)))
 
 
 def test_edge_split_counts_of_the_baseline_configs():
