@@ -181,8 +181,8 @@ s3grl_status s3grl_context_create(int32_t device, void* stream, s3grl_context** 
   ctx->device = device;
   ctx->stream = static_cast<hipStream_t>(stream);
   for (auto& e : ctx->ev) S3GRL_HIP_TRY(hipEventCreate(&e));
-  S3GRL_HIP_TRY(hipMalloc(&ctx->d_scalars, 32 * sizeof(int64_t)));
-  S3GRL_HIP_TRY(hipHostMalloc(&ctx->h_scalars, 32 * sizeof(int64_t)));
+  S3GRL_HIP_TRY(hipMalloc(&ctx->d_scalars, 64 * sizeof(int64_t)));
+  S3GRL_HIP_TRY(hipHostMalloc(&ctx->h_scalars, 64 * sizeof(int64_t)));
   *out = ctx;
   return S3GRL_OK;
 }
@@ -280,6 +280,13 @@ s3grl_status s3grl_graph_create(s3grl_context* ctx, int64_t num_nodes, const int
   S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
   g->max_degree = (int32_t)ctx->h_scalars[0];
+  if (onehop_mode_for(g)) {
+    const s3grl_status st = build_forward_rows(ctx, g);
+    if (st != S3GRL_OK) {
+      s3grl_graph_destroy(g);
+      return st;
+    }
+  }
   *out = g;
   return S3GRL_OK;
 }
@@ -288,6 +295,8 @@ s3grl_status s3grl_graph_destroy(s3grl_graph* g) {
   if (!g) return S3GRL_OK;
   g->ctx->arena.release(g->indptr);
   g->ctx->arena.release(g->indices);
+  g->ctx->arena.release(g->fwd_indptr);
+  g->ctx->arena.release(g->fwd_indices);
   delete g;
   return S3GRL_OK;
 }
@@ -319,11 +328,6 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   if (plus && cfg->strategy != S3GRL_STRATEGY_INTERSECTION) {
     set_last_error("check strat: only k_node_set_strategy='intersection' is usable");
     return S3GRL_ERR_NOT_IMPLEMENTED;
-  }
-  if (g->num_nodes > kMaxNodesLds) {
-    set_last_error("num_nodes " + std::to_string(g->num_nodes) + " exceeds the LDS bitmap limit " +
-                   std::to_string(kMaxNodesLds));
-    return S3GRL_ERR_GRAPH_TOO_LARGE;
   }
   if (L >= (int64_t)INT32_MAX / 16) return S3GRL_ERR_INVALID_ARGUMENT;
   if (cfg->rw_m < 0 || cfg->rw_M < 0 || cfg->rw_m > 65535 || cfg->rw_M > 65535 ||
@@ -379,12 +383,13 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   S3GRL_TRY(arena_alloc(ctx, (size_t)L * num_class_lists(), &class_list, tr));
   S3GRL_TRY(arena_alloc(ctx, (size_t)scan_workspace_elems(L), &scan_ws, tr));
 
-  // d_scalars (int64 x 32): [0] err flag, [1] max n, [2] Σ edges, [3] Σ support, [4] Σ vol,
-  // [5] max R, [6] Σ n counting folded links twice, [7] folded links, [8..15] class counts
+  // d_scalars (int64 x 64): [0] err flag, [1] max n, [2] Σ edges, [3] Σ support, [4] Σ vol,
+  // [5] max R, [6] Σ n counting folded links twice, [7] folded links, [16..23] debug stamps,
+  // [32..47] class counts (int32 each, see classify_kernel)
   int64_t* ds = ctx->d_scalars;
   int64_t* hs = ctx->h_scalars;
-  class_count = reinterpret_cast<int32_t*>(ds + 8);
-  S3GRL_HIP_TRY(hipMemsetAsync(ds, 0, 32 * sizeof(int64_t), ctx->stream));
+  class_count = reinterpret_cast<int32_t*>(ds + 32);
+  S3GRL_HIP_TRY(hipMemsetAsync(ds, 0, 64 * sizeof(int64_t), ctx->stream));
   // ScaLed: per-node random walks replace the BFS
   const int rw_m = cfg->rw_m, rw_M = cfg->rw_M;
   int32_t* rw_raw = nullptr;
@@ -415,16 +420,31 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   // longer than the slot are walked again there).  4096 entries cover 97 % of PubMed's 3-hop
   // subgraphs; the slot shrinks when L slots would pass 6 GB.
   S3GRL_TRY(arena_alloc(ctx, (size_t)L * kMaxLevels, &plan->lvl, own));
+  // one-hop plans on big graphs: sizes by intersecting the two sorted rows (no bitmaps, no limit on
+  // num_nodes, no node-list hand-over: link_full_kernel merges the rows again)
+  const bool onehop = cfg->num_hops == 1 && rw_len == 0 && !sampling && onehop_mode_for(g) && g->fwd_indptr;
   int32_t* stash = nullptr;
   int slot = 4096;
   if (const char* e = getenv("S3GRL_STASH_SLOT")) slot = std::max(0, atoi(e));   // test hook; 0 = off
   while (slot > 256 && (int64_t)L * slot * 4 > ((int64_t)6 << 30)) slot >>= 1;
-  if (slot > 0 && (int64_t)L * slot * 4 <= ((int64_t)6 << 30))
+  if (!onehop && slot > 0 && (int64_t)L * slot * 4 <= ((int64_t)6 << 30))
     S3GRL_TRY(arena_alloc(ctx, (size_t)L * slot, &stash, tr));
-  S3GRL_TRY(launch_count(ctx, g, plan->links, L, cfg->num_hops, plus ? 1 : 0, K, rw_raw, rw_len,
-                         partner, mirror_of,
-                         plan->n_nodes, p_nodes, n_rows, n_jobs, lvl_max,
-                         reinterpret_cast<int32_t*>(ds), ds + 6, smp, stash, slot, plan->lvl));
+  int32_t* e_cap = nullptr;
+  if (onehop) {
+    S3GRL_TRY(arena_alloc(ctx, (size_t)L, &e_cap, tr));
+    S3GRL_TRY(launch_count1(ctx, g, plan->links, L, plus ? 1 : 0, K, partner, mirror_of, plan->n_nodes, p_nodes,
+                            n_rows, n_jobs, lvl_max, e_cap, reinterpret_cast<int32_t*>(ds), ds + 6));
+  } else {
+    if (g->num_nodes > kMaxNodesLds) {
+      set_last_error("num_nodes " + std::to_string(g->num_nodes) + " exceeds the LDS bitmap limit " +
+                     std::to_string(kMaxNodesLds) + " of multi-hop / sampled / random-walk plans");
+      return S3GRL_ERR_GRAPH_TOO_LARGE;
+    }
+    S3GRL_TRY(launch_count(ctx, g, plan->links, L, cfg->num_hops, plus ? 1 : 0, K, rw_raw, rw_len,
+                           partner, mirror_of,
+                           plan->n_nodes, p_nodes, n_rows, n_jobs, lvl_max,
+                           reinterpret_cast<int32_t*>(ds), ds + 6, smp, stash, slot, plan->lvl));
+  }
   if (fold) S3GRL_TRY(launch_mirror_rows(ctx, partner, L, n_rows));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, plan->n_nodes, L, plan->node_off, scan_ws));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_rows, L, plan->row_ptr, scan_ws));
@@ -435,8 +455,9 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   // PoS has no common-neighbour rows: the LDS classes are known without a round trip
   if (!plus)
     S3GRL_TRY(launch_classify(ctx, g, 1, K, plan->n_nodes, p_nodes, lvl_max, L, class_count, class_list,
-                              !sampling));
-  S3GRL_HIP_TRY(hipMemcpyAsync(hs, ds, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
+                              !sampling, e_cap));
+  S3GRL_HIP_TRY(hipMemcpyAsync(hs, ds, 8 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipMemcpyAsync(hs + 32, ds + 32, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs + 16, plan->node_off + L, 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs + 17, plan->row_ptr + L, 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs + 18, plan->job_off + L, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -455,16 +476,22 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   const int cn_cap = (int)std::max<int64_t>(max_R - 2, 0) + 1;
   if (plus) {
     S3GRL_TRY(launch_classify(ctx, g, cn_cap, K, plan->n_nodes, p_nodes, lvl_max, L, class_count,
-                              class_list, !sampling));
-    S3GRL_HIP_TRY(hipMemcpyAsync(hs + 8, ds + 8, 8 * 8, hipMemcpyDeviceToHost, ctx->stream));
+                              class_list, !sampling, e_cap));
+    S3GRL_HIP_TRY(hipMemcpyAsync(hs + 32, ds + 32, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
     S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
-  int32_t class_count_host[16];   // [0..5] bitmap classes, [6] HBM-scratch class, [7] its max need,
-                                  // [8..13] hash classes (see classify_kernel)
-  std::memcpy(class_count_host, hs + 8, sizeof(class_count_host));
+  int32_t class_count_host[32];   // [0..5] bitmap classes, [6] HBM-scratch class, [7] its max need,
+                                  // [8..13] hash classes, [14..19] one-hop classes, [20] one-hop
+                                  // class with its bit matrix in HBM (see classify_kernel)
+  std::memcpy(class_count_host, hs + 32, sizeof(class_count_host));
+  if (g->num_nodes > kMaxNodesLds && class_count_host[6] > 0) {
+    set_last_error(std::to_string(class_count_host[6]) + " link(s) of a graph above the LDS bitmap limit "
+                   "do not fit the on-chip one-hop / hash paths");
+    return S3GRL_ERR_GRAPH_TOO_LARGE;
+  }
   if (getenv("S3GRL_DEBUG")) {
     fprintf(stderr, "[s3grl] L=%lld max_n=%lld classes:", (long long)L, (long long)max_n);
-    for (int c = 0; c < 14; ++c) fprintf(stderr, " %d", class_count_host[c]);
+    for (int c = 0; c < 21; ++c) fprintf(stderr, " %d", class_count_host[c]);
     fprintf(stderr, "\n");
   }
   plan->stats.total_nodes = hs[6];          // algorithmic: a folded link counts like any other
@@ -511,7 +538,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
                          plan->node_off,
                          plan->row_ptr, plan->job_off, coef_off, mirror_of, plan->c_ids,
                          plan->c_coef, plan->jobs, plan->job_z, plan->job_lim, plan->row_nodes, plan->lvl, ds + 2,
-                         ds + 3, ds + 4, smp, stash, slot));
+                         ds + 3, ds + 4, smp, stash, slot, e_cap, max_n));
   S3GRL_TRY(record(ctx, 2));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs + 2, ds + 2, 3 * 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));

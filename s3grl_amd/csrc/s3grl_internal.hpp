@@ -99,7 +99,7 @@ struct s3grl_context {
   static constexpr int kSide = 3;
   hipStream_t side[kSide] = {nullptr, nullptr, nullptr};
   hipEvent_t side_ev[kSide + 1] = {nullptr, nullptr, nullptr, nullptr};
-  int64_t* d_scalars = nullptr;  // small device scratch for totals (32 x int64)
+  int64_t* d_scalars = nullptr;  // small device scratch for totals (64 x int64)
   int64_t* h_scalars = nullptr;  // pinned host mirror
 };
 
@@ -110,6 +110,10 @@ struct s3grl_graph {
   int32_t max_degree = 0;      // decides whether the hub-row path of the row walker is armed
   int32_t* indptr = nullptr;   // [N+1] device, int32 (nnz < 2^31)
   int32_t* indices = nullptr;  // [nnz] device
+  // degree-oriented rows (s3grl_onehop.inl), built for big graphs only: every undirected edge once,
+  // in the row of its endpoint of lower (degree, id); self-loops in their own row
+  int32_t* fwd_indptr = nullptr;   // [N+1]
+  int32_t* fwd_indices = nullptr;  // [nnz / 2 (+ self-loops)]
 };
 
 struct s3grl_plan {
@@ -211,7 +215,15 @@ s3grl_status launch_scan_i32_to_i64(s3grl_context* ctx, const int32_t* in, int64
 s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_cap, int K,
                              const int32_t* n_nodes, const int32_t* p_nodes,
                              const int32_t* lvl_max, int64_t L, int32_t* class_count,
-                             int32_t* class_list, bool allow_hash = true);
+                             int32_t* class_list, bool allow_hash = true, const int32_t* e_cap = nullptr);
+// one-hop plans on big graphs (s3grl_onehop.inl): degree-oriented rows of the graph, and the
+// sizing pass that needs no bitmaps
+bool onehop_mode_for(const s3grl_graph* g);
+s3grl_status build_forward_rows(s3grl_context* ctx, s3grl_graph* g);
+s3grl_status launch_count1(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
+                           int plus, int K, const int32_t* partner, const int32_t* mirror_of,
+                           int32_t* n_nodes, int32_t* p_nodes, int32_t* n_rows, int32_t* n_jobs,
+                           int32_t* lvl_max, int32_t* e_cap, int32_t* err_flag, int64_t* tot_nodes_alg);
 s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                           const int32_t* class_list, const int32_t* class_count_host, int hops,
                           int plus, int cn_cap, int full_stats, int K, const int32_t* rw_raw,
@@ -222,7 +234,7 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           int32_t* lvl,
                           int64_t* tot_edges, int64_t* tot_support, int64_t* tot_vol,
                           HopSampling smp = HopSampling{1.0, 0, 0}, const int32_t* stash = nullptr,
-                          int slot = 0);
+                          int slot = 0, const int32_t* e_cap = nullptr, int64_t max_nodes = 0);
 s3grl_status launch_dists(s3grl_context* ctx, const int64_t* node_off, const int32_t* lvl, int64_t L,
                           int8_t* dists);
 // gather.hip

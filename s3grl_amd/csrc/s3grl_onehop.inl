@@ -1,0 +1,436 @@
+// One-hop plans on big graphs (included by s3grl_structure.hip inside namespace s3grl::{anon}).
+//
+// The reference's own answer to large graphs is num_hops = 1 (reference utils.py:57-74 with
+// num_hops = 1: S = {src,dst} ∪ N(src) ∪ N(dst)).  On a power-law graph such a subgraph has a few
+// hundred induced edges but its nodes store ~10^4 neighbours (hubs), and with sign_k - 1 >= 1 every
+// operator reaches all of S.  Walking the global rows through a hash of S for every operator
+// (link_kernel, HS flavour) costs vol(S) probes per pass.  Here instead:
+//
+//   count1_kernel     n = |S|, R, and a bound of the induced entries — by intersecting the two
+//                     sorted rows (binary searches), one wavefront per link, no bitmaps: no limit
+//                     on the number of nodes of the graph.
+//   link_full_kernel  S by a rank merge of the two sorted rows (canonical order: ascending id),
+//                     the masked induced adjacency ONCE as an n x n bit matrix through the
+//                     degree-ORIENTED rows (`fwd`: only the neighbours of higher (degree, id); a
+//                     hub's oriented row is short, Σ over S is ~10x smaller than vol(S)), from it a
+//                     CSR of local ids in LDS, and every operator as a pull over that CSR.
+//
+// Same rows, same coefficients as link_kernel up to the summation order (ascending local id here,
+// stored order of the global row there).
+
+// ---- degree-oriented rows ------------------------------------------------------------------
+// fwd(u) = { v in N(u) : (deg v, v) > (deg u, u) } ∪ ({u} if u has a self-loop), ascending id.
+// Every undirected edge sits in exactly one oriented row; the longest oriented row of a graph
+// with m edges has at most sqrt(2m) entries.
+__device__ __forceinline__ bool fwd_keep(int du, int u, int dv, int v) {
+  return v == u || dv > du || (dv == du && v > u);
+}
+
+__global__ void fwd_count_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                 int64_t N, int32_t* __restrict__ cnt) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= N) return;
+  const int b = indptr[u], e = indptr[u + 1], du = e - b;
+  int c = 0;
+  for (int k = b; k < e; ++k) {
+    const int v = indices[k];
+    c += fwd_keep(du, (int)u, indptr[v + 1] - indptr[v], v) ? 1 : 0;
+  }
+  cnt[u] = c;
+}
+
+__global__ void fwd_fill_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                int64_t N, const int64_t* __restrict__ off64, int32_t* __restrict__ fwd_indptr,
+                                int32_t* __restrict__ fwd_indices) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u > N) return;
+  fwd_indptr[u] = (int32_t)off64[u];
+  if (u == N) return;
+  const int b = indptr[u], e = indptr[u + 1], du = e - b;
+  int o = (int)off64[u];
+  for (int k = b; k < e; ++k) {
+    const int v = indices[k];
+    if (fwd_keep(du, (int)u, indptr[v + 1] - indptr[v], v)) fwd_indices[o++] = v;
+  }
+}
+
+// ---- sizes of a one-hop subgraph --------------------------------------------------------------
+// lower bound of x in an ascending row, through unsigned offsets on a uniform base
+__device__ __forceinline__ int row_lower_bound(const int32_t* __restrict__ a, int n, int x) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// LDS bytes of link_full_kernel beyond its fixed part; `with_bm`: the bit matrix in LDS too
+__host__ __device__ __forceinline__ int full_hash_slots(int n) {
+  int C = 64;
+  while (C < 2 * n) C <<= 1;
+  return C;
+}
+__host__ __device__ __forceinline__ int full_lds_need(int n, int ecap, bool with_bm) {
+  const int WB = (n + 31) >> 5;
+  return 8 * full_hash_slots(n) + 12 * n + 16 + 2 * ((ecap + 1) & ~1) + (with_bm ? 4 * n * WB : 0);
+}
+
+constexpr int kCount1Waves = 4;
+
+__global__ __launch_bounds__(64 * kCount1Waves) void count1_kernel(
+    const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const int32_t* __restrict__ fwd_indptr, int N, const int64_t* __restrict__ links, int64_t L, int plus,
+    int K, const int32_t* __restrict__ partner, const int32_t* __restrict__ mirror_of,
+    int32_t* __restrict__ n_nodes, int32_t* __restrict__ p_nodes, int32_t* __restrict__ n_rows,
+    int32_t* __restrict__ n_jobs, int32_t* __restrict__ lvl_max, int32_t* __restrict__ e_cap,
+    int32_t* __restrict__ err_flag, unsigned long long* __restrict__ tot_nodes_alg) {
+  const int lane = threadIdx.x & 63;
+  const int64_t l = (int64_t)blockIdx.x * kCount1Waves + (threadIdx.x >> 6);
+  if (l >= L) return;
+  const int64_t s64 = links[2 * l], d64 = links[2 * l + 1];
+  const bool bad = s64 < 0 || s64 >= N || d64 < 0 || d64 >= N || s64 == d64;
+  if (bad || (partner && partner[l] >= 0)) {   // invalid link, or a reversed duplicate (its primary works)
+    if (lane == 0) {
+      if (bad) atomicMax(err_flag, s64 == d64 ? 2 : 1);
+      n_nodes[l] = 0;
+      p_nodes[l] = 0;
+      n_rows[l] = 0;
+      n_jobs[l] = 0;
+      lvl_max[l] = 0;
+      e_cap[l] = 0;
+    }
+    return;
+  }
+  const int s = (int)s64, d = (int)d64;
+  const int32_t* __restrict__ rs = indices + indptr[s];
+  const int32_t* __restrict__ rd = indices + indptr[d];
+  const int cs = indptr[s + 1] - indptr[s], cd = indptr[d + 1] - indptr[d];
+  int members = 0, common = 0, loops = 0;
+  long long fsum = (fwd_indptr[s + 1] - fwd_indptr[s]) + (fwd_indptr[d + 1] - fwd_indptr[d]);
+  for (int c0 = 0; c0 < cs; c0 += 64) {
+    const int c = c0 + lane;
+    if (c < cs) {
+      const int x = rs[c];
+      if (x == s) loops += 1;                       // self-loop at src
+      if (x != s && x != d) {
+        const int lb = row_lower_bound(rd, cd, x);
+        const bool dup = lb < cd && rd[lb] == x;
+        members += 1;
+        common += dup ? 1 : 0;
+        if (!dup) fsum += fwd_indptr[x + 1] - fwd_indptr[x];   // common ones are counted from row d
+      }
+    }
+  }
+  for (int c0 = 0; c0 < cd; c0 += 64) {
+    const int c = c0 + lane;
+    if (c < cd) {
+      const int y = rd[c];
+      if (y == d) loops += 1;                       // self-loop at dst
+      if (y != s && y != d) {
+        members += 1;
+        fsum += fwd_indptr[y + 1] - fwd_indptr[y];
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    members += __shfl_xor(members, o);
+    common += __shfl_xor(common, o);
+    loops += __shfl_xor(loops, o);
+    fsum += __shfl_xor(fsum, o);
+  }
+  if (lane == 0) {
+    const int n = 2 + members - common;
+    // PoS Plus rows (common_neighbours above: N'(0) ∩ N'(1) on the masked sub-CSR): the common
+    // neighbours, plus src / dst themselves when they carry a self-loop
+    const int R = plus ? 2 + common + loops : 2;
+    const int cum_a = K >= 2 ? n : 2, cum_b = n;
+    n_nodes[l] = n;
+    p_nodes[l] = R > 2 ? cum_b : cum_a;
+    n_rows[l] = R;
+    n_jobs[l] = (R + 1) / 2;
+    lvl_max[l] = max(2, n - 2);
+    e_cap[l] = (int)min(2ll * fsum, (long long)0x3fffffff);
+    const unsigned long long mult = (mirror_of && mirror_of[l] >= 0) ? 2ull : 1ull;
+    atomicAdd(tot_nodes_alg, mult * (unsigned long long)n);
+  }
+}
+
+// ---- the fused per-link kernel of the full-reach one-hop case ------------------------------------
+// LDS (dynamic): [hkeys C | hvals C]  (aliased by the float2 state arrays cur[n], nxs[n] once the
+// probes are done: 8C >= 16n)  cn[cn_cap] cnpos[cn_cap] lvl_end[2] zbuf[4K] sh[32]
+// list[n] dinv[n] off[n+1] cols[ecap] (uint16 local ids)  bm[n][WB] (BMG: in a per-workgroup HBM slice)
+template <int T, int K, bool BMG>
+__global__ __launch_bounds__(T) void link_full_kernel(
+    const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const int32_t* __restrict__ fwd_indptr, const int32_t* __restrict__ fwd_indices,
+    const int64_t* __restrict__ links, const int32_t* __restrict__ class_list, int count, int plus,
+    int cn_cap, const int32_t* __restrict__ e_cap, const int64_t* __restrict__ node_off,
+    const int64_t* __restrict__ row_ptr, const int64_t* __restrict__ job_off,
+    const int64_t* __restrict__ coef_off, const int32_t* __restrict__ mirror_of,
+    int32_t* __restrict__ c_ids, float* __restrict__ c_coef, Job* __restrict__ jobs,
+    float* __restrict__ job_z, int32_t* __restrict__ job_lim, int64_t* __restrict__ row_nodes,
+    int32_t* __restrict__ lvl_out, unsigned long long* __restrict__ tot_edges,
+    unsigned long long* __restrict__ tot_support, unsigned long long* __restrict__ tot_vol,
+    uint32_t* __restrict__ bm_scratch, int64_t bm_stride_words) {
+  extern __shared__ uint32_t smem[];
+  const int tid = threadIdx.x;
+  constexpr int G = 4;
+  // BMG: a persistent grid, every workgroup owns one bit-matrix slice and strides over the class
+  for (int item = blockIdx.x; item < count; item += gridDim.x) {
+    const int l = class_list[item];
+    const int64_t noff = node_off[l];
+    const int n = (int)(node_off[l + 1] - noff);
+    const int ecap = (e_cap[l] + 1) & ~1;
+    const int mirror = mirror_of ? mirror_of[l] : -1;
+    const int64_t mrp = mirror >= 0 ? row_ptr[mirror] : -1;
+    const int C = full_hash_slots(n);
+    const uint32_t hmask = (uint32_t)(C - 1);
+    const int WB = (n + 31) >> 5;
+    int32_t* hkeys = reinterpret_cast<int32_t*>(smem);
+    int32_t* hvals = hkeys + C;
+    float2* cur = reinterpret_cast<float2*>(smem);          // aliases the hash (used after the probes)
+    float2* nxs = cur + n;
+    int32_t* cn = reinterpret_cast<int32_t*>(smem + 2 * C);
+    int32_t* cnpos = cn + cn_cap;
+    int* lvl_end = cnpos + cn_cap;                           // [2]
+    float* zbuf = reinterpret_cast<float*>(lvl_end + 2);     // [2][K][2]
+    int* sh = reinterpret_cast<int*>(zbuf + 4 * K);          // [32]
+    int32_t* list = sh + 32;
+    float* dinv = reinterpret_cast<float*>(list + n);
+    int32_t* off = reinterpret_cast<int32_t*>(dinv + n);     // [n+1]
+    uint16_t* cols = reinterpret_cast<uint16_t*>(off + n + 1 + ((n + 1) & 1));
+    // the bit matrix: in LDS, or (BMG) in this workgroup's HBM slice — set with atomics that
+    // execute at the L2, so it is read back with agent-scope loads that bypass the CU's L1
+    uint32_t* bm_l = reinterpret_cast<uint32_t*>(cols + ecap);
+    uint32_t* bm_g = bm_scratch + (int64_t)blockIdx.x * bm_stride_words;
+    auto bm_or = [&](int64_t idx, uint32_t m) {
+      if constexpr (BMG) atomicOr(&bm_g[idx], m); else atomicOr(&bm_l[idx], m);
+    };
+    auto bm_ld = [&](int64_t idx) -> uint32_t {
+      if constexpr (BMG) return __hip_atomic_load(&bm_g[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else return bm_l[idx];
+    };
+
+    const int src = (int)links[2 * (int64_t)l], dst = (int)links[2 * (int64_t)l + 1];
+    const int32_t* __restrict__ rs = indices + indptr[src];
+    const int32_t* __restrict__ rd = indices + indptr[dst];
+    const int cs = indptr[src + 1] - indptr[src], cd = indptr[dst + 1] - indptr[dst];
+
+    // ---- S in canonical order: {min,max}, then N(src) ∪ N(dst) \ {src,dst} ascending ------------
+    // rank merge of the two sorted rows: element x of one row lands at (its index among the row's
+    // own members) + (members of the other row below x) - (common members below x).  Phase 1 keeps
+    // (lower bound in the other row, common?, member?) per element in `tmp` (the hash's space:
+    // 4(cs+cd) <= 8n <= 4C... the two tables together hold 2C >= 4n words); phase 2 turns the
+    // per-row prefix counts of "common" into positions.
+    uint32_t* tmp = smem;   // [cs + cd]
+    const bool s_has_s = sorted_contains(rs, cs, src), s_has_d = sorted_contains(rs, cs, dst);
+    const bool d_has_s = sorted_contains(rd, cd, src), d_has_d = sorted_contains(rd, cd, dst);
+    for (int e = tid; e < cs + cd; e += T) {
+      const bool from_s = e < cs;
+      const int x = from_s ? rs[e] : rd[e - cs];
+      const bool member = x != src && x != dst;
+      const int lb = from_s ? row_lower_bound(rd, cd, x) : row_lower_bound(rs, cs, x);
+      const bool dup = member && (from_s ? (lb < cd && rd[lb] == x) : (lb < cs && rs[lb] == x));
+      tmp[e] = ((uint32_t)lb << 2) | (dup ? 2u : 0u) | (member ? 1u : 0u);
+    }
+    if (tid == 0) {
+      list[0] = min(src, dst);
+      list[1] = max(src, dst);
+      lvl_end[0] = 2;
+      lvl_end[1] = n;
+    }
+    __syncthreads();
+    for (int side = 0; side < 2; ++side) {
+      const int base = side == 0 ? 0 : cs, len = side == 0 ? cs : cd;
+      const int32_t* __restrict__ row = side == 0 ? rs : rd;
+      const int per = (len + T - 1) / T;
+      const int e0 = min(tid * per, len), e1 = min(e0 + per, len);
+      int dups = 0;
+      for (int e = e0; e < e1; ++e) dups += (tmp[base + e] >> 1) & 1u;
+      int total;
+      int c = block_excl_scan<T>(dups, sh, total);
+      // excluded entries (src, dst themselves) below x, in this row and in the other one
+      const bool own_s = side == 0 ? s_has_s : d_has_s, own_d = side == 0 ? s_has_d : d_has_d;
+      const bool oth_s = side == 0 ? d_has_s : s_has_s, oth_d = side == 0 ? d_has_d : s_has_d;
+      for (int e = e0; e < e1; ++e) {
+        const uint32_t w = tmp[base + e];
+        const bool dup = (w >> 1) & 1u;
+        if ((w & 1u) && !(side == 1 && dup)) {       // common members are emitted from row src only
+          const int x = row[e];
+          const int own = e - ((own_s && src < x) ? 1 : 0) - ((own_d && dst < x) ? 1 : 0);
+          const int oth = (int)(w >> 2) - ((oth_s && src < x) ? 1 : 0) - ((oth_d && dst < x) ? 1 : 0);
+          const int pos = 2 + own + oth - c;
+          if (pos < n) list[pos] = x;
+        }
+        c += dup ? 1 : 0;
+      }
+    }
+    __syncthreads();   // list complete, tmp dead
+
+    // ---- hash of S (probe structure), node list out, bit matrix zeroed --------------------------
+    for (uint32_t t = tid; t <= hmask; t += T) hkeys[t] = -1;
+    for (int i = tid; i < n * WB; i += T) {
+      if constexpr (BMG) bm_g[i] = 0; else bm_l[i] = 0;
+    }
+    __syncthreads();
+    int vol_local = 0;
+    for (int t = tid; t < n; t += T) {
+      const int v = list[t];
+      hs_insert(hkeys, hmask, v);
+      hvals[hs_find(hkeys, hmask, v)] = t;
+      c_ids[noff + t] = v;
+      vol_local += indptr[v + 1] - indptr[v];
+    }
+    const int64_t rp = row_ptr[l];
+    const int R = (int)(row_ptr[l + 1] - rp);
+    __syncthreads();
+    if (plus && tid < 64)
+      common_neighbours(indptr, indices, [&](int x) { return hs_find(hkeys, hmask, x) >= 0; }, src, dst, cn);
+    if (tid == 0)
+      for (int dd = 0; dd < kMaxLevels; ++dd)
+        lvl_out[(int64_t)l * kMaxLevels + dd] = dd == 0 ? 2 : n;
+    __syncthreads();
+    for (int r = tid; r < R; r += T) {
+      const int node = r == 0 ? src : (r == 1 ? dst : cn[r - 2]);
+      row_nodes[rp + r] = node;
+      if (mirror >= 0) row_nodes[mrp + r] = r == 0 ? dst : (r == 1 ? src : cn[r - 2]);
+      if (r >= 2) cnpos[r - 2] = hvals[hs_find(hkeys, hmask, node)];
+    }
+    const int pos_src = src < dst ? 0 : 1, pos_dst = 1 - pos_src;
+
+    // ---- masked induced adjacency through the oriented rows (reference utils.py:76-80) ----------
+    walk_rows<T, G, 2>(
+        0, n, list, fwd_indptr, fwd_indices, nullptr,
+        [&](RowAcc& a, int v, int u, bool valid) {
+          const int slot = hs_find(hkeys, hmask, u);
+          const int j = hvals[max(slot, 0)];
+          const int i = a.row;
+          const bool target = (v == src && u == dst) || (v == dst && u == src);
+          if (valid && slot >= 0 && !target) {
+            bm_or((int64_t)i * WB + (j >> 5), 1u << (j & 31));
+            if (i != j) bm_or((int64_t)j * WB + (i >> 5), 1u << (i & 31));
+          }
+        },
+        [](RowAcc&, int, int) {});
+    __syncthreads();
+
+    // ---- degrees, D^-1/2 (inf -> 0), CSR of local ids (ascending) --------------------------------
+    {
+      const int per = (n + T - 1) / T;
+      const int t0 = min(tid * per, n), t1 = min(t0 + per, n);
+      int mine = 0;
+      for (int t = t0; t < t1; ++t) {
+        int dg = 0;
+        for (int j = 0; j < WB; ++j) dg += __popc(bm_ld((int64_t)t * WB + j));
+        mine += dg;
+      }
+      int total;
+      int run = block_excl_scan<T>(mine, sh, total);
+      for (int t = t0; t < t1; ++t) {
+        off[t] = run;
+        int k = run;
+        for (int j = 0; j < WB; ++j) {
+          uint32_t w = bm_ld((int64_t)t * WB + j);
+          while (w) {
+            const int b = __ffs(w) - 1;
+            w &= w - 1;
+            if (k < ecap) cols[k] = (uint16_t)(j * 32 + b);
+            ++k;
+          }
+        }
+        const int dg = k - run;
+        dinv[t] = dg > 0 ? 1.0f / sqrtf((float)dg) : 0.0f;
+        run = k;
+      }
+      if (tid == 0) off[n] = total;
+    }
+    __syncthreads();   // hash dead from here: cur / nxs take its space
+    const int edges_total = off[n];
+
+    // ---- per row pair: K pulls over the CSR ------------------------------------------------------
+    const int npairs = (R + 1) / 2;
+    for (int pr = 0; pr < npairs; ++pr) {
+      const int64_t jid = job_off[l] + pr;
+      const int64_t coff = coef_off ? coef_off[jid] : noff;
+      const int node_a = pr == 0 ? src : cn[2 * pr - 2];
+      const int node_b = pr == 0 ? dst : (2 * pr + 1 < R ? cn[2 * pr - 1] : -1);
+      const int la = pr == 0 ? pos_src : cnpos[2 * pr - 2];
+      const int lb = pr == 0 ? pos_dst : (node_b >= 0 ? cnpos[2 * pr - 1] : -1);
+      for (int w = tid; w < n; w += T) {
+        cur[w] = make_float2(w == la ? dinv[w] : 0.f, w == lb ? dinv[w] : 0.f);
+      }
+      if (tid < 4 * K) zbuf[tid] = 0.f;
+      __syncthreads();
+      float2* s_in = cur;
+      float2* s_out = nxs;
+      float2* coef = reinterpret_cast<float2*>(c_coef) + coff * K;   // [K][n] float2
+#pragma unroll 1
+      for (int i = 0; i < K; ++i) {
+        const int g = tid & (G - 1);
+        for (int base = 0; base < n; base += T / G) {
+          const int t = base + tid / G;
+          float ax = 0.f, ay = 0.f;
+          if (t < n) {
+            const int k1 = off[t + 1];
+            for (int k = off[t] + g; k < k1; k += G) {
+              const float2 sv = s_in[cols[k]];
+              ax += sv.x;
+              ay += sv.y;
+            }
+          }
+#pragma unroll
+          for (int o = G / 2; o > 0; o >>= 1) {
+            ax += __shfl_xor(ax, o);
+            ay += __shfl_xor(ay, o);
+          }
+          if (t < n && g == 0) {
+            const float dw = dinv[t];
+            const float rx = dw * ax, ry = dw * ay;
+            s_out[t] = make_float2(dw * rx, dw * ry);
+            coef[(int64_t)i * n + t] = make_float2(rx, ry);
+            // label column of operator i+1: r[src] + r[dst]  (tuned_SIGN.py:177-185)
+            if (t == pos_src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
+            if (t == pos_dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
+          }
+        }
+        __syncthreads();
+        float2* tmp2 = s_in;
+        s_in = s_out;
+        s_out = tmp2;
+      }
+      if (tid < 2 * K) {
+        const int i = tid >> 1, r = tid & 1;
+        job_z[(jid * K + i) * 2 + r] = zbuf[(0 * K + i) * 2 + r] + zbuf[(1 * K + i) * 2 + r];
+      }
+      // operator i+1 reaches the list prefix within i+1 hops of the row; with one hop that is the
+      // whole list from the first operator on (from the second for nothing: n == support)
+      if (tid < K) job_lim[jid * K + tid] = n;
+      if (tid == 0) {
+        Job j;
+        j.coef_off = coff * K;
+        j.ids_off = noff;
+        j.out_row = rp + 2 * pr;
+        j.link = l;
+        j.support = n;
+        j.node_a = node_a;
+        j.node_b = node_b;
+        j.z_a = (node_a == src || node_a == dst) ? 1 : 0;
+        j.z_b = (node_b == src || node_b == dst) ? 1 : 0;
+        j.mirror_row = mirror >= 0 ? mrp + 2 * pr : -1;
+        j.mirror_swap = pr == 0 ? 1 : 0;
+        j.pad = 0;
+        jobs[jid] = j;
+        atomicAdd(tot_support, (unsigned long long)n * (mirror >= 0 ? 2ull : 1ull));
+      }
+      __syncthreads();
+    }
+    vol_local = block_sum<T>(vol_local, sh);
+    if (tid == 0) {
+      atomicAdd(tot_edges, (unsigned long long)edges_total * (mirror >= 0 ? 2ull : 1ull));
+      atomicAdd(tot_vol, (unsigned long long)vol_local * (mirror >= 0 ? 2ull : 1ull));
+    }
+    __syncthreads();   // LDS is reused by the next item of a persistent workgroup
+  }
+}

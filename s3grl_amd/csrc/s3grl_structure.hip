@@ -422,6 +422,8 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restri
   }
 }
 
+#include "s3grl_onehop.inl"
+
 // ---------------------------------------------------------------------------------------
 // LDS bytes link_kernel needs beyond its fixed part: list[n] + dinvP[p] + two float2 state
 // arrays [p] (+ alignment slack); the hash flavour adds its keys/vals tables.
@@ -446,12 +448,17 @@ struct ClassBounds {
 // kSparseBase.. = hash flavour by LDS need.  class_count[kNumClasses + 1] = max need of the
 // HBM-scratch class.
 constexpr int kSparseBase = kNumClasses + 2;
-constexpr int kNumLists = kSparseBase + kNumClasses;
+// kFullBase.. = one-hop full-reach links for link_full_kernel by LDS need (bit matrix in LDS),
+// kFullBig = the same with the bit matrix in an HBM slice (subgraphs of more than ~700 nodes)
+constexpr int kFullBase = kSparseBase + kNumClasses;
+constexpr int kFullBig = kFullBase + kNumClasses;
+constexpr int kNumLists = kFullBig + 1;
 
 __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
                                 const int32_t* __restrict__ p_nodes,
                                 const int32_t* __restrict__ lvl_max, int64_t L, ClassBounds bound,
-                                int sparse_mode, ClassBounds sbound,
+                                int sparse_mode, ClassBounds sbound, const int32_t* __restrict__ e_cap,
+                                ClassBounds fbound, int bm_limit,
                                 int32_t* __restrict__ class_count, int32_t* __restrict__ class_list) {
   const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int n = l < L ? n_nodes[l] : 0;
@@ -459,7 +466,22 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
   int need = link_lds_need(n, p);
   int c = 0;
   bool sparse = false;
-  if (sparse_mode && n > 0 && lvl_max[l] <= kSparseLevelMax) {
+  // one-hop plan (e_cap is only produced for those), every operator reaches all of S, local ids fit
+  // 16 bits: link_full_kernel, by its LDS need with or without the bit matrix on chip
+  if (e_cap && n > 0 && p == n && n <= 65535) {
+    const int ec = e_cap[l];
+    const int need_a = full_lds_need(n, ec, true), need_b = full_lds_need(n, ec, false);
+    if (need_a <= min(fbound.b[kNumClasses - 1], bm_limit)) {
+      sparse = true;
+#pragma unroll
+      for (int k = 0; k < kNumClasses; ++k) c += need_a > fbound.b[k] ? 1 : 0;
+      c += kFullBase;
+    } else if (need_b <= fbound.b[kNumClasses - 1]) {
+      sparse = true;
+      c = kFullBig;
+    }
+  }
+  if (!sparse && sparse_mode && n > 0 && lvl_max[l] <= kSparseLevelMax) {
     const int sneed = link_lds_need_sparse(n, p);
     if (sneed <= sbound.b[kNumClasses - 1]) {
       sparse = true;
@@ -1208,6 +1230,16 @@ static ClassBounds class_bounds_sparse(int cn_cap, int K) {
   return cb;
 }
 
+// link_full_kernel: fixed LDS = cn + cnpos + lvl_end[2] + zbuf + scan scratch
+static inline int full_fixed_words(int cn_cap, int K) { return 2 * cn_cap + 2 + 4 * K + 32; }
+static ClassBounds class_bounds_full(int cn_cap, int K) {
+  static const int nominal[kNumClasses] = {3072, 6144, 12288, 24576, 65536, 160000};
+  const int avail = 163840 - 4 * full_fixed_words(cn_cap, K);
+  ClassBounds cb;
+  for (int c = 0; c < kNumClasses; ++c) cb.b[c] = std::min(nominal[c], avail);
+  return cb;
+}
+
 // The hash flavour pays off when the bitmaps alone would hold a CU to a few workgroups.
 bool sparse_mode_for(const s3grl_graph* g) {
   if (getenv("S3GRL_FORCE_HASH")) return true;   // test hook
@@ -1217,20 +1249,77 @@ bool sparse_mode_for(const s3grl_graph* g) {
 
 int num_class_lists() { return kNumLists; }
 
+// One-hop plans take the row-intersection path on graphs where the hash flavour is in use anyway.
+bool onehop_mode_for(const s3grl_graph* g) {
+  if (getenv("S3GRL_NO_ONEHOP")) return false;
+  if (getenv("S3GRL_FORCE_ONEHOP")) return true;   // test hook
+  return sparse_mode_for(g);
+}
+
+s3grl_status build_forward_rows(s3grl_context* ctx, s3grl_graph* g) {
+  const int64_t N = g->num_nodes;
+  Transient tmp{ctx, {}};
+  void* q = nullptr;
+  S3GRL_TRY(ctx->arena.alloc((size_t)N * 4, &q));
+  tmp.ptrs.push_back(q);
+  int32_t* cnt = static_cast<int32_t*>(q);
+  S3GRL_TRY(ctx->arena.alloc((size_t)(N + 1) * 8, &q));
+  tmp.ptrs.push_back(q);
+  int64_t* off64 = static_cast<int64_t*>(q);
+  S3GRL_TRY(ctx->arena.alloc((size_t)scan_workspace_elems(N) * 8, &q));
+  tmp.ptrs.push_back(q);
+  int64_t* ws = static_cast<int64_t*>(q);
+  const unsigned grid = (unsigned)((N + 255) / 256);
+  hipLaunchKernelGGL(fwd_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, g->indptr, g->indices, N, cnt);
+  S3GRL_HIP_TRY(hipGetLastError());
+  S3GRL_TRY(launch_scan_i32_to_i64(ctx, cnt, N, off64, ws));
+  S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_scalars, off64 + N, 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const int64_t fnnz = ctx->h_scalars[0];
+  S3GRL_TRY(ctx->arena.alloc((size_t)(N + 1) * 4, &q));
+  g->fwd_indptr = static_cast<int32_t*>(q);
+  S3GRL_TRY(ctx->arena.alloc((size_t)std::max<int64_t>(fnnz, 1) * 4, &q));
+  g->fwd_indices = static_cast<int32_t*>(q);
+  hipLaunchKernelGGL(fwd_fill_kernel, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
+                     g->indptr, g->indices, N, off64, g->fwd_indptr, g->fwd_indices);
+  S3GRL_HIP_TRY(hipGetLastError());
+  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));   // tmp is released on return
+  return S3GRL_OK;
+}
+
+s3grl_status launch_count1(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
+                           int plus, int K, const int32_t* partner, const int32_t* mirror_of,
+                           int32_t* n_nodes, int32_t* p_nodes, int32_t* n_rows, int32_t* n_jobs,
+                           int32_t* lvl_max, int32_t* e_cap, int32_t* err_flag, int64_t* tot_nodes_alg) {
+  if (L == 0) return S3GRL_OK;
+  hipLaunchKernelGGL(count1_kernel, dim3((unsigned)((L + kCount1Waves - 1) / kCount1Waves)),
+                     dim3(64 * kCount1Waves), 0, ctx->stream, g->indptr, g->indices, g->fwd_indptr,
+                     (int)g->num_nodes, links, L, plus, K, partner, mirror_of, n_nodes, p_nodes, n_rows,
+                     n_jobs, lvl_max, e_cap, err_flag, reinterpret_cast<unsigned long long*>(tot_nodes_alg));
+  S3GRL_HIP_TRY(hipGetLastError());
+  return S3GRL_OK;
+}
+
 s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_cap, int K,
                              const int32_t* n_nodes, const int32_t* p_nodes,
                              const int32_t* lvl_max, int64_t L, int32_t* class_count,
-                             int32_t* class_list, bool allow_hash) {
+                             int32_t* class_list, bool allow_hash, const int32_t* e_cap) {
   if (L == 0) return S3GRL_OK;
-  const ClassBounds cb = class_bounds(g->num_nodes, cn_cap, K);
+  ClassBounds cb = class_bounds(g->num_nodes, cn_cap, K);
   if (cb.b[kNumClasses - 1] < 0) {
-    set_last_error("num_nodes " + std::to_string(g->num_nodes) +
-                   ": the LDS bitmaps alone exceed 160 KiB");
-    return S3GRL_ERR_GRAPH_TOO_LARGE;
+    // the N-bit bitmaps of the bitmap flavour do not fit: only the hash / one-hop classes exist
+    if (!(allow_hash && sparse_mode_for(g))) {
+      set_last_error("num_nodes " + std::to_string(g->num_nodes) +
+                     ": the LDS bitmaps alone exceed 160 KiB");
+      return S3GRL_ERR_GRAPH_TOO_LARGE;
+    }
+    for (int c = 0; c < kNumClasses; ++c) cb.b[c] = -1;   // every link "overflows" them
   }
   hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream,
                      n_nodes, p_nodes, lvl_max, L, cb, (allow_hash && sparse_mode_for(g)) ? 1 : 0,
-                     class_bounds_sparse(cn_cap, K), class_count, class_list);
+                     class_bounds_sparse(cn_cap, K), e_cap, class_bounds_full(cn_cap, K),
+                     getenv("S3GRL_FORCE_BM_HBM") ? 0 : (1 << 30),   // test hook: bit matrices in HBM
+                     class_count, class_list);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -1261,7 +1350,34 @@ struct LinkArgs {
   HopSampling smp;
   const int32_t* stash;
   int slot;
+  const int32_t* e_cap;
+  uint32_t* bm_scratch;
+  int64_t bm_stride_words;
+  int bm_grid;
 };
+
+// One-hop full-reach classes (link_full_kernel).  Small classes run one wavefront per link (no
+// cross-wave barriers to pay for 25-node subgraphs), the others four; the class whose bit matrix
+// lives in HBM runs a persistent grid, one matrix slice per resident workgroup.
+template <int T, int K, bool BMG>
+s3grl_status launch_full_class(s3grl_context* ctx, const LinkArgs& a, int64_t L, int cls, int count,
+                               hipStream_t stream, uint32_t* bm_scratch, int64_t bm_stride_words, int grid) {
+  const ClassBounds fb = class_bounds_full(a.cn_cap, K);
+  const size_t lds = (size_t)4 * full_fixed_words(a.cn_cap, K) +
+                     (size_t)fb.b[cls == kFullBig ? kNumClasses - 1 : cls - kFullBase];
+  auto kern = link_full_kernel<T, K, BMG>;
+  S3GRL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(T), lds, stream, a.g->indptr, a.g->indices,
+                     a.g->fwd_indptr, a.g->fwd_indices, a.links, a.class_list + (int64_t)cls * L, count,
+                     a.plus, a.cn_cap, a.e_cap, a.node_off, a.row_ptr, a.job_off, a.coef_off, a.mirror_of,
+                     a.c_ids, a.c_coef, a.jobs, a.job_z, a.job_lim, a.row_nodes, a.lvl,
+                     reinterpret_cast<unsigned long long*>(a.tot_edges),
+                     reinterpret_cast<unsigned long long*>(a.tot_support),
+                     reinterpret_cast<unsigned long long*>(a.tot_vol), bm_scratch, bm_stride_words);
+  S3GRL_HIP_TRY(hipGetLastError());
+  return S3GRL_OK;
+}
 
 template <int T, int K, int G, bool GS, bool HS>
 s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t L, int cls, int count,
@@ -1343,6 +1459,17 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
   // largest subgraphs first: they are the long poles of the tail
   if (class_count_host[kNumClasses] > 0)
     S3GRL_TRY((launch_link_class<1024, K>(ctx, a, L, kNumClasses, class_count_host[kNumClasses], next_stream())));
+  if (class_count_host[kFullBig] > 0)
+    S3GRL_TRY((launch_full_class<256, K, true>(ctx, a, L, kFullBig, class_count_host[kFullBig], next_stream(),
+                                                 a.bm_scratch, a.bm_stride_words, a.bm_grid)));
+  for (int c = kFullBig - 1; c >= kFullBase; --c) {
+    const int count = class_count_host[c];
+    if (count == 0) continue;
+    if (c - kFullBase <= 1)
+      S3GRL_TRY((launch_full_class<64, K, false>(ctx, a, L, c, count, next_stream(), nullptr, 0, count)));
+    else
+      S3GRL_TRY((launch_full_class<256, K, false>(ctx, a, L, c, count, next_stream(), nullptr, 0, count)));
+  }
   for (int c = kNumLists - 1; c >= kSparseBase; --c)
     if (class_count_host[c] > 0)
       S3GRL_TRY((launch_link_class<256, K>(ctx, a, L, c, class_count_host[c], next_stream())));
@@ -1376,7 +1503,8 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           float* c_coef, Job* jobs, float* job_z, int32_t* job_lim, int64_t* row_nodes,
                           int32_t* lvl,
                           int64_t* tot_edges, int64_t* tot_support, int64_t* tot_vol,
-                          HopSampling smp, const int32_t* stash, int slot) {
+                          HopSampling smp, const int32_t* stash, int slot, const int32_t* e_cap,
+                          int64_t max_nodes) {
   if (L == 0) return S3GRL_OK;
   // links too large for LDS keep their lists in HBM scratch: one 256-byte aligned slice each
   Transient scratch_owner{ctx, {}};
@@ -1394,7 +1522,17 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
              job_off, coef_off, mirror_of, c_ids, c_coef, jobs, job_z, job_lim, row_nodes, lvl, tot_edges,
              tot_support, tot_vol, scratch, scratch_stride,
              getenv("S3GRL_DEBUG_STAMPS") ? reinterpret_cast<unsigned long long*>(ctx->d_scalars + 16) : nullptr,
-             smp, stash, slot};
+             smp, stash, slot, e_cap, nullptr, 0, 0};
+  // the class whose bit matrix does not fit LDS: one slice per resident workgroup of a persistent grid
+  if (class_count_host[kFullBig] > 0) {
+    const int64_t WB = (max_nodes + 31) / 32;
+    a.bm_stride_words = (max_nodes * WB + 63) / 64 * 64;
+    a.bm_grid = (int)std::min<int64_t>(class_count_host[kFullBig], 256 * 2);
+    void* q = nullptr;
+    S3GRL_TRY(ctx->arena.alloc((size_t)a.bm_stride_words * 4 * a.bm_grid, &q));
+    scratch_owner.ptrs.push_back(q);
+    a.bm_scratch = static_cast<uint32_t*>(q);
+  }
   switch (K) {
     case 1: return launch_links_k<1>(ctx, a, L, class_count_host);
     case 2: return launch_links_k<2>(ctx, a, L, class_count_host);

@@ -1,0 +1,162 @@
+"""-m gpu: one-hop plans on the row-intersection path (count1_kernel + link_full_kernel,
+csrc/s3grl_onehop.inl) — forced here on the small fixture graphs (S3GRL_FORCE_ONEHOP; big graphs
+take it by themselves) and compared with the bitmap flavour of the same plan, with the
+reference-pinned extraction fixtures and with the fp64 oracle."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import EXTRACT_NAMES, csr_from_undirected, load_extract
+from test_gpu_parity import TOL, _ragged, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def eng():
+    import torch
+    from s3grl_amd.engine import Engine
+
+    assert torch.cuda.is_available()
+    e = Engine("cuda:0")
+    yield e
+    e.close()
+
+
+def _plans(eng, monkeypatch, A, links, mode, K, bm_hbm=False):
+    """(bitmap-flavour plan, one-hop-path plan) of the same one-hop request."""
+    for k in ("S3GRL_FORCE_ONEHOP", "S3GRL_FORCE_HASH", "S3GRL_FORCE_BM_HBM"):
+        monkeypatch.delenv(k, raising=False)
+    G0 = eng.graph(A)
+    p0 = eng.plan(G0, links, mode=mode, num_hops=1, sign_k=K, full_stats=True)
+    monkeypatch.setenv("S3GRL_FORCE_ONEHOP", "1")
+    monkeypatch.setenv("S3GRL_FORCE_HASH", "1")
+    if bm_hbm:
+        monkeypatch.setenv("S3GRL_FORCE_BM_HBM", "1")
+    G1 = eng.graph(A)                      # the oriented rows are built with the graph
+    p1 = eng.plan(G1, links, mode=mode, num_hops=1, sign_k=K, full_stats=True)
+    for k in ("S3GRL_FORCE_ONEHOP", "S3GRL_FORCE_HASH", "S3GRL_FORCE_BM_HBM"):
+        monkeypatch.delenv(k, raising=False)
+    return (G0, p0), (G1, p1)
+
+
+@pytest.mark.parametrize("name", EXTRACT_NAMES)
+@pytest.mark.parametrize("K,bm_hbm", [(1, False), (2, False), (3, True), (5, False)])
+def test_onehop_path_equals_bitmap_flavour(eng, monkeypatch, name, K, bm_hbm):
+    import torch
+
+    g = load_extract(name)
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = np.random.default_rng(17).standard_normal((n, 19)).astype(np.float32)
+    f = eng.features(X)
+    links = eng.links(g["links"].T)
+    for mode in ("pos", "pos_plus"):
+        (G0, p0), (G1, p1) = _plans(eng, monkeypatch, A, links, mode, K, bm_hbm)
+        r0, r1 = p0.run(f), p1.run(f)
+        assert torch.equal(p0.row_ptr(), p1.row_ptr()) and torch.equal(p0.row_nodes(), p1.row_nodes())
+        for a, b in zip(p0.export_subgraphs(), p1.export_subgraphs()):
+            assert torch.equal(a, b)                      # node lists, canonical order, hop distances
+        s0, s1 = dict(p0.stats), dict(p1.stats)
+        s0.pop("workspace_bytes"), s1.pop("workspace_bytes")
+        assert s0 == s1                                   # n, vol(S), induced edges, support: exact
+        assert rel_err(r1.cpu().numpy(), r0.cpu().numpy()) < 1e-6
+        # bit-reproducible against itself
+        r1b = p1.run(f)
+        assert torch.equal(r1, r1b)
+        p0.close(), p1.close(), G0.close(), G1.close()
+
+
+@pytest.mark.parametrize("name", ["usair", "rand300", "probe5"])
+def test_onehop_path_node_sets_vs_reference_fixture(eng, monkeypatch, name):
+    """Hop-1 node sets and CN rows against what the reference's own k_hop_subgraph produced."""
+    g = load_extract(name)
+    if 1 not in [int(h) for h in g["hops"]]:
+        pytest.skip("fixture has no 1-hop case")
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    links = eng.links(g["links"].T)
+    _, (G1, p1) = _plans(eng, monkeypatch, A, links, "pos_plus", 3)
+    node_ptr, nodes, dists = (t.cpu().numpy() for t in p1.export_subgraphs())
+    row_ptr, row_nodes = p1.row_ptr().cpu().numpy(), p1.row_nodes().cpu().numpy()
+    for li, (s, d) in enumerate(g["links"]):
+        np.testing.assert_array_equal(nodes[node_ptr[li]:node_ptr[li + 1]], _ragged(g, "h1_nodes", li))
+        np.testing.assert_array_equal(dists[node_ptr[li]:node_ptr[li + 1]], _ragged(g, "h1_dists", li))
+        rn = row_nodes[row_ptr[li]:row_ptr[li + 1]]
+        assert rn[0] == s and rn[1] == d
+        np.testing.assert_array_equal(rn[2:], _ragged(g, "h1_cn", li))
+    exp_e = sum(int((_ragged(g, "h1_sub", li)[:, 2] != 0).sum()) for li in range(len(g["links"])))
+    assert p1.stats["total_sub_edges"] == exp_e
+    p1.close(), G1.close()
+
+
+@pytest.mark.parametrize("mode", ["pos", "pos_plus"])
+@pytest.mark.parametrize("bm_hbm", [False, True])
+def test_onehop_path_vs_oracle_with_self_loops_and_hubs(eng, monkeypatch, mode, bm_hbm):
+    """A graph with self-loops at link endpoints and at common neighbours, a hub adjacent to
+    everything, isolated endpoints, and links in both directions (folded) — against the oracle."""
+    import scipy.sparse as ssp
+
+    rng = np.random.default_rng(23)
+    n = 160
+    e = rng.integers(0, n, size=(420, 2))
+    e = e[e[:, 0] != e[:, 1]]
+    hub = np.stack([np.full(n - 2, 5), np.array([v for v in range(n - 1) if v != 5])], 1)   # n-1 isolated
+    loops = np.array([[3, 3], [4, 4], [5, 5], [9, 9], [20, 20]])
+    e = np.vstack([e[(e != n - 1).all(1)], hub, loops, [[3, 4], [3, 9], [4, 9]]])
+    r = np.concatenate([e[:, 0], e[:, 1]])
+    c = np.concatenate([e[:, 1], e[:, 0]])
+    A = ssp.csr_matrix((np.ones(len(r), dtype=np.int64), (r, c)), shape=(n, n))
+    A.sum_duplicates()
+    A.data[:] = 1
+    X = rng.random((n, 11)).astype(np.float32)
+    links = np.array([[3, 4], [4, 3], [3, 5], [5, 20], [20, 5], [7, n - 1], [n - 1, 30], [40, 41], [9, 3],
+                      [5, 4], [60, 61], [61, 60], [8, 5]]).T
+    K = 3
+    kw = {"sign_k": K, "k_node_set_strategy": "intersection"}
+    fn = oracle.get_PoS_Plus_prepped_ds if mode == "pos_plus" else oracle.get_PoS_prepped_ds
+    ref, ref_ptr, _ = oracle.collate_rows(fn(links, 1, A, X.astype(np.float64), 1, kw, dtype=np.float64), K)
+    (G0, p0), (G1, p1) = _plans(eng, monkeypatch, A, eng.links(links), mode, K, bm_hbm)
+    p0.close(), G0.close()
+    monkeypatch.setenv("S3GRL_FORCE_ONEHOP", "1")
+    monkeypatch.setenv("S3GRL_FORCE_HASH", "1")
+    if bm_hbm:
+        monkeypatch.setenv("S3GRL_FORCE_BM_HBM", "1")
+    pf = eng.plan(G1, eng.links(links), mode=mode, num_hops=1, sign_k=K)       # with folding
+    for p in (p1, pf):
+        rows = p.run(eng.features(X)).cpu().numpy()
+        assert np.array_equal(p.row_ptr().cpu().numpy(), ref_ptr)
+        assert rel_err(rows, ref) < TOL
+    assert pf.stats["folded_links"] == 3
+    p1.close(), pf.close(), G1.close()
+
+
+def test_onehop_plans_have_no_node_limit(eng):
+    """A graph beyond the LDS-bitmap limit of the multi-hop paths (327 680 nodes): one-hop PoS /
+    PoS Plus run (the setting the reference uses on its large graphs), multi-hop plans refuse."""
+    from s3grl_amd import workloads
+
+    n, e = workloads.chung_lu(400000, 1200000, seed=21)
+    A = workloads.csr_from_undirected(n, e)
+    rng = np.random.default_rng(22)
+    X = rng.random((n, 8)).astype(np.float32)
+    deg = np.bincount(e.ravel(), minlength=n)
+    hubs = np.argsort(-deg)[:4]
+    pos = e[rng.choice(len(e), 300, replace=False)]
+    neg = rng.integers(0, n, size=(300, 2))
+    neg = neg[neg[:, 0] != neg[:, 1]]
+    links = np.concatenate([pos, neg, [[hubs[0], hubs[1]], [hubs[2], int(pos[0, 0])]]]).T
+    G = eng.graph(A)
+    kw = {"sign_k": 3, "k_node_set_strategy": "intersection"}
+    for mode, fn in (("pos", oracle.get_PoS_prepped_ds), ("pos_plus", oracle.get_PoS_Plus_prepped_ds)):
+        res = eng.precompute(G, eng.features(X), eng.links(links), mode=mode, num_hops=1, sign_k=3)
+        sel = np.concatenate([np.arange(0, 600, 12), [links.shape[1] - 2, links.shape[1] - 1]])
+        ref, ref_ptr, _ = oracle.collate_rows(fn(links[:, sel], 1, A, X.astype(np.float64), 1, kw,
+                                                 dtype=np.float64), 3)
+        ptr = res.row_ptr.cpu().numpy()
+        take = np.concatenate([np.arange(ptr[l], ptr[l + 1]) for l in sel])
+        assert np.array_equal(np.diff(ptr)[sel], np.diff(ref_ptr))
+        assert rel_err(res.rows.cpu().numpy()[take], ref) < TOL
+    with pytest.raises(Exception, match="(?i)too large|bitmap"):
+        eng.plan(G, eng.links(links), mode="pos", num_hops=2, sign_k=3)
+    G.close()
