@@ -348,8 +348,10 @@ def main():
     # ---- N > 1: shard, compute, all-gather ---------------------------------------------------
     shard_info = {}
     if world > 1:
-        cost = parallel.khop_cost(w.A, link_index, w.num_hops) if w.mode != "sop" \
-            else parallel.link_cost(w.A, link_index)
+        # shard weights, once at set-up (like the uploads): exact subgraph sizes from the engine's
+        # sizing pass; SoP extracts no subgraph, its cost is one gather per link + the scalar ball
+        cost = parallel.measured_cost(eng, g, link_index, w.num_hops) if w.mode != "sop" \
+            else parallel.link_cost(w.A, link_index) + 64.0
         li_dev = torch.as_tensor(link_index).to(eng.device)
         gather = not args.no_allgather
         timers = {}
@@ -469,8 +471,9 @@ def main():
         if world > 1:
             comp = [r["structure_ms"] + r["propagate_ms"] + r["gather_ms"] + r["sop_ms"] for r in per_rank]
             line["multi_gpu"] = {
-                "sharding": "contiguous link ranges balanced by the number of walks of length <= num_hops "
-                            "from src and dst (parallel.khop_cost); graph + X replicated",
+                "sharding": "contiguous link ranges balanced by exact subgraph size (the engine's sizing "
+                            "pass over the whole list, once at set-up: parallel.measured_cost); graph + X "
+                            "replicated",
                 "collective": None if args.no_allgather else
                               ("%d padded all_gather_into_tensor per step (pieces of a range are gathered on "
                                "RCCL's stream while the next piece is computed) + compaction" % args.chunks

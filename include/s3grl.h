@@ -70,6 +70,10 @@ typedef enum s3grl_strategy {
                                     sign_k < num_hops, subgraph export for every link (turns
                                     the folding of reversed duplicates off) */
 #define S3GRL_FLAG_NO_FOLD 2u    /* do not serve (d,s) from the extraction of (s,d) */
+#define S3GRL_FLAG_COUNT_ONLY 4u /* sizing pass only: the plan holds the subgraph sizes (node_ptr of
+                                    s3grl_plan_export_subgraphs, total_nodes / max_nodes / total_rows
+                                    of the stats) and nothing else; it cannot be run.  Used to
+                                    balance the shards of a multi-GPU job by exact subgraph size */
 
 /* sign_kwargs / call arguments of the reference operators (tuned_SIGN.py:137-138,145,200,229) */
 typedef struct s3grl_cfg {

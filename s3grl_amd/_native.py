@@ -48,7 +48,7 @@ class Cfg(C.Structure):
 
 
 ABI_VERSION = 3
-FLAG_FULL_STATS, FLAG_NO_FOLD = 1, 2
+FLAG_FULL_STATS, FLAG_NO_FOLD, FLAG_COUNT_ONLY = 1, 2, 4
 
 
 class PlanStats(C.Structure):

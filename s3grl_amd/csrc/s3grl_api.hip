@@ -400,7 +400,8 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   }
   // reversed duplicates (both directions of a train edge) are folded into one extraction
   int32_t *partner = nullptr, *mirror_of = nullptr;
-  const bool fold = !(cfg->flags & (S3GRL_FLAG_FULL_STATS | S3GRL_FLAG_NO_FOLD)) && !getenv("S3GRL_NO_MIRROR");
+  const bool fold = !(cfg->flags & (S3GRL_FLAG_FULL_STATS | S3GRL_FLAG_NO_FOLD | S3GRL_FLAG_COUNT_ONLY)) &&
+                    !getenv("S3GRL_NO_MIRROR");
   // per-hop sampling (utils.py:66-70; the reference's rw branch ignores it).  Its BFS keeps a
   // fourth bitmap, so the plan stays on the bitmap flavour of the visited set.
   HopSampling smp{rw_len > 0 ? 1.0 : cfg->ratio_per_hop, rw_len > 0 ? 0 : cfg->max_nodes_per_hop, cfg->seed};
@@ -493,6 +494,18 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
     fprintf(stderr, "[s3grl] L=%lld max_n=%lld classes:", (long long)L, (long long)max_n);
     for (int c = 0; c < 21; ++c) fprintf(stderr, " %d", class_count_host[c]);
     fprintf(stderr, "\n");
+  }
+  if (cfg->flags & S3GRL_FLAG_COUNT_ONLY) {   // sizing pass: sizes and offsets only
+    plan->stats.total_nodes = hs[6];
+    plan->stats.folded_links = hs[7];
+    plan->stats.extracted_nodes = tot_n;
+    plan->stats.max_nodes = max_n;
+    plan->stats.total_rows = tot_rows;
+    plan->stats.num_row_pairs = 0;
+    plan->njobs = 0;
+    plan->stats.workspace_bytes = (int64_t)ctx->arena.bytes_held();
+    *out = plan.release();
+    return S3GRL_OK;
   }
   plan->stats.total_nodes = hs[6];          // algorithmic: a folded link counts like any other
   plan->stats.folded_links = hs[7];
@@ -620,6 +633,10 @@ s3grl_status s3grl_plan_export_subgraphs(const s3grl_plan* p, int64_t* node_ptr,
   S3GRL_HIP_TRY(hipMemcpyAsync(node_ptr, p->node_off, (size_t)(p->L + 1) * 8,
                                hipMemcpyDeviceToDevice, st));
   const size_t n = (size_t)p->stats.extracted_nodes;
+  if ((nodes || dists) && (p->cfg.flags & S3GRL_FLAG_COUNT_ONLY)) {
+    set_last_error("a count-only plan holds sizes only (pass NULL for nodes and dists)");
+    return S3GRL_ERR_INVALID_ARGUMENT;
+  }
   if (nodes && n) S3GRL_HIP_TRY(hipMemcpyAsync(nodes, p->c_ids, n * 4, hipMemcpyDeviceToDevice, st));
   if (dists && n) S3GRL_TRY(launch_dists(p->ctx, p->node_off, p->lvl, p->L, dists));
   return S3GRL_OK;
@@ -627,6 +644,10 @@ s3grl_status s3grl_plan_export_subgraphs(const s3grl_plan* p, int64_t* node_ptr,
 
 static s3grl_status run_with(s3grl_context* ctx, const s3grl_plan* p, const s3grl_features* f,
                              float* rows) {
+  if (p->cfg.flags & S3GRL_FLAG_COUNT_ONLY) {
+    set_last_error("a count-only plan cannot be run");
+    return S3GRL_ERR_INVALID_ARGUMENT;
+  }
   if (p->njobs == 0) return S3GRL_OK;
   if (f->N != p->graph->num_nodes) {
     set_last_error("features have " + std::to_string(f->N) + " rows, the graph " +

@@ -1470,7 +1470,7 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
     else
       S3GRL_TRY((launch_full_class<256, K, false>(ctx, a, L, c, count, next_stream(), nullptr, 0, count)));
   }
-  for (int c = kNumLists - 1; c >= kSparseBase; --c)
+  for (int c = kFullBase - 1; c >= kSparseBase; --c)
     if (class_count_host[c] > 0)
       S3GRL_TRY((launch_link_class<256, K>(ctx, a, L, c, class_count_host[c], next_stream())));
   for (int c = kNumClasses - 1; c >= 0; --c) {

@@ -283,9 +283,23 @@ class Engine:
         return li.to(device=self.device, dtype=torch.int64).contiguous()
 
     # ---- the batched native entry ----------------------------------------------------------
+    def subgraph_sizes(self, graph, links, *, num_hops=1, rw=None, ratio_per_hop=1.0,
+                       max_nodes_per_hop=None, seed=0):
+        """int64 [L] on the device: |S| of every link's enclosing subgraph — the sizing pass alone
+        (count kernel + scan, ~1/8 of a plan), e.g. to balance multi-GPU shards by exact size."""
+        p = self.plan(graph, links, mode="pos", num_hops=num_hops, sign_k=1, rw=rw, ratio_per_hop=ratio_per_hop,
+                      max_nodes_per_hop=max_nodes_per_hop, seed=seed, count_only=True)
+        try:
+            node_ptr = torch.empty(p.num_links + 1, dtype=torch.int64, device=self.device)
+            N.check(N.lib().s3grl_plan_export_subgraphs(p._h, _ptr(node_ptr), C.c_void_p(0), C.c_void_p(0)),
+                    "s3grl_plan_export_subgraphs")
+            return node_ptr.diff()
+        finally:
+            p.close()
+
     def plan(self, graph, links, *, mode="pos", num_hops=1, sign_k=3, strategy="intersection",
              directed=False, full_stats=False, fold_reversed=True, rw=None, ratio_per_hop=1.0,
-             max_nodes_per_hop=None, seed=0):
+             max_nodes_per_hop=None, seed=0, count_only=False):
         cfg = N.Cfg()
         cfg.mode = {"pos": N.MODE_POS, "pos_plus": N.MODE_POS_PLUS}[mode]
         cfg.num_hops = int(num_hops)
@@ -294,7 +308,8 @@ class Engine:
             raise NotImplementedError(f"check strat {strategy}")      # tuned_SIGN.py:235
         cfg.strategy = N.STRATEGY[strategy]
         cfg.directed = int(bool(directed))
-        cfg.flags = (N.FLAG_FULL_STATS if full_stats else 0) | (0 if fold_reversed else N.FLAG_NO_FOLD)
+        cfg.flags = (N.FLAG_FULL_STATS if full_stats else 0) | (0 if fold_reversed else N.FLAG_NO_FOLD) | \
+            (N.FLAG_COUNT_ONLY if count_only else 0)
         cfg.seed = int(seed) & 0xffffffff
         cfg.ratio_per_hop = 1.0
         if rw is not None:

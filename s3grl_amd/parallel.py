@@ -61,6 +61,14 @@ def khop_cost(A, link_index, num_hops):
     return tot[li[0]] + tot[li[1]]
 
 
+def measured_cost(engine, graph, link_index, num_hops, per_link=48.0):
+    """Exact subgraph sizes from the engine's sizing pass (count kernel only) + a fixed per-link
+    share: what SURVEY §8(e) calls "the plan pass's exact vol(S)".  One cheap pass over the whole
+    list at set-up time, identical on every rank."""
+    n = engine.subgraph_sizes(graph, engine.links(link_index), num_hops=num_hops)
+    return n.cpu().numpy().astype(np.float64) + per_link
+
+
 def chunk_bounds(lo, hi, chunks, cost=None):
     """Cut [lo, hi) into `chunks` contiguous cost-balanced pieces (empty pieces allowed)."""
     c = None if cost is None else np.asarray(cost)[lo:hi]
