@@ -41,35 +41,52 @@ __global__ void global_dinv_kernel(const int32_t* __restrict__ indptr, int64_t N
   dinv[v] = deg > 0 ? 1.0 / sqrt((double)deg) : 0.0;
 }
 
-// Y_out[v,:] = dinv[v] · Σ_{u ∈ N(v)} dinv[u] · Y_in[u,:]      one wave per row, f64
+// Y_out[v,:] = dinv[v] · Σ_{u ∈ N(v)} dinv[u] · Y_in[u,:]      f64, neighbours in stored order.
+// One wavefront per (row, 256-column tile): a lane owns columns {2l, 2l+1} and {128+2l, 129+2l} of
+// the tile (two 16-byte loads per neighbour), four neighbours in flight.  A PubMed row has 4.5
+// neighbours: one wave per whole row (six tiles in sequence) left the loads of a tile waiting for
+// the previous tile's sums — latency-bound at 0.4 TB/s; (row, tile) waves run at the fabric's rate.
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
 __global__ __launch_bounds__(256) void spmm_norm_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
     const double* __restrict__ dinv, const double* __restrict__ Yin, double* __restrict__ Yout,
-    int64_t N, int64_t ldy) {
+    int64_t N, int64_t ldy, int tiles) {
   const int lane = threadIdx.x & 63;
-  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (v >= N) return;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= N * tiles) return;
+  const int64_t v = w / tiles;
+  const int tile = (int)(w - v * tiles);
   const int e0 = indptr[v], e1 = indptr[v + 1];
-  const double dv = dinv[v];
-  for (int64_t c0 = 0; c0 < ldy; c0 += 256) {  // 4 columns per lane per tile
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int e = e0; e < e1; ++e) {
-      const int u = indices[e];
-      const double du = dinv[u];
-      const double* __restrict__ yr = Yin + (int64_t)u * ldy + c0;
+  const int64_t ca = (int64_t)tile * 256 + 2 * lane, cb = ca + 128;
+  const bool oka = ca < ldy, okb = cb < ldy;          // ldy is even: a pair is inside or outside
+  const int64_t la = oka ? ca : 0, lb = okb ? cb : 0;
+  double2_t acc_a = {0.0, 0.0}, acc_b = {0.0, 0.0};
+  for (int e = e0; e < e1; e += 4) {
+    int u[4];
+    double du[4];
+    double2_t ya[4], yb[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int64_t c = lane + 64 * k;
-        if (c0 + c < ldy) acc[k] += du * yr[c];
-      }
-    }
-    double* __restrict__ yo = Yout + v * ldy + c0;
+    for (int k = 0; k < 4; ++k) u[k] = indices[min(e + k, e1 - 1)];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int64_t c = lane + 64 * k;
-      if (c0 + c < ldy) yo[c] = dv * acc[k];
+      du[k] = e + k < e1 ? dinv[u[k]] : 0.0;
+      const double* __restrict__ yr = Yin + (int64_t)u[k] * ldy;
+      ya[k] = *reinterpret_cast<const double2_t*>(yr + la);
+      yb[k] = *reinterpret_cast<const double2_t*>(yr + lb);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (e + k < e1) {          // uniform over the wave: the same sums in the same order as a scalar loop
+        acc_a += du[k] * ya[k];
+        acc_b += du[k] * yb[k];
+      }
     }
   }
+  const double dv = dinv[v];
+  double* __restrict__ yo = Yout + v * ldy;
+  if (oka) *reinterpret_cast<double2_t*>(yo + ca) = dv * acc_a;
+  if (okb) *reinterpret_cast<double2_t*>(yo + cb) = dv * acc_b;
 }
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
@@ -84,7 +101,7 @@ template <int T, int G>
 __global__ __launch_bounds__(T) void sop_scalar_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int W,
     const double* __restrict__ gdinv, const int64_t* __restrict__ links,
-    const int32_t* __restrict__ class_list, const int64_t* __restrict__ node_off, int K, int HB,
+    const int32_t* __restrict__ class_list, const int64_t* __restrict__ node_off, int K, int HB, int RB,
     int hubs, double* __restrict__ scal /* [L][K][3] = sd, ss, dd */) {
   extern __shared__ uint32_t smem[];
   const int tid = threadIdx.x;
@@ -104,7 +121,11 @@ __global__ __launch_bounds__(T) void sop_scalar_kernel(
   const int src = (int)links[2 * (int64_t)l], dst = (int)links[2 * (int64_t)l + 1];
   const int g = tid & (G - 1);
   int nlev;
-  const int n = bfs_list<T, G>(indptr, indices, W, src, dst, HB, vis, nxt, list, n_alloc, lvl_end, sh, hub, nlev);
+  // ball of radius RB: HB = ⌈K/2⌉ when K is even; HB - 1 when K is odd — r_HB then only ever meets
+  // r_{HB-1} in a dot product (i = K: a = HB - 1, b = HB), whose support lies within HB - 1 hops,
+  // so r_HB is only evaluated there (its pulls still range over whole global rows: neighbours
+  // outside the ball carry r_{HB-1} = 0).  K = 3: the 1-hop ball instead of the 2-hop one.
+  const int n = bfs_list<T, G>(indptr, indices, W, src, dst, RB, vis, nxt, list, n_alloc, lvl_end, sh, hub, nlev);
   rank_prefix<T>(vis, wpre, W, sh);
   for (int w = tid; w < n * HB; w += T) r[w] = make_double2(0.0, 0.0);
   __syncthreads();
@@ -312,11 +333,12 @@ s3grl_status s3grl_sop_create(s3grl_context* ctx, const s3grl_graph* g, const fl
   const int64_t total = N * s->ldy;
   hipLaunchKernelGGL(to_f64_pad_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 8192)),
                      dim3(256), 0, ctx->stream, X, ldx, N, F, s->Y, s->ldy);
+  const int spmm_tiles = (int)((s->ldy + 255) / 256);
   if (ctx->profiling) S3GRL_HIP_TRY(hipEventRecord(ctx->ev[5], ctx->stream));
   for (int i = 1; i <= K; ++i)
-    hipLaunchKernelGGL(spmm_norm_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(spmm_norm_kernel, dim3((unsigned)((N * spmm_tiles + 3) / 4)), dim3(256), 0, ctx->stream,
                        g->indptr, g->indices, s->dinv, s->Y + (int64_t)(i - 1) * N * s->ldy,
-                       s->Y + (int64_t)i * N * s->ldy, N, s->ldy);
+                       s->Y + (int64_t)i * N * s->ldy, N, s->ldy, spmm_tiles);
   S3GRL_HIP_TRY(hipGetLastError());
   if (ctx->profiling) {
     S3GRL_HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
@@ -350,6 +372,7 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
   S3GRL_HIP_TRY(hipSetDevice(ctx->device));
   const s3grl_graph* g = s->graph;
   const int K = s->K, HB = (K + 1) / 2;
+  const int RB = (K & 1) ? HB - 1 : HB;   // radius of the ball the scalars are formed in (see the kernel)
   const int W = words_for(g->num_nodes);
   std::vector<void*> tmp;
   struct Rel {
@@ -383,8 +406,8 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
   int32_t* class_count = reinterpret_cast<int32_t*>(ds + 8);
   if (ctx->profiling) S3GRL_HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
   S3GRL_HIP_TRY(hipMemsetAsync(ds, 0, 32 * sizeof(int64_t), ctx->stream));
-  // the ⌈K/2⌉-hop ball of {s,d}: same BFS as PoS, no row selection
-  S3GRL_TRY(launch_count(ctx, g, links, L, HB, 0, 1, nullptr, 0, nullptr, nullptr, n_nodes, p_nodes, n_rows,
+  // the ball of {s,d}: same BFS as PoS, no row selection
+  S3GRL_TRY(launch_count(ctx, g, links, L, RB, 0, 1, nullptr, 0, nullptr, nullptr, n_nodes, p_nodes, n_rows,
                          n_jobs, lvl_max, reinterpret_cast<int32_t*>(ds), ds + 6));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_nodes, L, node_off, scan_ws));
   const int fixed = 4 * (3 * W + kMaxLevels + 32 + kHubWords + 6 * 16) + 64;
@@ -407,7 +430,7 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
   int32_t cc[4];
   std::memcpy(cc, hs + 8, sizeof(cc));
   if (cc[3] > 0 || b2 < 1024) {
-    set_last_error(std::to_string(cc[3]) + " link(s): the " + std::to_string(HB) +
+    set_last_error(std::to_string(cc[3]) + " link(s): the " + std::to_string(RB) +
                    "-hop ball does not fit the 160 KiB LDS-resident SoP scalar path");
     return S3GRL_ERR_GRAPH_TOO_LARGE;
   }
@@ -423,7 +446,7 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
     hipLaunchKernelGGL(kern, dim3((unsigned)cc[c]), dim3(TT), lds, ctx->stream, g->indptr,         \
                        g->indices, W, s->dinv, links, class_list + (int64_t)c * L, node_off, K,    \
-                       HB, g->max_degree > kHubArmDegree ? 1 : 0, scal);                                                                  \
+                       HB, RB, g->max_degree > kHubArmDegree ? 1 : 0, scal);                                                                  \
   } while (0)
     if (c == 0) {
       if (sparse) S3GRL_SOP_LAUNCH(256, 4); else S3GRL_SOP_LAUNCH(256, 8);
