@@ -223,7 +223,7 @@ def end_to_end_api(w, link_index, y):
         best = dt if best is None else min(best, dt)
         first = lists[0][0]
         _ = first.x.shape, first[f"x{w.sign_k}"].shape
-        del lists
+        del lists, first, lst
     ts.clear_cache()
     return {"value": total / best, "unit": "link pairs/s", "seconds": best, "links": total,
             "what": "OptimizedSignOperations.get_*_prepped_ds of s3grl_amd.tuned_SIGN over the 6 "

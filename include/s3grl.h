@@ -244,6 +244,14 @@ s3grl_status s3grl_context_trim(s3grl_context* ctx, int64_t* released);
 s3grl_status s3grl_plan_gather_traffic(s3grl_context* ctx, const s3grl_plan* p,
                                        const s3grl_features* f, int64_t* what);
 
+/* Measurement aid, not on the product path: reads a KNOWN number of bytes of `buf` (device, `bytes`
+ * long) in one of the engine's access shapes, so that rocprofv3's FETCH_SIZE can be calibrated on
+ * gfx950 for that shape (tools/pmc_calibrate.py).  pattern 0 / 1 / 2: one coalesced pass with 16 /
+ * 8 / 4 bytes per lane; 3: `rows` rows of `row_bytes` (multiple of 16) at pseudo-random places, one
+ * wavefront per row, 16 bytes per lane.  *requested_bytes (host) = the bytes the loads asked for. */
+s3grl_status s3grl_calibration_read(s3grl_context* ctx, const void* buf, int64_t bytes, int32_t pattern,
+                                    int64_t rows, int32_t row_bytes, int64_t* requested_bytes);
+
 #ifdef __cplusplus
 }
 #endif

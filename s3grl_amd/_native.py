@@ -35,7 +35,7 @@ SYMBOLS = [
     "s3grl_plan_row_nodes", "s3grl_plan_export_subgraphs", "s3grl_run",
     "s3grl_sop_create", "s3grl_sop_destroy", "s3grl_sop_run", "s3grl_sop_features",
     "s3grl_features_create", "s3grl_features_destroy", "s3grl_features_info", "s3grl_run_features",
-    "s3grl_centre_pool_forward", "s3grl_centre_pool_backward",
+    "s3grl_centre_pool_forward", "s3grl_centre_pool_backward", "s3grl_calibration_read",
 ]
 
 
@@ -117,6 +117,7 @@ def lib():
         "s3grl_run_features": [vp, vp, vp, vp],
         "s3grl_centre_pool_forward": [vp, vp, vp, i64, i64, i32, vp],
         "s3grl_centre_pool_backward": [vp, vp, vp, i64, i64, i32, vp, vp],
+        "s3grl_calibration_read": [vp, vp, i64, i32, i64, i32, C.POINTER(i64)],
     }
     for name, args in proto.items():
         fn = getattr(L, name)

@@ -71,9 +71,10 @@ __host__ __device__ __forceinline__ int full_hash_slots(int n) {
   while (C < 2 * n) C <<= 1;
   return C;
 }
-__host__ __device__ __forceinline__ int full_lds_need(int n, int ecap, bool with_bm) {
+// on_chip: the bit matrix and the CSR columns in LDS too (otherwise both sit in an HBM slice)
+__host__ __device__ __forceinline__ int full_lds_need(int n, int ecap, bool on_chip) {
   const int WB = (n + 31) >> 5;
-  return 8 * full_hash_slots(n) + 12 * n + 16 + 2 * ((ecap + 1) & ~1) + (with_bm ? 4 * n * WB : 0);
+  return 8 * full_hash_slots(n) + 12 * n + 16 + (on_chip ? 2 * ((ecap + 1) & ~1) + 4 * n * WB : 0);
 }
 
 constexpr int kCount1Waves = 4;
@@ -160,7 +161,8 @@ __global__ __launch_bounds__(64 * kCount1Waves) void count1_kernel(
 // ---- the fused per-link kernel of the full-reach one-hop case ------------------------------------
 // LDS (dynamic): [hkeys C | hvals C]  (aliased by the float2 state arrays cur[n], nxs[n] once the
 // probes are done: 8C >= 16n)  cn[cn_cap] cnpos[cn_cap] lvl_end[2] zbuf[4K] sh[32]
-// list[n] dinv[n] off[n+1] cols[ecap] (uint16 local ids)  bm[n][WB] (BMG: in a per-workgroup HBM slice)
+// list[n] dinv[n] off[n+1] cols[ecap] (uint16 local ids) bm[n][WB]  (BMG: cols and bm in a per-workgroup
+// HBM slice)
 template <int T, int K, bool BMG>
 __global__ __launch_bounds__(T) void link_full_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
@@ -200,11 +202,19 @@ __global__ __launch_bounds__(T) void link_full_kernel(
     int32_t* list = sh + 32;
     float* dinv = reinterpret_cast<float*>(list + n);
     int32_t* off = reinterpret_cast<int32_t*>(dinv + n);     // [n+1]
-    uint16_t* cols = reinterpret_cast<uint16_t*>(off + n + 1 + ((n + 1) & 1));
-    // the bit matrix: in LDS, or (BMG) in this workgroup's HBM slice — set with atomics that
-    // execute at the L2, so it is read back with agent-scope loads that bypass the CU's L1
-    uint32_t* bm_l = reinterpret_cast<uint32_t*>(cols + ecap);
+    // the CSR columns and the bit matrix: in LDS, or (BMG) in this workgroup's HBM slice.  The
+    // matrix is set with atomics that execute at the L2, so it is read back with agent-scope loads
+    // that bypass the CU's L1; the columns are plain stores and loads of this one CU
+    uint16_t* cols_l = reinterpret_cast<uint16_t*>(off + n + 1 + ((n + 1) & 1));
+    uint32_t* bm_l = reinterpret_cast<uint32_t*>(cols_l + ecap);
     uint32_t* bm_g = bm_scratch + (int64_t)blockIdx.x * bm_stride_words;
+    uint16_t* cols_g = reinterpret_cast<uint16_t*>(bm_g + (((int64_t)n * WB + 1) & ~(int64_t)1));
+    auto cols_st = [&](int k, int v) {
+      if constexpr (BMG) cols_g[k] = (uint16_t)v; else cols_l[k] = (uint16_t)v;
+    };
+    auto cols_ld = [&](int k) -> int {
+      if constexpr (BMG) return cols_g[k]; else return cols_l[k];
+    };
     auto bm_or = [&](int64_t idx, uint32_t m) {
       if constexpr (BMG) atomicOr(&bm_g[idx], m); else atomicOr(&bm_l[idx], m);
     };
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(T) void link_full_kernel(
           while (w) {
             const int b = __ffs(w) - 1;
             w &= w - 1;
-            if (k < ecap) cols[k] = (uint16_t)(j * 32 + b);
+            if (k < ecap) cols_st(k, j * 32 + b);
             ++k;
           }
         }
@@ -375,7 +385,7 @@ __global__ __launch_bounds__(T) void link_full_kernel(
           if (t < n) {
             const int k1 = off[t + 1];
             for (int k = off[t] + g; k < k1; k += G) {
-              const float2 sv = s_in[cols[k]];
+              const float2 sv = s_in[cols_ld(k)];
               ax += sv.x;
               ay += sv.y;
             }

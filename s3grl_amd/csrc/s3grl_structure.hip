@@ -479,6 +479,8 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
     } else if (need_b <= fbound.b[kNumClasses - 1]) {
       sparse = true;
       c = kFullBig;
+      atomicMax(&class_count[31], ec);   // sizes the HBM slices of that class
+      atomicMax(&class_count[30], need_b);   // and its LDS
     }
   }
   if (!sparse && sparse_mode && n > 0 && lvl_max[l] <= kSparseLevelMax) {
@@ -1354,6 +1356,7 @@ struct LinkArgs {
   uint32_t* bm_scratch;
   int64_t bm_stride_words;
   int bm_grid;
+  int big_need;   // LDS need of the biggest link of the class whose matrix / columns sit in HBM
 };
 
 // One-hop full-reach classes (link_full_kernel).  Small classes run one wavefront per link (no
@@ -1364,7 +1367,7 @@ s3grl_status launch_full_class(s3grl_context* ctx, const LinkArgs& a, int64_t L,
                                hipStream_t stream, uint32_t* bm_scratch, int64_t bm_stride_words, int grid) {
   const ClassBounds fb = class_bounds_full(a.cn_cap, K);
   const size_t lds = (size_t)4 * full_fixed_words(a.cn_cap, K) +
-                     (size_t)fb.b[cls == kFullBig ? kNumClasses - 1 : cls - kFullBase];
+                     (size_t)(cls == kFullBig ? a.big_need : fb.b[cls - kFullBase]);
   auto kern = link_full_kernel<T, K, BMG>;
   S3GRL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1522,12 +1525,15 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
              job_off, coef_off, mirror_of, c_ids, c_coef, jobs, job_z, job_lim, row_nodes, lvl, tot_edges,
              tot_support, tot_vol, scratch, scratch_stride,
              getenv("S3GRL_DEBUG_STAMPS") ? reinterpret_cast<unsigned long long*>(ctx->d_scalars + 16) : nullptr,
-             smp, stash, slot, e_cap, nullptr, 0, 0};
+             smp, stash, slot, e_cap, nullptr, 0, 0, 0};
   // the class whose bit matrix does not fit LDS: one slice per resident workgroup of a persistent grid
   if (class_count_host[kFullBig] > 0) {
-    const int64_t WB = (max_nodes + 31) / 32;
-    a.bm_stride_words = (max_nodes * WB + 63) / 64 * 64;
-    a.bm_grid = (int)std::min<int64_t>(class_count_host[kFullBig], 256 * 2);
+    const int64_t WB = (max_nodes + 31) / 32;   // bit matrix + CSR columns (uint16) of the biggest link
+    a.bm_stride_words = (max_nodes * WB + 2 + (class_count_host[31] + 2) / 2 + 63) / 64 * 64;
+    a.big_need = (class_count_host[30] + 255) / 256 * 256;
+    // persistent grid: as many workgroups as the LDS lets reside (at most 4 per CU)
+    const int per_cu = std::max(1, std::min(4, 163840 / std::max(a.big_need + 1024, 1)));
+    a.bm_grid = (int)std::min<int64_t>(class_count_host[kFullBig], 256 * per_cu);
     void* q = nullptr;
     S3GRL_TRY(ctx->arena.alloc((size_t)a.bm_stride_words * 4 * a.bm_grid, &q));
     scratch_owner.ptrs.push_back(q);
