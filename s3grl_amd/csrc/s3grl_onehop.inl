@@ -74,7 +74,7 @@ __host__ __device__ __forceinline__ int full_hash_slots(int n) {
 // on_chip: the bit matrix and the CSR columns in LDS too (otherwise both sit in an HBM slice)
 __host__ __device__ __forceinline__ int full_lds_need(int n, int ecap, bool on_chip) {
   const int WB = (n + 31) >> 5;
-  return 8 * full_hash_slots(n) + 12 * n + 16 + (on_chip ? 2 * ((ecap + 1) & ~1) + 4 * n * WB : 0);
+  return 8 * full_hash_slots(n) + 12 * n + 16 + (on_chip ? 2 * ((ecap + 1) & ~1) + 4 * n * WB : 16 * WB);
 }
 
 constexpr int kCount1Waves = 4;
@@ -161,8 +161,9 @@ __global__ __launch_bounds__(64 * kCount1Waves) void count1_kernel(
 // ---- the fused per-link kernel of the full-reach one-hop case ------------------------------------
 // LDS (dynamic): [hkeys C | hvals C]  (aliased by the float2 state arrays cur[n], nxs[n] once the
 // probes are done: 8C >= 16n)  cn[cn_cap] cnpos[cn_cap] lvl_end[2] zbuf[4K] sh[32]
-// list[n] dinv[n] off[n+1] cols[ecap] (uint16 local ids) bm[n][WB]  (BMG: cols and bm in a per-workgroup
-// HBM slice)
+// list[n] dinv[n] off[n+1] cols[ecap] (uint16 local ids) bm[n][WB]
+// (BMG, the class of the biggest subgraphs: no matrix; cols and the list of found edges in a
+// per-workgroup HBM slice, four per-wave sort bitmaps of WB words behind off[])
 template <int T, int K, bool BMG>
 __global__ __launch_bounds__(T) void link_full_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
@@ -202,25 +203,17 @@ __global__ __launch_bounds__(T) void link_full_kernel(
     int32_t* list = sh + 32;
     float* dinv = reinterpret_cast<float*>(list + n);
     int32_t* off = reinterpret_cast<int32_t*>(dinv + n);     // [n+1]
-    // the CSR columns and the bit matrix: in LDS, or (BMG) in this workgroup's HBM slice.  The
-    // matrix is set with atomics that execute at the L2, so it is read back with agent-scope loads
-    // that bypass the CU's L1; the columns are plain stores and loads of this one CU
+    // On-chip classes: CSR columns and an n x n bit matrix in LDS.  Big class (BMG): the columns
+    // and a list of the found edges sit in this workgroup's HBM slice and there is no matrix — the
+    // CSR is built from the edge list (degree count, scan, scatter) and every row is then sorted,
+    // so that the sums run in ascending local id like in the on-chip classes.
     uint16_t* cols_l = reinterpret_cast<uint16_t*>(off + n + 1 + ((n + 1) & 1));
     uint32_t* bm_l = reinterpret_cast<uint32_t*>(cols_l + ecap);
-    uint32_t* bm_g = bm_scratch + (int64_t)blockIdx.x * bm_stride_words;
-    uint16_t* cols_g = reinterpret_cast<uint16_t*>(bm_g + (((int64_t)n * WB + 1) & ~(int64_t)1));
-    auto cols_st = [&](int k, int v) {
-      if constexpr (BMG) cols_g[k] = (uint16_t)v; else cols_l[k] = (uint16_t)v;
-    };
+    uint32_t* elist = bm_scratch + (int64_t)blockIdx.x * bm_stride_words;              // [ecap / 2]
+    uint16_t* cols_g = reinterpret_cast<uint16_t*>(elist + ((ecap / 2 + 1) & ~1));         // [ecap]
+    uint32_t* sortbm = reinterpret_cast<uint32_t*>(off + n + 1);                         // [T/64][WB] (BMG)
     auto cols_ld = [&](int k) -> int {
       if constexpr (BMG) return cols_g[k]; else return cols_l[k];
-    };
-    auto bm_or = [&](int64_t idx, uint32_t m) {
-      if constexpr (BMG) atomicOr(&bm_g[idx], m); else atomicOr(&bm_l[idx], m);
-    };
-    auto bm_ld = [&](int64_t idx) -> uint32_t {
-      if constexpr (BMG) return __hip_atomic_load(&bm_g[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else return bm_l[idx];
     };
 
     const int src = (int)links[2 * (int64_t)l], dst = (int)links[2 * (int64_t)l + 1];
@@ -281,8 +274,11 @@ __global__ __launch_bounds__(T) void link_full_kernel(
 
     // ---- hash of S (probe structure), node list out, bit matrix zeroed --------------------------
     for (uint32_t t = tid; t <= hmask; t += T) hkeys[t] = -1;
-    for (int i = tid; i < n * WB; i += T) {
-      if constexpr (BMG) bm_g[i] = 0; else bm_l[i] = 0;
+    if constexpr (BMG) {
+      for (int t = tid; t <= n; t += T) off[t] = 0;            // degree counters
+      if (tid == 0) sh[30] = 0;                                // edges found
+    } else {
+      for (int i = tid; i < n * WB; i += T) bm_l[i] = 0;
     }
     __syncthreads();
     int vol_local = 0;
@@ -319,21 +315,94 @@ __global__ __launch_bounds__(T) void link_full_kernel(
           const int i = a.row;
           const bool target = (v == src && u == dst) || (v == dst && u == src);
           if (valid && slot >= 0 && !target) {
-            bm_or((int64_t)i * WB + (j >> 5), 1u << (j & 31));
-            if (i != j) bm_or((int64_t)j * WB + (i >> 5), 1u << (i & 31));
+            if constexpr (BMG) {
+              const int k = atomicAdd(&sh[30], 1);
+              if (2 * k < ecap) elist[k] = ((uint32_t)i << 16) | (uint32_t)j;
+              atomicAdd(&off[i], 1);
+              if (i != j) atomicAdd(&off[j], 1);
+            } else {
+              atomicOr(&bm_l[i * WB + (j >> 5)], 1u << (j & 31));
+              if (i != j) atomicOr(&bm_l[j * WB + (i >> 5)], 1u << (i & 31));
+            }
           }
         },
         [](RowAcc&, int, int) {});
+    if constexpr (BMG) __threadfence();   // the edge list is read back by other waves (through L2)
     __syncthreads();
 
     // ---- degrees, D^-1/2 (inf -> 0), CSR of local ids (ascending) --------------------------------
-    {
+    if constexpr (BMG) {
+      int32_t* cursor = hvals;              // the hash values are dead: positions were copied out
+      const int per = (n + T - 1) / T;
+      const int t0 = min(tid * per, n), t1 = min(t0 + per, n);
+      int mine = 0;
+      for (int t = t0; t < t1; ++t) mine += off[t];
+      int total;
+      int run = block_excl_scan<T>(mine, sh, total);
+      for (int t = t0; t < t1; ++t) {
+        const int dg = off[t];
+        dinv[t] = dg > 0 ? 1.0f / sqrtf((float)dg) : 0.0f;
+        off[t] = run;
+        cursor[t] = run;
+        run += dg;
+      }
+      if (tid == 0) off[n] = total;
+      __syncthreads();
+      const int found = min(sh[30], ecap / 2);
+      for (int k = tid; k < found; k += T) {
+        const uint32_t w = elist[k];
+        const int i = (int)(w >> 16), j = (int)(w & 0xffffu);
+        cols_g[atomicAdd(&cursor[i], 1)] = (uint16_t)j;
+        if (i != j) cols_g[atomicAdd(&cursor[j], 1)] = (uint16_t)i;
+      }
+      __threadfence();
+      __syncthreads();
+      // every row ascending: one wavefront per row.  Short rows by rank (each lane counts the
+      // smaller entries), long ones through a per-wave bitmap of the n local ids.
+      const int lane = tid & 63, wv = tid >> 6;
+      uint32_t* wbm = sortbm + wv * WB;
+      for (int r = wv; r < n; r += T / 64) {
+        const int b = off[r], len = off[r + 1] - b;
+        if (len <= 1) continue;
+        if (len <= 64) {
+          const int x = lane < len ? (int)cols_g[b + lane] : 0x7fffffff;
+          int rank = 0;
+          for (int k = 0; k < len; ++k) rank += __shfl(x, k) < x ? 1 : 0;
+          if (lane < len) cols_g[b + rank] = (uint16_t)x;
+        } else {
+          for (int w = lane; w < WB; w += 64) wbm[w] = 0;
+          for (int k = lane; k < len; k += 64) {
+            const int c = cols_g[b + k];
+            atomicOr(&wbm[c >> 5], 1u << (c & 31));
+          }
+          int base = b;
+          for (int w0 = 0; w0 < WB; w0 += 64) {
+            uint32_t word = w0 + lane < WB ? wbm[w0 + lane] : 0u;
+            const int cnt = __popc(word);
+            int inc = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+              const int t = __shfl_up(inc, o);
+              if (lane >= o) inc += t;
+            }
+            int k = base + inc - cnt;
+            while (word) {
+              const int bit = __ffs(word) - 1;
+              word &= word - 1;
+              cols_g[k++] = (uint16_t)((w0 + lane) * 32 + bit);
+            }
+            base += __shfl(inc, 63);
+          }
+        }
+      }
+      __threadfence();
+    } else {
       const int per = (n + T - 1) / T;
       const int t0 = min(tid * per, n), t1 = min(t0 + per, n);
       int mine = 0;
       for (int t = t0; t < t1; ++t) {
         int dg = 0;
-        for (int j = 0; j < WB; ++j) dg += __popc(bm_ld((int64_t)t * WB + j));
+        for (int j = 0; j < WB; ++j) dg += __popc(bm_l[t * WB + j]);
         mine += dg;
       }
       int total;
@@ -342,11 +411,11 @@ __global__ __launch_bounds__(T) void link_full_kernel(
         off[t] = run;
         int k = run;
         for (int j = 0; j < WB; ++j) {
-          uint32_t w = bm_ld((int64_t)t * WB + j);
+          uint32_t w = bm_l[t * WB + j];
           while (w) {
             const int b = __ffs(w) - 1;
             w &= w - 1;
-            if (k < ecap) cols_st(k, j * 32 + b);
+            if (k < ecap) cols_l[k] = (uint16_t)(j * 32 + b);
             ++k;
           }
         }

@@ -1528,8 +1528,10 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
              smp, stash, slot, e_cap, nullptr, 0, 0, 0};
   // the class whose bit matrix does not fit LDS: one slice per resident workgroup of a persistent grid
   if (class_count_host[kFullBig] > 0) {
-    const int64_t WB = (max_nodes + 31) / 32;   // bit matrix + CSR columns (uint16) of the biggest link
-    a.bm_stride_words = (max_nodes * WB + 2 + (class_count_host[31] + 2) / 2 + 63) / 64 * 64;
+    // slice = list of found edges (uint32, at most ecap / 2) + CSR columns (uint16 x ecap) of the
+    // link with the largest bound
+    a.bm_stride_words = ((int64_t)class_count_host[31] / 2 + 2 + (class_count_host[31] + 2) / 2 + 63) / 64 * 64;
+    (void)max_nodes;
     a.big_need = (class_count_host[30] + 255) / 256 * 256;
     // persistent grid: as many workgroups as the LDS lets reside (at most 4 per CU)
     const int per_cu = std::max(1, std::min(4, 163840 / std::max(a.big_need + 1024, 1)));
