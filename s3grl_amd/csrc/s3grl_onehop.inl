@@ -74,7 +74,7 @@ __host__ __device__ __forceinline__ int full_hash_slots(int n) {
 // on_chip: the bit matrix and the CSR columns in LDS too (otherwise both sit in an HBM slice)
 __host__ __device__ __forceinline__ int full_lds_need(int n, int ecap, bool on_chip) {
   const int WB = (n + 31) >> 5;
-  return 8 * full_hash_slots(n) + 12 * n + 16 + (on_chip ? 2 * ((ecap + 1) & ~1) + 4 * n * WB : 16 * WB);
+  return 8 * full_hash_slots(n) + 12 * n + 16 + (on_chip ? 2 * ((ecap + 1) & ~1) + 4 * n * WB : 64 * WB);
 }
 
 constexpr int kCount1Waves = 4;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(T) void link_full_kernel(
     float* __restrict__ job_z, int32_t* __restrict__ job_lim, int64_t* __restrict__ row_nodes,
     int32_t* __restrict__ lvl_out, unsigned long long* __restrict__ tot_edges,
     unsigned long long* __restrict__ tot_support, unsigned long long* __restrict__ tot_vol,
-    uint32_t* __restrict__ bm_scratch, int64_t bm_stride_words) {
+    uint32_t* __restrict__ bm_scratch, int64_t bm_stride_words, int lds_bytes) {
   extern __shared__ uint32_t smem[];
   const int tid = threadIdx.x;
   constexpr int G = 4;
@@ -212,8 +212,20 @@ __global__ __launch_bounds__(T) void link_full_kernel(
     uint32_t* elist = bm_scratch + (int64_t)blockIdx.x * bm_stride_words;              // [ecap / 2]
     uint16_t* cols_g = reinterpret_cast<uint16_t*>(elist + ((ecap / 2 + 1) & ~1));         // [ecap]
     uint32_t* sortbm = reinterpret_cast<uint32_t*>(off + n + 1);                         // [T/64][WB] (BMG)
+    // BMG: the columns stay on chip after all when the EXACT entry count (known once the degrees
+    // are) fits what the class's LDS leaves — the bound the class was chosen by is loose
+    uint16_t* cols_b = reinterpret_cast<uint16_t*>(sortbm + (T / 64) * WB);
+    const int cols_b_cap = (lds_bytes - (int)(reinterpret_cast<char*>(cols_b) - reinterpret_cast<char*>(smem))) / 2;
+    bool big_on_chip = false;
     auto cols_ld = [&](int k) -> int {
-      if constexpr (BMG) return cols_g[k]; else return cols_l[k];
+      if constexpr (BMG) return big_on_chip ? cols_b[k] : cols_g[k]; else return cols_l[k];
+    };
+    auto cols_st = [&](int k, int v) {
+      if constexpr (BMG) {
+        if (big_on_chip) cols_b[k] = (uint16_t)v; else cols_g[k] = (uint16_t)v;
+      } else {
+        cols_l[k] = (uint16_t)v;
+      }
     };
 
     const int src = (int)links[2 * (int64_t)l], dst = (int)links[2 * (int64_t)l + 1];
@@ -347,15 +359,16 @@ __global__ __launch_bounds__(T) void link_full_kernel(
         run += dg;
       }
       if (tid == 0) off[n] = total;
+      big_on_chip = total <= cols_b_cap;
       __syncthreads();
       const int found = min(sh[30], ecap / 2);
       for (int k = tid; k < found; k += T) {
         const uint32_t w = elist[k];
         const int i = (int)(w >> 16), j = (int)(w & 0xffffu);
-        cols_g[atomicAdd(&cursor[i], 1)] = (uint16_t)j;
-        if (i != j) cols_g[atomicAdd(&cursor[j], 1)] = (uint16_t)i;
+        cols_st(atomicAdd(&cursor[i], 1), j);
+        if (i != j) cols_st(atomicAdd(&cursor[j], 1), i);
       }
-      __threadfence();
+      if (!big_on_chip) __threadfence();
       __syncthreads();
       // every row ascending: one wavefront per row.  Short rows by rank (each lane counts the
       // smaller entries), long ones through a per-wave bitmap of the n local ids.
@@ -365,14 +378,14 @@ __global__ __launch_bounds__(T) void link_full_kernel(
         const int b = off[r], len = off[r + 1] - b;
         if (len <= 1) continue;
         if (len <= 64) {
-          const int x = lane < len ? (int)cols_g[b + lane] : 0x7fffffff;
+          const int x = lane < len ? cols_ld(b + lane) : 0x7fffffff;
           int rank = 0;
           for (int k = 0; k < len; ++k) rank += __shfl(x, k) < x ? 1 : 0;
-          if (lane < len) cols_g[b + rank] = (uint16_t)x;
+          if (lane < len) cols_st(b + rank, x);
         } else {
           for (int w = lane; w < WB; w += 64) wbm[w] = 0;
           for (int k = lane; k < len; k += 64) {
-            const int c = cols_g[b + k];
+            const int c = cols_ld(b + k);
             atomicOr(&wbm[c >> 5], 1u << (c & 31));
           }
           int base = b;
@@ -389,13 +402,13 @@ __global__ __launch_bounds__(T) void link_full_kernel(
             while (word) {
               const int bit = __ffs(word) - 1;
               word &= word - 1;
-              cols_g[k++] = (uint16_t)((w0 + lane) * 32 + bit);
+              cols_st(k++, (w0 + lane) * 32 + bit);
             }
             base += __shfl(inc, 63);
           }
         }
       }
-      __threadfence();
+      if (!big_on_chip) __threadfence();
     } else {
       const int per = (n + T - 1) / T;
       const int t0 = min(tid * per, n), t1 = min(t0 + per, n);

@@ -1377,7 +1377,8 @@ s3grl_status launch_full_class(s3grl_context* ctx, const LinkArgs& a, int64_t L,
                      a.c_ids, a.c_coef, a.jobs, a.job_z, a.job_lim, a.row_nodes, a.lvl,
                      reinterpret_cast<unsigned long long*>(a.tot_edges),
                      reinterpret_cast<unsigned long long*>(a.tot_support),
-                     reinterpret_cast<unsigned long long*>(a.tot_vol), bm_scratch, bm_stride_words);
+                     reinterpret_cast<unsigned long long*>(a.tot_vol), bm_scratch, bm_stride_words,
+                     getenv("S3GRL_BIG_COLS_HBM") ? 0 : (int)lds);   // test hook: big class, columns in HBM
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -1463,8 +1464,8 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
   if (class_count_host[kNumClasses] > 0)
     S3GRL_TRY((launch_link_class<1024, K>(ctx, a, L, kNumClasses, class_count_host[kNumClasses], next_stream())));
   if (class_count_host[kFullBig] > 0)
-    S3GRL_TRY((launch_full_class<256, K, true>(ctx, a, L, kFullBig, class_count_host[kFullBig], next_stream(),
-                                                 a.bm_scratch, a.bm_stride_words, a.bm_grid)));
+    S3GRL_TRY((launch_full_class<1024, K, true>(ctx, a, L, kFullBig, class_count_host[kFullBig], next_stream(),
+                                                  a.bm_scratch, a.bm_stride_words, a.bm_grid)));
   for (int c = kFullBig - 1; c >= kFullBase; --c) {
     const int count = class_count_host[c];
     if (count == 0) continue;
@@ -1532,10 +1533,11 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
     // link with the largest bound
     a.bm_stride_words = ((int64_t)class_count_host[31] / 2 + 2 + (class_count_host[31] + 2) / 2 + 63) / 64 * 64;
     (void)max_nodes;
-    a.big_need = (class_count_host[30] + 255) / 256 * 256;
-    // persistent grid: as many workgroups as the LDS lets reside (at most 4 per CU)
-    const int per_cu = std::max(1, std::min(4, 163840 / std::max(a.big_need + 1024, 1)));
-    a.bm_grid = (int)std::min<int64_t>(class_count_host[kFullBig], 256 * per_cu);
+    // all of a CU's LDS for one 1024-thread workgroup: whatever the hash and the per-node arrays
+    // leave holds the CSR columns whenever the exact entry count allows (see link_full_kernel)
+    a.big_need = 163840 - 4 * full_fixed_words(cn_cap, K);
+    (void)class_count_host[30];
+    a.bm_grid = (int)std::min<int64_t>(class_count_host[kFullBig], 256);
     void* q = nullptr;
     S3GRL_TRY(ctx->arena.alloc((size_t)a.bm_stride_words * 4 * a.bm_grid, &q));
     scratch_owner.ptrs.push_back(q);

@@ -25,23 +25,25 @@ def eng():
 
 def _plans(eng, monkeypatch, A, links, mode, K, bm_hbm=False):
     """(bitmap-flavour plan, one-hop-path plan) of the same one-hop request."""
-    for k in ("S3GRL_FORCE_ONEHOP", "S3GRL_FORCE_HASH", "S3GRL_FORCE_BM_HBM"):
+    for k in ("S3GRL_FORCE_ONEHOP", "S3GRL_FORCE_HASH", "S3GRL_FORCE_BM_HBM", "S3GRL_BIG_COLS_HBM"):
         monkeypatch.delenv(k, raising=False)
     G0 = eng.graph(A)
     p0 = eng.plan(G0, links, mode=mode, num_hops=1, sign_k=K, full_stats=True)
     monkeypatch.setenv("S3GRL_FORCE_ONEHOP", "1")
     monkeypatch.setenv("S3GRL_FORCE_HASH", "1")
-    if bm_hbm:
+    if bm_hbm:                                 # the class of the biggest subgraphs (edge list + sort)
         monkeypatch.setenv("S3GRL_FORCE_BM_HBM", "1")
+    if bm_hbm == "hbm":                        # ... with its CSR columns in the HBM slice
+        monkeypatch.setenv("S3GRL_BIG_COLS_HBM", "1")
     G1 = eng.graph(A)                      # the oriented rows are built with the graph
     p1 = eng.plan(G1, links, mode=mode, num_hops=1, sign_k=K, full_stats=True)
-    for k in ("S3GRL_FORCE_ONEHOP", "S3GRL_FORCE_HASH", "S3GRL_FORCE_BM_HBM"):
+    for k in ("S3GRL_FORCE_ONEHOP", "S3GRL_FORCE_HASH", "S3GRL_FORCE_BM_HBM", "S3GRL_BIG_COLS_HBM"):
         monkeypatch.delenv(k, raising=False)
     return (G0, p0), (G1, p1)
 
 
 @pytest.mark.parametrize("name", EXTRACT_NAMES)
-@pytest.mark.parametrize("K,bm_hbm", [(1, False), (2, False), (3, True), (5, False)])
+@pytest.mark.parametrize("K,bm_hbm", [(1, False), (2, "hbm"), (3, "lds"), (5, False)])
 def test_onehop_path_equals_bitmap_flavour(eng, monkeypatch, name, K, bm_hbm):
     import torch
 
@@ -91,7 +93,7 @@ def test_onehop_path_node_sets_vs_reference_fixture(eng, monkeypatch, name):
 
 
 @pytest.mark.parametrize("mode", ["pos", "pos_plus"])
-@pytest.mark.parametrize("bm_hbm", [False, True])
+@pytest.mark.parametrize("bm_hbm", [False, "lds", "hbm"])
 def test_onehop_path_vs_oracle_with_self_loops_and_hubs(eng, monkeypatch, mode, bm_hbm):
     """A graph with self-loops at link endpoints and at common neighbours, a hub adjacent to
     everything, isolated endpoints, and links in both directions (folded) — against the oracle."""
@@ -122,6 +124,8 @@ def test_onehop_path_vs_oracle_with_self_loops_and_hubs(eng, monkeypatch, mode, 
     monkeypatch.setenv("S3GRL_FORCE_HASH", "1")
     if bm_hbm:
         monkeypatch.setenv("S3GRL_FORCE_BM_HBM", "1")
+    if bm_hbm == "hbm":
+        monkeypatch.setenv("S3GRL_BIG_COLS_HBM", "1")
     pf = eng.plan(G1, eng.links(links), mode=mode, num_hops=1, sign_k=K)       # with folding
     for p in (p1, pf):
         rows = p.run(eng.features(X)).cpu().numpy()
