@@ -78,6 +78,8 @@ __host__ __device__ __forceinline__ int full_lds_need(int n, int ecap, bool on_c
 }
 
 constexpr int kCount1Waves = 4;
+constexpr int kLongRow = 96;    // CSR rows longer than this are summed by a whole wavefront
+constexpr int kLongCap = 128;   // ... at most this many per link (the others stay with their 4 lanes)
 
 __global__ __launch_bounds__(64 * kCount1Waves) void count1_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
@@ -200,7 +202,8 @@ __global__ __launch_bounds__(T) void link_full_kernel(
     int* lvl_end = cnpos + cn_cap;                           // [2]
     float* zbuf = reinterpret_cast<float*>(lvl_end + 2);     // [2][K][2]
     int* sh = reinterpret_cast<int*>(zbuf + 4 * K);          // [32]
-    int32_t* list = sh + 32;
+    uint16_t* longrows = reinterpret_cast<uint16_t*>(sh + 32);   // [kLongCap]
+    int32_t* list = sh + 32 + kLongCap / 2;
     float* dinv = reinterpret_cast<float*>(list + n);
     int32_t* off = reinterpret_cast<int32_t*>(dinv + n);     // [n+1]
     // On-chip classes: CSR columns and an n x n bit matrix in LDS.  Big class (BMG): the columns
@@ -255,6 +258,7 @@ __global__ __launch_bounds__(T) void link_full_kernel(
       list[1] = max(src, dst);
       lvl_end[0] = 2;
       lvl_end[1] = n;
+      sh[29] = 0;   // long rows registered
     }
     __syncthreads();
     for (int side = 0; side < 2; ++side) {
@@ -440,6 +444,21 @@ __global__ __launch_bounds__(T) void link_full_kernel(
     }
     __syncthreads();   // hash dead from here: cur / nxs take its space
     const int edges_total = off[n];
+    // Long rows (src and dst are adjacent to about half of a one-hop subgraph each, a hub inside
+    // it to more): four lanes would stride such a row for hundreds of trips while the rest of the
+    // workgroup waits at the barrier of the pass.  They are registered here (sign bit of their
+    // D^-1/2 as the per-row flag) and summed by a whole wavefront each, after the short rows.
+    for (int t = tid; t < n; t += T) {
+      if (off[t + 1] - off[t] > kLongRow) {
+        const int q = atomicAdd(&sh[29], 1);
+        if (q < kLongCap) {
+          longrows[q] = (uint16_t)t;
+          dinv[t] = -dinv[t];
+        }
+      }
+    }
+    __syncthreads();
+    const int nlong = min(sh[29], kLongCap);
 
     // ---- per row pair: K pulls over the CSR ------------------------------------------------------
     const int npairs = (R + 1) / 2;
@@ -451,7 +470,7 @@ __global__ __launch_bounds__(T) void link_full_kernel(
       const int la = pr == 0 ? pos_src : cnpos[2 * pr - 2];
       const int lb = pr == 0 ? pos_dst : (node_b >= 0 ? cnpos[2 * pr - 1] : -1);
       for (int w = tid; w < n; w += T) {
-        cur[w] = make_float2(w == la ? dinv[w] : 0.f, w == lb ? dinv[w] : 0.f);
+        cur[w] = make_float2(w == la ? fabsf(dinv[w]) : 0.f, w == lb ? fabsf(dinv[w]) : 0.f);
       }
       if (tid < 4 * K) zbuf[tid] = 0.f;
       __syncthreads();
@@ -461,10 +480,20 @@ __global__ __launch_bounds__(T) void link_full_kernel(
 #pragma unroll 1
       for (int i = 0; i < K; ++i) {
         const int g = tid & (G - 1);
+        auto commit = [&](int t, float ax, float ay) {
+          const float dw = fabsf(dinv[t]);
+          const float rx = dw * ax, ry = dw * ay;
+          s_out[t] = make_float2(dw * rx, dw * ry);
+          coef[(int64_t)i * n + t] = make_float2(rx, ry);
+          // label column of operator i+1: r[src] + r[dst]  (tuned_SIGN.py:177-185)
+          if (t == pos_src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
+          if (t == pos_dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
+        };
         for (int base = 0; base < n; base += T / G) {
           const int t = base + tid / G;
           float ax = 0.f, ay = 0.f;
-          if (t < n) {
+          const bool mine = t < n && !(dinv[min(t, n - 1)] < 0.f);   // short row of this lane group
+          if (mine) {
             const int k1 = off[t + 1];
             for (int k = off[t] + g; k < k1; k += G) {
               const float2 sv = s_in[cols_ld(k)];
@@ -477,15 +506,23 @@ __global__ __launch_bounds__(T) void link_full_kernel(
             ax += __shfl_xor(ax, o);
             ay += __shfl_xor(ay, o);
           }
-          if (t < n && g == 0) {
-            const float dw = dinv[t];
-            const float rx = dw * ax, ry = dw * ay;
-            s_out[t] = make_float2(dw * rx, dw * ry);
-            coef[(int64_t)i * n + t] = make_float2(rx, ry);
-            // label column of operator i+1: r[src] + r[dst]  (tuned_SIGN.py:177-185)
-            if (t == pos_src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
-            if (t == pos_dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
+          if (mine && g == 0) commit(t, ax, ay);
+        }
+        for (int q = tid >> 6; q < nlong; q += T / 64) {   // one wavefront per long row
+          const int t = longrows[q];
+          const int k1 = off[t + 1];
+          float ax = 0.f, ay = 0.f;
+          for (int k = off[t] + (tid & 63); k < k1; k += 64) {
+            const float2 sv = s_in[cols_ld(k)];
+            ax += sv.x;
+            ay += sv.y;
           }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            ax += __shfl_xor(ax, o);
+            ay += __shfl_xor(ay, o);
+          }
+          if ((tid & 63) == 0) commit(t, ax, ay);
         }
         __syncthreads();
         float2* tmp2 = s_in;

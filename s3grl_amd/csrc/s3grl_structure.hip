@@ -1232,8 +1232,8 @@ static ClassBounds class_bounds_sparse(int cn_cap, int K) {
   return cb;
 }
 
-// link_full_kernel: fixed LDS = cn + cnpos + lvl_end[2] + zbuf + scan scratch
-static inline int full_fixed_words(int cn_cap, int K) { return 2 * cn_cap + 2 + 4 * K + 32; }
+// link_full_kernel: fixed LDS = cn + cnpos + lvl_end[2] + zbuf + scan scratch + long-row list
+static inline int full_fixed_words(int cn_cap, int K) { return 2 * cn_cap + 2 + 4 * K + 32 + kLongCap / 2; }
 static ClassBounds class_bounds_full(int cn_cap, int K) {
   static const int nominal[kNumClasses] = {3072, 6144, 12288, 24576, 65536, 160000};
   const int avail = 163840 - 4 * full_fixed_words(cn_cap, K);
