@@ -297,6 +297,7 @@ s3grl_status s3grl_graph_destroy(s3grl_graph* g) {
   g->ctx->arena.release(g->indices);
   g->ctx->arena.release(g->fwd_indptr);
   g->ctx->arena.release(g->fwd_indices);
+  g->ctx->arena.release(g->fwd_deg);
   delete g;
   return S3GRL_OK;
 }

@@ -114,6 +114,7 @@ struct s3grl_graph {
   // in the row of its endpoint of lower (degree, id); self-loops in their own row
   int32_t* fwd_indptr = nullptr;   // [N+1]
   int32_t* fwd_indices = nullptr;  // [nnz / 2 (+ self-loops)]
+  uint16_t* fwd_deg = nullptr;     // [N] length of the oriented rows, for the sizing pass
 };
 
 struct s3grl_plan {

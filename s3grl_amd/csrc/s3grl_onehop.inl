@@ -41,11 +41,14 @@ __global__ void fwd_count_kernel(const int32_t* __restrict__ indptr, const int32
 
 __global__ void fwd_fill_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                 int64_t N, const int64_t* __restrict__ off64, int32_t* __restrict__ fwd_indptr,
-                                int32_t* __restrict__ fwd_indices) {
+                                int32_t* __restrict__ fwd_indices, uint16_t* __restrict__ fwd_deg) {
   const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (u > N) return;
   fwd_indptr[u] = (int32_t)off64[u];
   if (u == N) return;
+  // 16-bit copy of the oriented degree for the sizing pass (an oriented row has at most sqrt(2m)
+  // entries; saturated beyond 65535, which only loosens a bound)
+  fwd_deg[u] = (uint16_t)min((long long)(off64[u + 1] - off64[u]), 65535ll);
   const int b = indptr[u], e = indptr[u + 1], du = e - b;
   int o = (int)off64[u];
   for (int k = b; k < e; ++k) {
@@ -83,7 +86,7 @@ constexpr int kLongCap = 128;   // ... at most this many per link (the others st
 
 __global__ __launch_bounds__(64 * kCount1Waves) void count1_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
-    const int32_t* __restrict__ fwd_indptr, int N, const int64_t* __restrict__ links, int64_t L, int plus,
+    const uint16_t* __restrict__ fwd_deg, int N, const int64_t* __restrict__ links, int64_t L, int plus,
     int K, const int32_t* __restrict__ partner, const int32_t* __restrict__ mirror_of,
     int32_t* __restrict__ n_nodes, int32_t* __restrict__ p_nodes, int32_t* __restrict__ n_rows,
     int32_t* __restrict__ n_jobs, int32_t* __restrict__ lvl_max, int32_t* __restrict__ e_cap,
@@ -106,41 +109,43 @@ __global__ __launch_bounds__(64 * kCount1Waves) void count1_kernel(
     return;
   }
   const int s = (int)s64, d = (int)d64;
-  const int32_t* __restrict__ rs = indices + indptr[s];
-  const int32_t* __restrict__ rd = indices + indptr[d];
   const int cs = indptr[s + 1] - indptr[s], cd = indptr[d + 1] - indptr[d];
-  int members = 0, common = 0, loops = 0;
-  long long fsum = (fwd_indptr[s + 1] - fwd_indptr[s]) + (fwd_indptr[d + 1] - fwd_indptr[d]);
-  for (int c0 = 0; c0 < cs; c0 += 64) {
+  // the SHORTER row is searched in the longer one (a leaf against a hub: one chunk of searches
+  // instead of forty); the longer row is only swept for its oriented degrees
+  const bool s_short = cs <= cd;
+  const int32_t* __restrict__ ra = indices + indptr[s_short ? s : d];   // shorter
+  const int32_t* __restrict__ rb = indices + indptr[s_short ? d : s];   // longer
+  const int ca = s_short ? cs : cd, cb = s_short ? cd : cs;
+  const int a_own = s_short ? s : d, b_own = s_short ? d : s;
+  // src / dst themselves inside the rows: excluded from the members; a node in its own row = self-loop
+  const int excl_a = (sorted_contains(ra, ca, s) ? 1 : 0) + (sorted_contains(ra, ca, d) ? 1 : 0);
+  const int excl_b = (sorted_contains(rb, cb, s) ? 1 : 0) + (sorted_contains(rb, cb, d) ? 1 : 0);
+  const int loops = (sorted_contains(ra, ca, a_own) ? 1 : 0) + (sorted_contains(rb, cb, b_own) ? 1 : 0);
+  int members = lane == 0 ? ca - excl_a + cb - excl_b : 0, common = 0;
+  long long fsum = lane == 0 ? (long long)fwd_deg[s] + fwd_deg[d] : 0ll;
+  for (int c0 = 0; c0 < ca; c0 += 64) {
     const int c = c0 + lane;
-    if (c < cs) {
-      const int x = rs[c];
-      if (x == s) loops += 1;                       // self-loop at src
+    if (c < ca) {
+      const int x = ra[c];
       if (x != s && x != d) {
-        const int lb = row_lower_bound(rd, cd, x);
-        const bool dup = lb < cd && rd[lb] == x;
-        members += 1;
+        const int lb = row_lower_bound(rb, cb, x);
+        const bool dup = lb < cb && rb[lb] == x;
         common += dup ? 1 : 0;
-        if (!dup) fsum += fwd_indptr[x + 1] - fwd_indptr[x];   // common ones are counted from row d
+        if (!dup) fsum += fwd_deg[x];            // common ones are counted from the longer row
       }
     }
   }
-  for (int c0 = 0; c0 < cd; c0 += 64) {
+  for (int c0 = 0; c0 < cb; c0 += 64) {
     const int c = c0 + lane;
-    if (c < cd) {
-      const int y = rd[c];
-      if (y == d) loops += 1;                       // self-loop at dst
-      if (y != s && y != d) {
-        members += 1;
-        fsum += fwd_indptr[y + 1] - fwd_indptr[y];
-      }
+    if (c < cb) {
+      const int y = rb[c];
+      if (y != s && y != d) fsum += fwd_deg[y];
     }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     members += __shfl_xor(members, o);
     common += __shfl_xor(common, o);
-    loops += __shfl_xor(loops, o);
     fsum += __shfl_xor(fsum, o);
   }
   if (lane == 0) {
@@ -242,17 +247,11 @@ __global__ __launch_bounds__(T) void link_full_kernel(
     // (lower bound in the other row, common?, member?) per element in `tmp` (the hash's space:
     // 4(cs+cd) <= 8n <= 4C... the two tables together hold 2C >= 4n words); phase 2 turns the
     // per-row prefix counts of "common" into positions.
-    uint32_t* tmp = smem;   // [cs + cd]
-    const bool s_has_s = sorted_contains(rs, cs, src), s_has_d = sorted_contains(rs, cs, dst);
-    const bool d_has_s = sorted_contains(rd, cd, src), d_has_d = sorted_contains(rd, cd, dst);
-    for (int e = tid; e < cs + cd; e += T) {
-      const bool from_s = e < cs;
-      const int x = from_s ? rs[e] : rd[e - cs];
-      const bool member = x != src && x != dst;
-      const int lb = from_s ? row_lower_bound(rd, cd, x) : row_lower_bound(rs, cs, x);
-      const bool dup = member && (from_s ? (lb < cd && rd[lb] == x) : (lb < cs && rs[lb] == x));
-      tmp[e] = ((uint32_t)lb << 2) | (dup ? 2u : 0u) | (member ? 1u : 0u);
-    }
+    // both rows are staged in LDS first (the hash's space holds 2C >= 4n >= 2(cs + cd) words):
+    // the searches then cost LDS latency instead of a dozen dependent trips to L2 each
+    int32_t* rows_l = reinterpret_cast<int32_t*>(smem);   // [cs + cd]: row src, then row dst
+    uint32_t* tmp = smem + (cs + cd);                     // [cs + cd]
+    for (int e = tid; e < cs + cd; e += T) rows_l[e] = e < cs ? rs[e] : rd[e - cs];
     if (tid == 0) {
       list[0] = min(src, dst);
       list[1] = max(src, dst);
@@ -261,9 +260,22 @@ __global__ __launch_bounds__(T) void link_full_kernel(
       sh[29] = 0;   // long rows registered
     }
     __syncthreads();
+    const int32_t* rs_l = rows_l;
+    const int32_t* rd_l = rows_l + cs;
+    const bool s_has_s = sorted_contains(rs_l, cs, src), s_has_d = sorted_contains(rs_l, cs, dst);
+    const bool d_has_s = sorted_contains(rd_l, cd, src), d_has_d = sorted_contains(rd_l, cd, dst);
+    for (int e = tid; e < cs + cd; e += T) {
+      const bool from_s = e < cs;
+      const int x = rows_l[e];
+      const bool member = x != src && x != dst;
+      const int lb = from_s ? row_lower_bound(rd_l, cd, x) : row_lower_bound(rs_l, cs, x);
+      const bool dup = member && (from_s ? (lb < cd && rd_l[lb] == x) : (lb < cs && rs_l[lb] == x));
+      tmp[e] = ((uint32_t)lb << 2) | (dup ? 2u : 0u) | (member ? 1u : 0u);
+    }
+    __syncthreads();
     for (int side = 0; side < 2; ++side) {
       const int base = side == 0 ? 0 : cs, len = side == 0 ? cs : cd;
-      const int32_t* __restrict__ row = side == 0 ? rs : rd;
+      const int32_t* row = rows_l + base;
       const int per = (len + T - 1) / T;
       const int e0 = min(tid * per, len), e1 = min(e0 + per, len);
       int dups = 0;

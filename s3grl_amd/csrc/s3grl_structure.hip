@@ -1282,8 +1282,10 @@ s3grl_status build_forward_rows(s3grl_context* ctx, s3grl_graph* g) {
   g->fwd_indptr = static_cast<int32_t*>(q);
   S3GRL_TRY(ctx->arena.alloc((size_t)std::max<int64_t>(fnnz, 1) * 4, &q));
   g->fwd_indices = static_cast<int32_t*>(q);
+  S3GRL_TRY(ctx->arena.alloc((size_t)N * 2, &q));
+  g->fwd_deg = static_cast<uint16_t*>(q);
   hipLaunchKernelGGL(fwd_fill_kernel, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
-                     g->indptr, g->indices, N, off64, g->fwd_indptr, g->fwd_indices);
+                     g->indptr, g->indices, N, off64, g->fwd_indptr, g->fwd_indices, g->fwd_deg);
   S3GRL_HIP_TRY(hipGetLastError());
   S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));   // tmp is released on return
   return S3GRL_OK;
@@ -1295,7 +1297,7 @@ s3grl_status launch_count1(s3grl_context* ctx, const s3grl_graph* g, const int64
                            int32_t* lvl_max, int32_t* e_cap, int32_t* err_flag, int64_t* tot_nodes_alg) {
   if (L == 0) return S3GRL_OK;
   hipLaunchKernelGGL(count1_kernel, dim3((unsigned)((L + kCount1Waves - 1) / kCount1Waves)),
-                     dim3(64 * kCount1Waves), 0, ctx->stream, g->indptr, g->indices, g->fwd_indptr,
+                     dim3(64 * kCount1Waves), 0, ctx->stream, g->indptr, g->indices, g->fwd_deg,
                      (int)g->num_nodes, links, L, plus, K, partner, mirror_of, n_nodes, p_nodes, n_rows,
                      n_jobs, lvl_max, e_cap, err_flag, reinterpret_cast<unsigned long long*>(tot_nodes_alg));
   S3GRL_HIP_TRY(hipGetLastError());
