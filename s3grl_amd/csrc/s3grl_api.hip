@@ -183,6 +183,8 @@ s3grl_status s3grl_context_create(int32_t device, void* stream, s3grl_context** 
   for (auto& e : ctx->ev) S3GRL_HIP_TRY(hipEventCreate(&e));
   S3GRL_HIP_TRY(hipMalloc(&ctx->d_scalars, 64 * sizeof(int64_t)));
   S3GRL_HIP_TRY(hipHostMalloc(&ctx->h_scalars, 64 * sizeof(int64_t)));
+  S3GRL_HIP_TRY(hipMalloc(&ctx->d_stats, kStatRows * kStatShards * kStatStride * sizeof(int64_t)));
+  S3GRL_HIP_TRY(hipHostMalloc(&ctx->h_stats, kStatRows * kStatShards * kStatStride * sizeof(int64_t)));
   *out = ctx;
   return S3GRL_OK;
 }
@@ -202,6 +204,8 @@ s3grl_status s3grl_context_destroy(s3grl_context* ctx) {
     if (e) (void)hipEventDestroy(e);
   if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
   if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
+  if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+  if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
   delete ctx;
   return S3GRL_OK;
 }
@@ -391,6 +395,14 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   int64_t* hs = ctx->h_scalars;
   class_count = reinterpret_cast<int32_t*>(ds + 32);
   S3GRL_HIP_TRY(hipMemsetAsync(ds, 0, 64 * sizeof(int64_t), ctx->stream));
+  constexpr size_t kStatRow = (size_t)kStatShards * kStatStride;   // int64 per total
+  int64_t* st = ctx->d_stats;   // rows: 0 Σ edges, 1 Σ support, 2 Σ vol, 3 Σ n counting folded links twice
+  S3GRL_HIP_TRY(hipMemsetAsync(st, 0, kStatRows * kStatRow * sizeof(int64_t), ctx->stream));
+  auto stat_total = [&](int row) {
+    int64_t t = 0;
+    for (int k = 0; k < kStatShards; ++k) t += ctx->h_stats[row * kStatRow + (size_t)k * kStatStride];
+    return t;
+  };
   // ScaLed: per-node random walks replace the BFS
   const int rw_m = cfg->rw_m, rw_M = cfg->rw_M;
   int32_t* rw_raw = nullptr;
@@ -435,7 +447,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   if (onehop) {
     S3GRL_TRY(arena_alloc(ctx, (size_t)L, &e_cap, tr));
     S3GRL_TRY(launch_count1(ctx, g, plan->links, L, plus ? 1 : 0, K, partner, mirror_of, plan->n_nodes, p_nodes,
-                            n_rows, n_jobs, lvl_max, e_cap, reinterpret_cast<int32_t*>(ds), ds + 6));
+                            n_rows, n_jobs, lvl_max, e_cap, reinterpret_cast<int32_t*>(ds), st + 3 * kStatRow));
   } else {
     if (g->num_nodes > kMaxNodesLds) {
       set_last_error("num_nodes " + std::to_string(g->num_nodes) + " exceeds the LDS bitmap limit " +
@@ -445,7 +457,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
     S3GRL_TRY(launch_count(ctx, g, plan->links, L, cfg->num_hops, plus ? 1 : 0, K, rw_raw, rw_len,
                            partner, mirror_of,
                            plan->n_nodes, p_nodes, n_rows, n_jobs, lvl_max,
-                           reinterpret_cast<int32_t*>(ds), ds + 6, smp, stash, slot, plan->lvl));
+                           reinterpret_cast<int32_t*>(ds), st + 3 * kStatRow, smp, stash, slot, plan->lvl));
   }
   if (fold) S3GRL_TRY(launch_mirror_rows(ctx, partner, L, n_rows));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, plan->n_nodes, L, plan->node_off, scan_ws));
@@ -460,6 +472,8 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
                               !sampling, e_cap));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs, ds, 8 * 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs + 32, ds + 32, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_stats + 3 * kStatRow, st + 3 * kStatRow, kStatRow * sizeof(int64_t),
+                               hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs + 16, plan->node_off + L, 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs + 17, plan->row_ptr + L, 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs + 18, plan->job_off + L, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -497,7 +511,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
     fprintf(stderr, "\n");
   }
   if (cfg->flags & S3GRL_FLAG_COUNT_ONLY) {   // sizing pass: sizes and offsets only
-    plan->stats.total_nodes = hs[6];
+    plan->stats.total_nodes = stat_total(3);
     plan->stats.folded_links = hs[7];
     plan->stats.extracted_nodes = tot_n;
     plan->stats.max_nodes = max_n;
@@ -508,7 +522,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
     *out = plan.release();
     return S3GRL_OK;
   }
-  plan->stats.total_nodes = hs[6];          // algorithmic: a folded link counts like any other
+  plan->stats.total_nodes = stat_total(3);  // algorithmic: a folded link counts like any other
   plan->stats.folded_links = hs[7];
   plan->stats.extracted_nodes = tot_n;
   plan->stats.max_nodes = max_n;
@@ -551,14 +565,15 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
                          plus ? 1 : 0, cn_cap, (cfg->flags & S3GRL_FLAG_FULL_STATS) ? 1 : 0, K, rw_raw, rw_len, p_nodes,
                          plan->node_off,
                          plan->row_ptr, plan->job_off, coef_off, mirror_of, plan->c_ids,
-                         plan->c_coef, plan->jobs, plan->job_z, plan->job_lim, plan->row_nodes, plan->lvl, ds + 2,
-                         ds + 3, ds + 4, smp, stash, slot, e_cap, max_n));
+                         plan->c_coef, plan->jobs, plan->job_z, plan->job_lim, plan->row_nodes, plan->lvl, st,
+                         st + kStatRow, st + 2 * kStatRow, smp, stash, slot, e_cap, max_n));
   S3GRL_TRY(record(ctx, 2));
-  S3GRL_HIP_TRY(hipMemcpyAsync(hs + 2, ds + 2, 3 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_stats, st, 3 * kStatRow * sizeof(int64_t), hipMemcpyDeviceToHost,
+                               ctx->stream));
   S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
-  plan->stats.total_sub_edges = hs[2];
-  plan->stats.total_support = hs[3];
-  plan->stats.total_volume = hs[4];
+  plan->stats.total_sub_edges = stat_total(0);
+  plan->stats.total_support = stat_total(1);
+  plan->stats.total_volume = stat_total(2);
   if (getenv("S3GRL_DEBUG_STAMPS")) {   // diagnostic build aid: cycles per link_kernel phase
     S3GRL_HIP_TRY(hipMemcpy(hs + 16, ds + 16, 8 * 8, hipMemcpyDeviceToHost));
     fprintf(stderr, "[s3grl] link_kernel phase cycles (sum over workgroups): bfs %lld  P/rank %lld  "

@@ -10,6 +10,13 @@
 namespace s3grl {
 namespace {
 
+// Plan statistics are summed with one atomic per link: on ONE address a million of them serialise at
+// the L2 (that alone was half of the sizing pass), so every total is kept in kStatShards counters
+// on lines of their own, picked by the workgroup index, and added up on the host.
+__device__ __forceinline__ unsigned long long* stat_slot(unsigned long long* base) {
+  return base + (blockIdx.x & (kStatShards - 1)) * kStatStride;
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 

@@ -34,6 +34,9 @@ void set_last_error(const std::string& msg);
 constexpr int kBlock = 256;            // threads per workgroup in the structure kernels
 constexpr int kMaxNodesLds = 327680;   // 4 bitmaps of N bits must fit 160 KiB of LDS
 constexpr int kMaxSignK = 8;
+constexpr int kStatShards = 64;        // see stat_slot() in s3grl_device.hpp
+constexpr int kStatStride = 16;        // int64 per shard: one 128-byte line
+constexpr int kStatRows = 4;           // Σ edges, Σ support, Σ vol, Σ n (algorithmic)
 constexpr int kMaxLevels = 32;         // BFS levels tracked per link (num_hops <= 30)
 // link_kernel keeps a whole subgraph on-chip; links are binned by LDS need into classes
 constexpr int kNumClasses = 6;
@@ -101,6 +104,8 @@ struct s3grl_context {
   hipEvent_t side_ev[kSide + 1] = {nullptr, nullptr, nullptr, nullptr};
   int64_t* d_scalars = nullptr;  // small device scratch for totals (64 x int64)
   int64_t* h_scalars = nullptr;  // pinned host mirror
+  int64_t* d_stats = nullptr;    // [kStatRows][kStatShards * kStatStride] sharded totals of a plan
+  int64_t* h_stats = nullptr;    // pinned host mirror
 };
 
 struct s3grl_graph {

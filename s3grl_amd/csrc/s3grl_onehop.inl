@@ -117,19 +117,18 @@ __global__ __launch_bounds__(64 * kCount1Waves) void count1_kernel(
   const int32_t* __restrict__ rb = indices + indptr[s_short ? d : s];   // longer
   const int ca = s_short ? cs : cd, cb = s_short ? cd : cs;
   const int a_own = s_short ? s : d, b_own = s_short ? d : s;
-  // src / dst themselves inside the rows: excluded from the members; a node in its own row = self-loop
-  const int excl_a = (sorted_contains(ra, ca, s) ? 1 : 0) + (sorted_contains(ra, ca, d) ? 1 : 0);
-  const int excl_b = (sorted_contains(rb, cb, s) ? 1 : 0) + (sorted_contains(rb, cb, d) ? 1 : 0);
-  const int loops = (sorted_contains(ra, ca, a_own) ? 1 : 0) + (sorted_contains(rb, cb, b_own) ? 1 : 0);
-  int members = lane == 0 ? ca - excl_a + cb - excl_b : 0, common = 0;
+  // src / dst themselves inside a row are not members; a node in its own row is a self-loop
+  int members = 0, common = 0, loops = 0;
   long long fsum = lane == 0 ? (long long)fwd_deg[s] + fwd_deg[d] : 0ll;
   for (int c0 = 0; c0 < ca; c0 += 64) {
     const int c = c0 + lane;
     if (c < ca) {
       const int x = ra[c];
+      loops += x == a_own ? 1 : 0;
       if (x != s && x != d) {
         const int lb = row_lower_bound(rb, cb, x);
         const bool dup = lb < cb && rb[lb] == x;
+        members += 1;
         common += dup ? 1 : 0;
         if (!dup) fsum += fwd_deg[x];            // common ones are counted from the longer row
       }
@@ -139,13 +138,18 @@ __global__ __launch_bounds__(64 * kCount1Waves) void count1_kernel(
     const int c = c0 + lane;
     if (c < cb) {
       const int y = rb[c];
-      if (y != s && y != d) fsum += fwd_deg[y];
+      loops += y == b_own ? 1 : 0;
+      if (y != s && y != d) {
+        members += 1;
+        fsum += fwd_deg[y];
+      }
     }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     members += __shfl_xor(members, o);
     common += __shfl_xor(common, o);
+    loops += __shfl_xor(loops, o);
     fsum += __shfl_xor(fsum, o);
   }
   if (lane == 0) {
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(64 * kCount1Waves) void count1_kernel(
     lvl_max[l] = max(2, n - 2);
     e_cap[l] = (int)min(2ll * fsum, (long long)0x3fffffff);
     const unsigned long long mult = (mirror_of && mirror_of[l] >= 0) ? 2ull : 1ull;
-    atomicAdd(tot_nodes_alg, mult * (unsigned long long)n);
+    atomicAdd(stat_slot(tot_nodes_alg), mult * (unsigned long long)n);
   }
 }
 
@@ -563,14 +567,14 @@ __global__ __launch_bounds__(T) void link_full_kernel(
         j.mirror_swap = pr == 0 ? 1 : 0;
         j.pad = 0;
         jobs[jid] = j;
-        atomicAdd(tot_support, (unsigned long long)n * (mirror >= 0 ? 2ull : 1ull));
+        atomicAdd(stat_slot(tot_support), (unsigned long long)n * (mirror >= 0 ? 2ull : 1ull));
       }
       __syncthreads();
     }
     vol_local = block_sum<T>(vol_local, sh);
     if (tid == 0) {
-      atomicAdd(tot_edges, (unsigned long long)edges_total * (mirror >= 0 ? 2ull : 1ull));
-      atomicAdd(tot_vol, (unsigned long long)vol_local * (mirror >= 0 ? 2ull : 1ull));
+      atomicAdd(stat_slot(tot_edges), (unsigned long long)edges_total * (mirror >= 0 ? 2ull : 1ull));
+      atomicAdd(stat_slot(tot_vol), (unsigned long long)vol_local * (mirror >= 0 ? 2ull : 1ull));
     }
     __syncthreads();   // LDS is reused by the next item of a persistent workgroup
   }

@@ -408,7 +408,7 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
   S3GRL_HIP_TRY(hipMemsetAsync(ds, 0, 32 * sizeof(int64_t), ctx->stream));
   // the ball of {s,d}: same BFS as PoS, no row selection
   S3GRL_TRY(launch_count(ctx, g, links, L, RB, 0, 1, nullptr, 0, nullptr, nullptr, n_nodes, p_nodes, n_rows,
-                         n_jobs, lvl_max, reinterpret_cast<int32_t*>(ds), ds + 6));
+                         n_jobs, lvl_max, reinterpret_cast<int32_t*>(ds), ctx->d_stats));
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_nodes, L, node_off, scan_ws));
   const int fixed = 4 * (3 * W + kMaxLevels + 32 + kHubWords + 6 * 16) + 64;
   const int per_node = 4 + 16 * HB;

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
     lvl_max[l] = biggest;
     // algorithmic totals count a folded link as if it had been extracted on its own
     const unsigned long long mult = (mirror_of && mirror_of[l] >= 0) ? 2ull : 1ull;
-    atomicAdd(tot_nodes_alg, mult * (unsigned long long)n);
+    atomicAdd(stat_slot(tot_nodes_alg), mult * (unsigned long long)n);
   }
 }
 
@@ -988,7 +988,7 @@ __global__ __launch_bounds__(T) void link_kernel(
       j.mirror_swap = pr == 0 ? 1 : 0;
       j.pad = 0;
       jobs[jid] = j;
-      atomicAdd(tot_support, (unsigned long long)support * (mirror >= 0 ? 2ull : 1ull));
+      atomicAdd(stat_slot(tot_support), (unsigned long long)support * (mirror >= 0 ? 2ull : 1ull));
     }
     __syncthreads();
   }
@@ -998,8 +998,8 @@ __global__ __launch_bounds__(T) void link_kernel(
   edges_local = block_sum<T>(edges_exact >= 0 ? edges_exact : edges_local, sh);
   vol_local = block_sum<T>(vol_local, sh);
   if (tid == 0) {
-    atomicAdd(tot_edges, (unsigned long long)edges_local * (mirror >= 0 ? 2ull : 1ull));
-    atomicAdd(tot_vol, (unsigned long long)vol_local * (mirror >= 0 ? 2ull : 1ull));
+    atomicAdd(stat_slot(tot_edges), (unsigned long long)edges_local * (mirror >= 0 ? 2ull : 1ull));
+    atomicAdd(stat_slot(tot_vol), (unsigned long long)vol_local * (mirror >= 0 ? 2ull : 1ull));
   }
 }
 
