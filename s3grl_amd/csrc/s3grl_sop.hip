@@ -208,43 +208,69 @@ __global__ __launch_bounds__(T) void sop_scalar_kernel(
   }
 }
 
-// rows[2l + e, i, :] for e ∈ {src, dst}: one wave per link, f64 arithmetic, f32 out
+// rows[2l + e, i, :] for e ∈ {src, dst}: one wave per link, f64 arithmetic, f32 out.
+// Column-outer: a lane loads X[s,c], X[d,c] ONCE and then the 2K entries Y_i[s,c], Y_i[d,c] — 2K + 2
+// independent loads in flight per trip, every row of the f64 table read exactly once per link.
+// (Operator-outer, the first version, re-read the two X rows for each operator: 14 row reads per
+// link instead of 8 at K = 3, all of them beyond L2 — 29 GB of fabric traffic against 16 GB.)
+template <int KT>
 __global__ __launch_bounds__(256) void sop_rows_kernel(
     const int64_t* __restrict__ links, int64_t L, const double* __restrict__ Y, int64_t N,
     int64_t ldy, int F, int K, const double* __restrict__ scal, float* __restrict__ rows) {
   const int lane = threadIdx.x & 63;
   const int64_t l = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (l >= L) return;
+  const int KK = KT > 0 ? KT : K;
   const int64_t s = links[2 * l], d = links[2 * l + 1];
   const int Fp = F + 1;
-  float* __restrict__ out_s = rows + (2 * l) * (int64_t)(K + 1) * Fp;
-  float* __restrict__ out_d = out_s + (int64_t)(K + 1) * Fp;
+  float* __restrict__ out_s = rows + (2 * l) * (int64_t)(KK + 1) * Fp;
+  float* __restrict__ out_d = out_s + (int64_t)(KK + 1) * Fp;
   const double* __restrict__ x_s = Y + s * ldy;
   const double* __restrict__ x_d = Y + d * ldy;
+  const int64_t plane = N * ldy;
+  double sd[kMaxSignK];
+#pragma unroll
+  for (int i = 0; i < (KT > 0 ? KT : kMaxSignK); ++i) sd[i] = i < KK ? scal[(l * KK + i) * 3 + 0] : 0.0;
   for (int c = lane; c < F; c += 64) {
-    out_s[1 + c] = (float)x_s[c];   // operator 0: x = [[1|X[s]],[1|X[d]]]  (tuned_SIGN.py:119-125)
-    out_d[1 + c] = (float)x_d[c];
-  }
-  if (lane == 0) {
-    out_s[0] = 1.f;
-    out_d[0] = 1.f;
-  }
-  for (int i = 1; i <= K; ++i) {
-    const double* __restrict__ yi = Y + (int64_t)i * N * ldy;
-    const double sd = scal[(l * K + (i - 1)) * 3 + 0];
-    const double* __restrict__ y_s = yi + s * ldy;
-    const double* __restrict__ y_d = yi + d * ldy;
-    float* __restrict__ o_s = out_s + (int64_t)i * Fp;
-    float* __restrict__ o_d = out_d + (int64_t)i * Fp;
-    for (int c = lane; c < F; c += 64) {
-      o_s[1 + c] = (float)(y_s[c] - sd * x_d[c]);
-      o_d[1 + c] = (float)(y_d[c] - sd * x_s[c]);
+    const double xs = x_s[c], xd = x_d[c];
+    double ys[KT > 0 ? KT : kMaxSignK], yd[KT > 0 ? KT : kMaxSignK];
+#pragma unroll
+    for (int i = 0; i < (KT > 0 ? KT : kMaxSignK); ++i) {
+      if (i < KK) {
+        ys[i] = x_s[(int64_t)(i + 1) * plane + c];
+        yd[i] = x_d[(int64_t)(i + 1) * plane + c];
+      }
     }
-    if (lane == 0) {
-      o_s[0] = (float)scal[(l * K + (i - 1)) * 3 + 1];
-      o_d[0] = (float)scal[(l * K + (i - 1)) * 3 + 2];
+    out_s[1 + c] = (float)xs;   // operator 0: x = [[1|X[s]],[1|X[d]]]  (tuned_SIGN.py:119-125)
+    out_d[1 + c] = (float)xd;
+#pragma unroll
+    for (int i = 0; i < (KT > 0 ? KT : kMaxSignK); ++i) {
+      if (i < KK) {
+        out_s[(int64_t)(i + 1) * Fp + 1 + c] = (float)(ys[i] - sd[i] * xd);
+        out_d[(int64_t)(i + 1) * Fp + 1 + c] = (float)(yd[i] - sd[i] * xs);
+      }
     }
   }
+  if (lane <= KK) {
+    out_s[(int64_t)lane * Fp] = lane == 0 ? 1.f : (float)scal[(l * KK + (lane - 1)) * 3 + 1];
+    out_d[(int64_t)lane * Fp] = lane == 0 ? 1.f : (float)scal[(l * KK + (lane - 1)) * 3 + 2];
+  }
+}
+
+// n_alloc of the scalar kernel when its ball has radius <= 1: deg(s) + deg(d) + 2 bounds the ball,
+// no sizing BFS needed
+__global__ void sop_ball_bound_kernel(const int32_t* __restrict__ indptr, int64_t N,
+                                      const int64_t* __restrict__ links, int64_t L, int radius,
+                                      int32_t* __restrict__ n_nodes, int32_t* __restrict__ err_flag) {
+  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L) return;
+  const int64_t s = links[2 * l], d = links[2 * l + 1];
+  if (s < 0 || s >= N || d < 0 || d >= N || s == d) {
+    atomicMax(err_flag, s == d ? 2 : 1);
+    n_nodes[l] = 0;
+    return;
+  }
+  n_nodes[l] = radius == 0 ? 2 : 2 + (indptr[s + 1] - indptr[s]) + (indptr[d + 1] - indptr[d]);
 }
 
 // Y (f64, padded ld) -> out fp32 [K, N, F]
@@ -406,9 +432,15 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
   int32_t* class_count = reinterpret_cast<int32_t*>(ds + 8);
   if (ctx->profiling) S3GRL_HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
   S3GRL_HIP_TRY(hipMemsetAsync(ds, 0, 32 * sizeof(int64_t), ctx->stream));
-  // the ball of {s,d}: same BFS as PoS, no row selection
-  S3GRL_TRY(launch_count(ctx, g, links, L, RB, 0, 1, nullptr, 0, nullptr, nullptr, n_nodes, p_nodes, n_rows,
-                         n_jobs, lvl_max, reinterpret_cast<int32_t*>(ds), ctx->d_stats));
+  // capacity of every link's ball: the sizing BFS of the PoS path, or a degree bound for radius <= 1
+  if (RB <= 1) {
+    hipLaunchKernelGGL(sop_ball_bound_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream,
+                       g->indptr, g->num_nodes, links, L, RB, n_nodes, reinterpret_cast<int32_t*>(ds));
+    S3GRL_HIP_TRY(hipGetLastError());
+  } else {
+    S3GRL_TRY(launch_count(ctx, g, links, L, RB, 0, 1, nullptr, 0, nullptr, nullptr, n_nodes, p_nodes, n_rows,
+                           n_jobs, lvl_max, reinterpret_cast<int32_t*>(ds), ctx->d_stats));
+  }
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_nodes, L, node_off, scan_ws));
   const int fixed = 4 * (3 * W + kMaxLevels + 32 + kHubWords + 6 * 16) + 64;
   const int per_node = 4 + 16 * HB;
@@ -448,7 +480,9 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
                        g->indices, W, s->dinv, links, class_list + (int64_t)c * L, node_off, K,    \
                        HB, RB, g->max_degree > kHubArmDegree ? 1 : 0, scal);                                                                  \
   } while (0)
-    if (c == 0) {
+    if (c == 0 && RB <= 1) {   // a ball of a dozen nodes: one wavefront per link, no cross-wave barriers
+      if (sparse) S3GRL_SOP_LAUNCH(64, 4); else S3GRL_SOP_LAUNCH(64, 8);
+    } else if (c == 0) {
       if (sparse) S3GRL_SOP_LAUNCH(256, 4); else S3GRL_SOP_LAUNCH(256, 8);
     } else {
       if (sparse) S3GRL_SOP_LAUNCH(1024, 4); else S3GRL_SOP_LAUNCH(1024, 8);
@@ -457,8 +491,21 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
     S3GRL_HIP_TRY(hipGetLastError());
   }
   if (ctx->profiling) S3GRL_HIP_TRY(hipEventRecord(ctx->ev[5], ctx->stream));
-  hipLaunchKernelGGL(sop_rows_kernel, dim3((unsigned)((L + 3) / 4)), dim3(256), 0, ctx->stream, links,
-                     L, s->Y, g->num_nodes, s->ldy, (int)s->F, K, scal, rows);
+  {
+    const dim3 grid((unsigned)((L + 3) / 4)), block(256);
+#define S3GRL_ROWS(KT)                                                                            \
+  hipLaunchKernelGGL(sop_rows_kernel<KT>, grid, block, 0, ctx->stream, links, L, s->Y, g->num_nodes, \
+                     s->ldy, (int)s->F, K, scal, rows)
+    switch (K) {   // the common sign_k get their loops unrolled (2K + 2 loads in registers)
+      case 1: S3GRL_ROWS(1); break;
+      case 2: S3GRL_ROWS(2); break;
+      case 3: S3GRL_ROWS(3); break;
+      case 4: S3GRL_ROWS(4); break;
+      case 5: S3GRL_ROWS(5); break;
+      default: S3GRL_ROWS(0); break;
+    }
+#undef S3GRL_ROWS
+  }
   S3GRL_HIP_TRY(hipGetLastError());
   if (ctx->profiling) {
     S3GRL_HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
