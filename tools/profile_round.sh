@@ -1,25 +1,33 @@
 #!/bin/bash
-# Round profile of the default bench (run ON THE GPU BOX through gpurun, from the repo root):
-#   gpurun -- 'bash tools/profile_round.sh v8'
-# leaves gpurun_out/<tag>/{trace,fetch,write,tcc,sq}/ + bench.json; afterwards, in the build
-# container:  python tools/pmc_collect.py --tag r01_<tag> --build "..." --bench-json gpurun_out/<tag>/bench.json \
-#                 gpurun_out/<tag>/{fetch,write,tcc,sq}
-# Counter passes are separate runs without any trace (MI355X_MICROARCH.md, HBM section); the
-# program follows `--` directly (no env/bash hop under rocprofv3).
+# Round profile (run ON THE GPU BOX through gpurun, from the repo root):
+#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r02'
+# For every workload below: a rocprofv3 --kernel-trace --stats summary of `bench.py`, and the bench
+# line itself with the counters collected in the same run (bench.py --collect-pmc: one child
+# rocprofv3 --pmc pass per counter group, never together with a trace; the program itself after `--`).
+# Plus the FETCH_SIZE calibration (tools/pmc_calibrate.py).  Everything lands in
+# gpurun_out/<tag>/; copy what is to be judged into profiles/ afterwards:
+#   for f in gpurun_out/r02/*.{json,csv}; do cp $f profiles/r02_$(basename $f); done
 set -o pipefail
 TAG=${1:-round}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-ONE="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline"
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/trace.log 2>&1 &&
-timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $ONE > $O/fetch.log 2>&1 &&
-timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $ONE > $O/write.log 2>&1 &&
-timeout -k 10 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/tcc -- $ONE > $O/tcc.log 2>&1 &&
-timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES --output-format csv -d $O/sq -- $ONE > $O/sq.log 2>&1 &&
-cd $R && timeout -k 10 300 python3 bench.py > $O/bench.json 2> $O/bench.err
-rc=$?
-find $O -name "*kernel_trace.csv" -delete
-echo "profile_round rc=$rc"; tail -c 400 $O/bench.json
+rc=0
+for wl in pubmed_pos_k3 pubmed_pos_k3_dense pubmed_sop_k3 pubmed_pos_k5 collab_pos_k3; do
+  timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$wl -- python3 $R/bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --no-api > $O/trace_$wl.log 2>&1 || rc=1
+  f=$(find $O/trace_$wl -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_$wl.csv
+  rm -rf $O/trace_$wl
+done
+timeout -k 10 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/calib -- python3 $R/tools/pmc_calibrate.py --run $O/calib_known.json > $O/calib.log 2>&1 || rc=1
+python3 $R/tools/pmc_calibrate.py --parse $O/calib $O/calib_known.json --out $O/pmc_calibration.json || rc=1
+rm -rf $O/calib
+cd $R
+for wl in pubmed_pos_k3 pubmed_pos_k3_dense pubmed_sop_k3; do
+  timeout -k 10 420 python3 bench.py --workload $wl --collect-pmc > $O/bench_$wl.json 2> $O/bench_$wl.err || rc=1
+done
+for wl in pubmed_pos_k5 collab_pos_k3 cora_posplus_k3 usair_pos_k2; do
+  timeout -k 10 300 python3 bench.py --workload $wl > $O/bench_$wl.json 2> $O/bench_$wl.err || rc=1
+done
+echo "profile_round rc=$rc"; ls $O
 exit $rc
