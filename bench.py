@@ -273,7 +273,7 @@ def main():
     ap.add_argument("--collect-pmc", action="store_true",
                     help="collect FETCH_SIZE / WRITE_SIZE / L2 hit rate of this command in child rocprofv3 passes")
     ap.add_argument("--max-links", type=int, default=0, help="truncate the link list (debug)")
-    ap.add_argument("--chunks", type=int, default=4,
+    ap.add_argument("--chunks", type=int, default=2,
                     help="N > 1: pieces per rank (all-gather of piece c overlaps the compute of c+1)")
     ap.add_argument("--no-allgather", action="store_true",
                     help="N > 1: every rank keeps its shard (data-parallel consumer); no collective")
@@ -471,9 +471,9 @@ def main():
         if world > 1:
             comp = [r["structure_ms"] + r["propagate_ms"] + r["gather_ms"] + r["sop_ms"] for r in per_rank]
             line["multi_gpu"] = {
-                "sharding": "contiguous link ranges balanced by exact subgraph size (the engine's sizing "
-                            "pass over the whole list, once at set-up: parallel.measured_cost); graph + X "
-                            "replicated",
+                "sharding": "contiguous link ranges balanced by the engine's per-link cost model on exact "
+                            "subgraph sizes (the sizing pass over the whole list, once at set-up: "
+                            "parallel.measured_cost / s3grl_plan_link_cost); graph + X replicated",
                 "collective": None if args.no_allgather else
                               ("%d padded all_gather_into_tensor per step (pieces of a range are gathered on "
                                "RCCL's stream while the next piece is computed) + compaction" % args.chunks

@@ -163,6 +163,15 @@ s3grl_status s3grl_plan_row_nodes(const s3grl_plan* p, int64_t* row_nodes);
 s3grl_status s3grl_plan_export_subgraphs(const s3grl_plan* p, int64_t* node_ptr, int32_t* nodes,
                                          int8_t* dists);
 
+/* Relative cost of every link (device fp32 [L] out), in arbitrary units, from the sizes the plan
+ * measured — what a multi-GPU caller balances its shards by (a count-only plan is enough).  The
+ * model follows the kernels and was fitted on MI355X: multi-hop plans  n + 800  (gather and row
+ * walks grow with the subgraph, ~800 nodes' worth of fixed work per link: PubMed 8 shards within
+ * 4 % of each other); one-hop plans on big graphs  e_bound + 150  with e_bound the bound of the
+ * induced entries the sizing pass derives from the degree-oriented rows (a hub-rich positive costs
+ * several times a random negative of the collab-scale workload; node counts alone say 1.5x). */
+s3grl_status s3grl_plan_link_cost(const s3grl_plan* p, float* cost);
+
 /* PoS / PoS Plus, feature half: rows[r, i, :] = [z | Σ_w Â^i[row r, w] X[w, :]].
  * X fp32 [N, F] row-major with leading dimension ldx (elements); rows fp32
  * [total_rows, K+1, 1+F] dense.  Asynchronous on the context's stream. */

@@ -32,7 +32,7 @@ SYMBOLS = [
     "s3grl_context_set_profiling", "s3grl_context_trim", "s3grl_plan_gather_traffic",
     "s3grl_graph_create", "s3grl_graph_destroy",
     "s3grl_plan_create", "s3grl_plan_destroy", "s3grl_plan_get_stats", "s3grl_plan_row_ptr",
-    "s3grl_plan_row_nodes", "s3grl_plan_export_subgraphs", "s3grl_run",
+    "s3grl_plan_row_nodes", "s3grl_plan_export_subgraphs", "s3grl_plan_link_cost", "s3grl_run",
     "s3grl_sop_create", "s3grl_sop_destroy", "s3grl_sop_run", "s3grl_sop_features",
     "s3grl_features_create", "s3grl_features_destroy", "s3grl_features_info", "s3grl_run_features",
     "s3grl_centre_pool_forward", "s3grl_centre_pool_backward", "s3grl_calibration_read",
@@ -106,6 +106,7 @@ def lib():
         "s3grl_plan_row_ptr": [vp, vp],
         "s3grl_plan_row_nodes": [vp, vp],
         "s3grl_plan_export_subgraphs": [vp, vp, vp, vp],
+        "s3grl_plan_link_cost": [vp, vp],
         "s3grl_run": [vp, vp, vp, i64, i64, vp],
         "s3grl_sop_create": [vp, vp, vp, i64, i64, i32, C.POINTER(vp)],
         "s3grl_sop_destroy": [vp],

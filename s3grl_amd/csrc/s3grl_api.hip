@@ -118,6 +118,13 @@ __global__ void max_i32_kernel(const int32_t* __restrict__ in, int64_t n, int64_
   if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<long long*>(out), (long long)m);
 }
 
+__global__ void link_cost_kernel(const int32_t* __restrict__ n_nodes, const int32_t* __restrict__ e_cap,
+                                 int64_t L, float* __restrict__ cost) {
+  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L) return;
+  cost[l] = e_cap ? (float)e_cap[l] + 150.f : (float)n_nodes[l] + 800.f;
+}
+
 // job_n[job_off[l] + p] = n_nodes[l]: every row pair of a link gets a list of the link's size
 __global__ void expand_job_n_kernel(const int32_t* __restrict__ n_nodes,
                                     const int64_t* __restrict__ job_off, int64_t L,
@@ -445,7 +452,8 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
     S3GRL_TRY(arena_alloc(ctx, (size_t)L * slot, &stash, tr));
   int32_t* e_cap = nullptr;
   if (onehop) {
-    S3GRL_TRY(arena_alloc(ctx, (size_t)L, &e_cap, tr));
+    S3GRL_TRY(arena_alloc(ctx, (size_t)L, &e_cap, own));
+    plan->e_cap = e_cap;
     S3GRL_TRY(launch_count1(ctx, g, plan->links, L, plus ? 1 : 0, K, partner, mirror_of, plan->n_nodes, p_nodes,
                             n_rows, n_jobs, lvl_max, e_cap, reinterpret_cast<int32_t*>(ds), st + 3 * kStatRow));
   } else {
@@ -624,6 +632,15 @@ s3grl_status s3grl_plan_gather_traffic(s3grl_context* ctx, const s3grl_plan* p,
 s3grl_status s3grl_plan_get_stats(const s3grl_plan* p, s3grl_plan_stats* out) {
   if (!p || !out) return S3GRL_ERR_INVALID_ARGUMENT;
   *out = p->stats;
+  return S3GRL_OK;
+}
+
+s3grl_status s3grl_plan_link_cost(const s3grl_plan* p, float* cost) {
+  if (!p || (!cost && p->L)) return S3GRL_ERR_INVALID_ARGUMENT;
+  if (p->L == 0) return S3GRL_OK;
+  hipLaunchKernelGGL(link_cost_kernel, dim3((unsigned)((p->L + 255) / 256)), dim3(256), 0, p->ctx->stream,
+                     p->n_nodes, p->e_cap, p->L, cost);
+  S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
 

@@ -135,6 +135,7 @@ struct s3grl_plan {
   int64_t* row_ptr = nullptr;    // [L+1]
   int64_t* job_off = nullptr;    // [L+1]
   int32_t* lvl = nullptr;        // [L, kMaxLevels] cumulative node count per BFS level
+  int32_t* e_cap = nullptr;      // [L] bound of the induced entries (one-hop plans on big graphs), else null
   int32_t* c_ids = nullptr;      // [Σn] subgraph nodes, hop-major, ascending id inside a hop
   // per job (row pair)
   s3grl::Job* jobs = nullptr;    // [njobs]

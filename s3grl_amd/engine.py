@@ -297,6 +297,19 @@ class Engine:
         finally:
             p.close()
 
+    def link_costs(self, graph, links, *, num_hops=1, rw=None, ratio_per_hop=1.0, max_nodes_per_hop=None,
+                   seed=0):
+        """fp32 [L] on the device: the relative cost of every link (s3grl_plan_link_cost), from the
+        sizing pass alone — the weights a multi-GPU job balances its shards by."""
+        p = self.plan(graph, links, mode="pos", num_hops=num_hops, sign_k=2, rw=rw, ratio_per_hop=ratio_per_hop,
+                      max_nodes_per_hop=max_nodes_per_hop, seed=seed, count_only=True)
+        try:
+            cost = torch.empty(p.num_links, dtype=torch.float32, device=self.device)
+            N.check(N.lib().s3grl_plan_link_cost(p._h, _ptr(cost)), "s3grl_plan_link_cost")
+            return cost
+        finally:
+            p.close()
+
     def plan(self, graph, links, *, mode="pos", num_hops=1, sign_k=3, strategy="intersection",
              directed=False, full_stats=False, fold_reversed=True, rw=None, ratio_per_hop=1.0,
              max_nodes_per_hop=None, seed=0, count_only=False):

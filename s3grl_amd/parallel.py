@@ -61,12 +61,11 @@ def khop_cost(A, link_index, num_hops):
     return tot[li[0]] + tot[li[1]]
 
 
-def measured_cost(engine, graph, link_index, num_hops, per_link=48.0):
-    """Exact subgraph sizes from the engine's sizing pass (count kernel only) + a fixed per-link
-    share: what SURVEY §8(e) calls "the plan pass's exact vol(S)".  One cheap pass over the whole
-    list at set-up time, identical on every rank."""
-    n = engine.subgraph_sizes(graph, engine.links(link_index), num_hops=num_hops)
-    return n.cpu().numpy().astype(np.float64) + per_link
+def measured_cost(engine, graph, link_index, num_hops):
+    """The engine's own per-link cost (`Engine.link_costs`: the sizing pass alone + the cost model
+    of s3grl_plan_link_cost) — what SURVEY §8(e) calls balancing by "the plan pass's exact vol(S)".
+    One cheap pass over the whole list at set-up time, identical on every rank."""
+    return engine.link_costs(graph, engine.links(link_index), num_hops=num_hops).cpu().numpy().astype(np.float64)
 
 
 def chunk_bounds(lo, hi, chunks, cost=None):
