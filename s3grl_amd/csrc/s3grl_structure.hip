@@ -528,7 +528,9 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
 // whose subgraph does not fit what the bitmaps leave of 160 KiB); same code, slower memory.
 // HS = true: the visited set is a hash table sized by the subgraph (keys/vals of C = pow2 >= 2n
 // slots) instead of three N-bit bitmaps, local id = position in the hop-major list: for graphs
-// whose bitmaps alone would take tens of KB of LDS per workgroup.  Same results bit for bit.
+// whose bitmaps alone would take tens of KB of LDS per workgroup.  Same node lists, rows and
+// statistics bit for bit; the sums agree to fp32 round-off (small fully-reached subgraphs are
+// propagated through an LDS adjacency bit matrix in this flavour: another summation order).
 template <int T, int K, int G, bool GS, bool HS>
 __global__ __launch_bounds__(T) void link_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int W,

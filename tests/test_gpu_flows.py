@@ -245,3 +245,67 @@ def test_sharded_precompute_with_the_engine_world1_nccl(mode, chunks):
     finally:
         dist.destroy_process_group()
         parallel._Buffers.clear()
+
+
+def test_graph_create_rejects_malformed_csr_and_trim_returns_memory():
+    """the raw-CSR entry validates its input on the device (ids in range, rows strictly
+    ascending, monotone indptr) instead of corrupting LDS; `trim` gives the cached workspace back."""
+    import torch
+    from s3grl_amd.engine import Engine
+
+    eng = Engine("cuda:0")
+    good_ptr, good_idx = np.array([0, 2, 4, 6]), np.array([1, 2, 0, 2, 0, 1])
+    g = eng.graph(indptr=good_ptr, indices=good_idx, num_nodes=3)
+    g.close()
+    for ptr, idx, what in [
+        (np.array([0, 2, 4, 6]), np.array([1, 7, 0, 2, 0, 1]), "outside"),          # id out of range
+        (np.array([0, 2, 4, 6]), np.array([2, 1, 0, 2, 0, 1]), "ascending"),        # unsorted row
+        (np.array([0, 2, 4, 6]), np.array([1, 1, 0, 2, 0, 1]), "ascending"),        # duplicate entry
+        (np.array([0, 4, 2, 6]), np.array([1, 2, 0, 2, 0, 1]), "monotone"),         # indptr not monotone
+        (np.array([0, 2, 4, 5]), np.array([1, 2, 0, 2, 0, 1]), "monotone"),         # does not end at nnz
+    ]:
+        with pytest.raises(ValueError, match=what):
+            eng.graph(indptr=ptr, indices=idx, num_nodes=3)
+    # a PubMed-scale plan leaves GBs cached in the context's arena; trim hands them back
+    from s3grl_amd import workloads
+
+    w = workloads.make("cora_posplus_k3")
+    li, _ = w.split.all_links()
+    G = eng.graph(w.A)
+    res = eng.precompute(G, eng.features(w.X), eng.links(li), mode="pos_plus", num_hops=3, sign_k=3)
+    before = res.stats["workspace_bytes"]
+    del res
+    G.close()
+    torch.cuda.synchronize()
+    freed = eng.trim()
+    assert freed > 0 and freed <= before
+    assert eng.trim() == 0
+    # and the engine keeps working afterwards
+    G = eng.graph(w.A)
+    res = eng.precompute(G, eng.features(w.X), eng.links(li[:, :100]), mode="pos", num_hops=2, sign_k=2)
+    assert res.rows.shape[0] == 200
+    eng.close()
+
+
+def test_link_costs_and_sizes_from_the_sizing_pass():
+    from s3grl_amd.engine import Engine
+
+    eng = Engine("cuda:0")
+    g = load_extract("usair")
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    G = eng.graph(A)
+    links = eng.links(g["links"].T)
+    sizes = eng.subgraph_sizes(G, links, num_hops=2).cpu().numpy()
+    plan = eng.plan(G, links, mode="pos", num_hops=2, sign_k=2, full_stats=True)
+    node_ptr = plan.export_subgraphs()[0].cpu().numpy()
+    assert np.array_equal(sizes, np.diff(node_ptr))            # folding off: every link sized
+    cost = eng.link_costs(G, links, num_hops=2).cpu().numpy()
+    assert np.allclose(cost, sizes + 800.0)
+    plan.close()
+    # a count-only plan cannot be run
+    p = eng.plan(G, links, mode="pos", num_hops=2, sign_k=2, count_only=True)
+    with pytest.raises(ValueError, match="count-only"):
+        p.run(eng.features(np.ones((n, 4), dtype=np.float32)))
+    p.close()
+    eng.close()
