@@ -119,14 +119,34 @@ __device__ __forceinline__ uint32_t select_by_mask(uint64_t mask, uint32_t if_se
   return r;
 }
 
-template <int K>
+// Chunk fetch of the MASKED variant of the kernel (the default).  The unconditional form above makes
+// every lane of a wave-instruction fetch 16 bytes — a masked-off lane the shared chunk of zeros —
+// so a row with a third of its chunks populated still pushes 2 x 1 KiB through the CU's texture
+// path: 206 M wave-loads x 1 KiB per PubMed launch against a vector-L1 return path of 64 B/clk/CU
+// is 6 of the kernel's 8 ms.  Here the chunks are read through a raw BUFFER descriptor over
+// pk_data and a masked-off lane is given an offset beyond the buffer: the hardware's range check
+// returns zeros for it without a memory request.  Still one unconditional, compiler-visible load
+// per lane (no branches, vmcnt tracked by the compiler) — only populated chunks travel.
+// (An EXEC-masked global_load in inline assembly does the same on paper; the compiler cannot know
+// that such a load is still in flight when it copies or reuses the destination registers, and the
+// kernel faulted at PubMed scale.)
+typedef unsigned int uint4_t __attribute__((ext_vector_type(4)));
+constexpr uint32_t kOobOffset = 0x80000000u;   // >= any pk_data size (build_packed_rows keeps it below 2 GiB)
+
+__device__ __forceinline__ uint32_t select_or_oob(uint64_t mask, uint32_t if_set, uint32_t oob) {
+  uint32_t r;   // lane-wise: bit `lane` of the wave-uniform mask ? if_set : oob
+  asm("v_cndmask_b32_e64 %0, %3, %1, %2" : "=v"(r) : "v"(if_set), "s"(mask), "v"(oob));
+  return r;
+}
+
+template <int K, bool MASKED>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
     const Job* __restrict__ jobs, int njobs, const int32_t* __restrict__ c_ids,
     const float* __restrict__ c_coef, const float* __restrict__ job_z,
     const int32_t* __restrict__ job_lim, const int32_t* __restrict__ job_order,
     const PackedHdr* __restrict__ hdr,
-    const float4_t* __restrict__ data, int64_t N, const float* __restrict__ X, int64_t ldx, int F,
-    float* __restrict__ rows) {
+    const float4_t* __restrict__ data, uint32_t data_bytes, int64_t N, const float* __restrict__ X,
+    int64_t ldx, int F, float* __restrict__ rows) {
   constexpr int CH = 2;
   constexpr int U = 4;   // rows per group
   const int lane = threadIdx.x & 63;
@@ -140,6 +160,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
   const float2* __restrict__ cf = reinterpret_cast<const float2*>(c_coef) + job.coef_off;
   const PackedHdr* __restrict__ th = hdr + (int64_t)blockIdx.y * N;
   const char* __restrict__ bytes = reinterpret_cast<const char*>(data);
+  // raw buffer over pk_data (dword 3 = 0x00020000: gfx9-family untyped 32-bit data format), stride 0:
+  // an offset at or beyond data_bytes is out of range and reads as zero
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float4_t*>(data), 0, (int)data_bytes, 0x00020000);
+  const uint32_t oobv = kOobOffset;
   // Operator i+1 has no non-zero coefficient at list positions >= lim[i] (a walk of i+1 steps
   // stays within i+1 hops, and the list is hop-major), lim non-decreasing: its multiply-adds are
   // skipped there.  On PubMed (3 hops, K = 3) four fifths of the rows only feed the last operator.
@@ -187,11 +212,17 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t base = (uint32_t)h[u].off;
-      const uint32_t o0 = select_by_mask(h[u].m0, (base + (uint32_t)below(h[u].m0)) << 4);
-      const uint32_t o1 = select_by_mask(
-          h[u].m1, (base + (uint32_t)__popcll(h[u].m0) + (uint32_t)below(h[u].m1)) << 4);
-      v[u][0] = *reinterpret_cast<const float4_t*>(bytes + o0);
-      v[u][1] = *reinterpret_cast<const float4_t*>(bytes + o1);
+      const uint32_t a0 = (base + (uint32_t)below(h[u].m0)) << 4;
+      const uint32_t a1 = (base + (uint32_t)__popcll(h[u].m0) + (uint32_t)below(h[u].m1)) << 4;
+      if constexpr (MASKED) {
+        v[u][0] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   rsrc, (int)select_or_oob(h[u].m0, a0, oobv), 0, 0));
+        v[u][1] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   rsrc, (int)select_or_oob(h[u].m1, a1, oobv), 0, 0));
+      } else {
+        v[u][0] = *reinterpret_cast<const float4_t*>(bytes + select_by_mask(h[u].m0, a0));
+        v[u][1] = *reinterpret_cast<const float4_t*>(bytes + select_by_mask(h[u].m1, a1));
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -230,11 +261,18 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
     for (int j = j0; j < cnt; ++j) {
       const PackedHdr h = th[uid[j]];
       const uint32_t base = (uint32_t)h.off;
-      const uint32_t o0 = select_by_mask(h.m0, (base + (uint32_t)below(h.m0)) << 4);
-      const uint32_t o1 = select_by_mask(h.m1, (base + (uint32_t)__popcll(h.m0) + (uint32_t)below(h.m1)) << 4);
+      const uint32_t a0 = (base + (uint32_t)below(h.m0)) << 4;
+      const uint32_t a1 = (base + (uint32_t)__popcll(h.m0) + (uint32_t)below(h.m1)) << 4;
       float4_t v[CH];
-      v[0] = *reinterpret_cast<const float4_t*>(bytes + o0);
-      v[1] = *reinterpret_cast<const float4_t*>(bytes + o1);
+      if constexpr (MASKED) {
+        v[0] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                                                rsrc, (int)select_or_oob(h.m0, a0, oobv), 0, 0));
+        v[1] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                                                rsrc, (int)select_or_oob(h.m1, a1, oobv), 0, 0));
+      } else {
+        v[0] = *reinterpret_cast<const float4_t*>(bytes + select_by_mask(h.m0, a0));
+        v[1] = *reinterpret_cast<const float4_t*>(bytes + select_by_mask(h.m1, a1));
+      }
 #pragma unroll
       for (int i = I0; i < K; ++i) {
         const float2 q = cf[(int64_t)i * cnt + j];
@@ -396,10 +434,18 @@ template <int K>
 s3grl_status launch_packed_k(s3grl_context* ctx, const s3grl_plan* p, const s3grl_features* f,
                              float* rows) {
   const unsigned gx = (unsigned)((p->njobs + kWavesPerBlock - 1) / kWavesPerBlock);
-  hipLaunchKernelGGL((gather_packed_kernel<K>), dim3(gx, (unsigned)f->tiles), dim3(kWavesPerBlock * 64),
-                     0, ctx->stream, p->jobs, (int)p->njobs, p->c_ids, p->c_coef, p->job_z, p->job_lim, p->job_order,
-                     static_cast<const PackedHdr*>(f->pk_hdr), static_cast<const float4_t*>(f->pk_data),
-                     f->N, f->dense, f->ld, (int)f->F, rows);
+  static const bool masked = !getenv("S3GRL_GATHER_UNMASKED");   // comparison hook: the unconditional loads
+  const uint32_t data_bytes = (uint32_t)((f->pk_chunks + 1) * 16);
+  if (masked)
+    hipLaunchKernelGGL((gather_packed_kernel<K, true>), dim3(gx, (unsigned)f->tiles), dim3(kWavesPerBlock * 64),
+                       0, ctx->stream, p->jobs, (int)p->njobs, p->c_ids, p->c_coef, p->job_z, p->job_lim,
+                       p->job_order, static_cast<const PackedHdr*>(f->pk_hdr),
+                       static_cast<const float4_t*>(f->pk_data), data_bytes, f->N, f->dense, f->ld, (int)f->F, rows);
+  else
+    hipLaunchKernelGGL((gather_packed_kernel<K, false>), dim3(gx, (unsigned)f->tiles), dim3(kWavesPerBlock * 64),
+                       0, ctx->stream, p->jobs, (int)p->njobs, p->c_ids, p->c_coef, p->job_z, p->job_lim,
+                       p->job_order, static_cast<const PackedHdr*>(f->pk_hdr),
+                       static_cast<const float4_t*>(f->pk_data), data_bytes, f->N, f->dense, f->ld, (int)f->F, rows);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -434,7 +480,7 @@ s3grl_status build_packed_rows(s3grl_context* ctx, s3grl_features* f, double max
   const double slots = (double)N * (double)((f->F + 3) / 4);
   f->pk_chunks = chunks;
   if ((double)chunks > max_density * slots) return S3GRL_OK;
-  if ((chunks + 1) * 16 >= ((int64_t)1 << 32)) return S3GRL_OK;   // the kernel addresses chunks with 32-bit byte offsets
+  if ((chunks + 1) * 16 >= ((int64_t)1 << 31)) return S3GRL_OK;   // 32-bit byte offsets, and room for the out-of-range one
   void* hdr = nullptr;
   void* data = nullptr;
   S3GRL_TRY(ctx->arena.alloc((size_t)items * sizeof(PackedHdr), &hdr));
