@@ -346,16 +346,25 @@ __global__ __launch_bounds__(T) void link_full_kernel(
           const int j = hvals[max(slot, 0)];
           const int i = a.row;
           const bool target = (v == src && u == dst) || (v == dst && u == src);
-          if (valid && slot >= 0 && !target) {
-            if constexpr (BMG) {
-              const int k = atomicAdd(&sh[30], 1);
+          const bool found = valid && slot >= 0 && !target;
+          if constexpr (BMG) {
+            // one LDS atomic per wavefront for the list position (the visit is called by all lanes)
+            const unsigned long long fm = __ballot(found);
+            int base = 0;
+            if (fm) {
+              const int leader = __ffsll((long long)fm) - 1;
+              if ((tid & 63) == leader) base = atomicAdd(&sh[30], __popcll(fm));
+              base = __shfl(base, leader);
+            }
+            if (found) {
+              const int k = base + __popcll(fm & ((1ull << (tid & 63)) - 1ull));
               if (2 * k < ecap) elist[k] = ((uint32_t)i << 16) | (uint32_t)j;
               atomicAdd(&off[i], 1);
               if (i != j) atomicAdd(&off[j], 1);
-            } else {
-              atomicOr(&bm_l[i * WB + (j >> 5)], 1u << (j & 31));
-              if (i != j) atomicOr(&bm_l[j * WB + (i >> 5)], 1u << (i & 31));
             }
+          } else if (found) {
+            atomicOr(&bm_l[i * WB + (j >> 5)], 1u << (j & 31));
+            if (i != j) atomicOr(&bm_l[j * WB + (i >> 5)], 1u << (i & 31));
           }
         },
         [](RowAcc&, int, int) {});
@@ -394,9 +403,24 @@ __global__ __launch_bounds__(T) void link_full_kernel(
       // smaller entries), long ones through a per-wave bitmap of the n local ids.
       const int lane = tid & 63, wv = tid >> 6;
       uint32_t* wbm = sortbm + wv * WB;
+      // (a) rows of at most 16 entries — nearly all of them — four at a time per wavefront
+      {
+        const int sub = lane >> 4, sl = lane & 15;
+        for (int r0 = wv * 4; r0 < n; r0 += (T / 64) * 4) {
+          const int r = min(r0 + sub, n - 1);
+          const int b = off[r], len = off[r + 1] - b;
+          const bool mine = r0 + sub < n && len > 1 && len <= 16;
+          const int x = mine && sl < len ? cols_ld(b + sl) : 0x7fffffff;
+          int rank = 0;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) rank += __shfl(x, (lane & 48) + k) < x ? 1 : 0;
+          if (mine && sl < len) cols_st(b + rank, x);
+        }
+      }
+      // (b) longer rows, one wavefront each: by rank up to 64 entries, through a bitmap beyond
       for (int r = wv; r < n; r += T / 64) {
         const int b = off[r], len = off[r + 1] - b;
-        if (len <= 1) continue;
+        if (len <= 16) continue;
         if (len <= 64) {
           const int x = lane < len ? cols_ld(b + lane) : 0x7fffffff;
           int rank = 0;

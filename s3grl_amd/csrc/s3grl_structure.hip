@@ -1473,10 +1473,17 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
   for (int c = kFullBig - 1; c >= kFullBase; --c) {
     const int count = class_count_host[c];
     if (count == 0) continue;
+    // threads per link by class: a wavefront for the smallest subgraphs; the classes whose LDS
+    // leaves one or two workgroups per CU get 1024 / 512 threads (their probing trips are chains
+    // of dependent loads: more rows per trip, more loads in flight)
     if (c - kFullBase <= 1)
       S3GRL_TRY((launch_full_class<64, K, false>(ctx, a, L, c, count, next_stream(), nullptr, 0, count)));
-    else
+    else if (c - kFullBase <= 3)
       S3GRL_TRY((launch_full_class<256, K, false>(ctx, a, L, c, count, next_stream(), nullptr, 0, count)));
+    else if (c - kFullBase == 4)
+      S3GRL_TRY((launch_full_class<512, K, false>(ctx, a, L, c, count, next_stream(), nullptr, 0, count)));
+    else
+      S3GRL_TRY((launch_full_class<1024, K, false>(ctx, a, L, c, count, next_stream(), nullptr, 0, count)));
   }
   for (int c = kFullBase - 1; c >= kSparseBase; --c)
     if (class_count_host[c] > 0)
