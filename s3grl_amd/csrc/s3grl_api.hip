@@ -588,6 +588,10 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
                     "deg %lld  ops<K %lld  last op %lld  tail %lld\n",
             (long long)hs[16], (long long)hs[17], (long long)hs[18], (long long)hs[19],
             (long long)hs[20], (long long)hs[21]);
+    S3GRL_HIP_TRY(hipMemcpy(hs + 24, ds + 24, 8 * 8, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[s3grl] link_full_kernel, big class: merge %lld  hash+ids %lld  probes %lld  "
+                    "csr+sort %lld  passes %lld\n",
+            (long long)hs[24], (long long)hs[25], (long long)hs[26], (long long)hs[27], (long long)hs[28]);
   }
   plan->stats.workspace_bytes = (int64_t)ctx->arena.bytes_held();
   if (ctx->profiling) {

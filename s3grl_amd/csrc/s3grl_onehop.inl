@@ -187,10 +187,20 @@ __global__ __launch_bounds__(T) void link_full_kernel(
     float* __restrict__ job_z, int32_t* __restrict__ job_lim, int64_t* __restrict__ row_nodes,
     int32_t* __restrict__ lvl_out, unsigned long long* __restrict__ tot_edges,
     unsigned long long* __restrict__ tot_support, unsigned long long* __restrict__ tot_vol,
-    uint32_t* __restrict__ bm_scratch, int64_t bm_stride_words, int lds_bytes) {
+    uint32_t* __restrict__ bm_scratch, int64_t bm_stride_words, int lds_bytes,
+    unsigned long long* __restrict__ dbg) {
   extern __shared__ uint32_t smem[];
   const int tid = threadIdx.x;
   constexpr int G = 4;
+  // diagnostic only (S3GRL_DEBUG_STAMPS): cycles per phase summed over workgroups, slots 8..15
+  unsigned long long t_prev = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+#define S3GRL_FSTAMP(idx)                                                             \
+  if (dbg) {                                                                          \
+    __syncthreads();                                                                  \
+    const unsigned long long t_now = __builtin_amdgcn_s_memtime();                    \
+    if (threadIdx.x == 0) atomicAdd(&dbg[8 + idx], t_now - t_prev);                   \
+    t_prev = t_now;                                                                   \
+  }
   // BMG: a persistent grid, every workgroup owns one bit-matrix slice and strides over the class
   for (int item = blockIdx.x; item < count; item += gridDim.x) {
     const int l = class_list[item];
@@ -303,6 +313,7 @@ __global__ __launch_bounds__(T) void link_full_kernel(
       }
     }
     __syncthreads();   // list complete, tmp dead
+    S3GRL_FSTAMP(0)
 
     // ---- hash of S (probe structure), node list out, bit matrix zeroed --------------------------
     for (uint32_t t = tid; t <= hmask; t += T) hkeys[t] = -1;
@@ -337,6 +348,7 @@ __global__ __launch_bounds__(T) void link_full_kernel(
       if (r >= 2) cnpos[r - 2] = hvals[hs_find(hkeys, hmask, node)];
     }
     const int pos_src = src < dst ? 0 : 1, pos_dst = 1 - pos_src;
+    S3GRL_FSTAMP(1)
 
     // ---- masked induced adjacency through the oriented rows (reference utils.py:76-80) ----------
     walk_rows<T, G, 2>(
@@ -370,6 +382,7 @@ __global__ __launch_bounds__(T) void link_full_kernel(
         [](RowAcc&, int, int) {});
     if constexpr (BMG) __threadfence();   // the edge list is read back by other waves (through L2)
     __syncthreads();
+    S3GRL_FSTAMP(2)
 
     // ---- degrees, D^-1/2 (inf -> 0), CSR of local ids (ascending) --------------------------------
     if constexpr (BMG) {
@@ -483,6 +496,7 @@ __global__ __launch_bounds__(T) void link_full_kernel(
       if (tid == 0) off[n] = total;
     }
     __syncthreads();   // hash dead from here: cur / nxs take its space
+    S3GRL_FSTAMP(3)
     const int edges_total = off[n];
     // Long rows (src and dst are adjacent to about half of a one-hop subgraph each, a hub inside
     // it to more): four lanes would stride such a row for hundreds of trips while the rest of the
@@ -595,6 +609,7 @@ __global__ __launch_bounds__(T) void link_full_kernel(
       }
       __syncthreads();
     }
+    S3GRL_FSTAMP(4)
     vol_local = block_sum<T>(vol_local, sh);
     if (tid == 0) {
       atomicAdd(stat_slot(tot_edges), (unsigned long long)edges_total * (mirror >= 0 ? 2ull : 1ull));
