@@ -94,7 +94,7 @@ def _all_gather(out, inp, group, async_op=False):
 
 def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, group=None, gather=True,
                        rows_per_link=None, chunks=1, row_shape=None, dtype=torch.float32,
-                       device=None, timers=None):
+                       device=None, timers=None, collective_at_world1=False):
     """Shard `link_index` ([2, L]) over the ranks and (when `gather`) reassemble the whole result
     on every rank.
 
@@ -105,6 +105,8 @@ def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, grou
 
     Returns (rows, row_ptr, (lo, hi)): the WHOLE list on every rank when `gather`, else the local
     shard.  `timers` (dict, optional) receives host-side timestamps for the benchmark.
+    `collective_at_world1`: run the pieces / in-place all-gather / compaction path even on a
+    one-rank group (a test hook: it is how the collective code meets real RCCL on a one-GPU box).
     """
     li = torch.as_tensor(link_index)
     L = int(li.shape[1])
@@ -112,7 +114,7 @@ def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, grou
     lo, hi = b[rank], b[rank + 1]
     if rows_per_link is not None:
         return _fixed(compute, li, b, rank, world_size, cost, group, gather, int(rows_per_link),
-                      max(int(chunks), 1), tuple(row_shape), dtype, device, timers)
+                      max(int(chunks), 1), tuple(row_shape), dtype, device, timers, collective_at_world1)
     rows, row_ptr = compute(li[:, lo:hi])
     if not gather or world_size == 1:
         return rows, row_ptr, (lo, hi)
@@ -159,11 +161,11 @@ class _Buffers:
 
 
 def _fixed(compute, li, b, rank, world, cost, group, gather, rpl, chunks, row_shape, dtype, device,
-           timers):
+           timers, collective_at_world1=False):
     L = int(li.shape[1])
     lo, hi = b[rank], b[rank + 1]
     row_ptr = torch.arange(0, rpl * L + 1, rpl, dtype=torch.int64, device=device)
-    if not gather or world == 1:
+    if not gather or (world == 1 and not collective_at_world1):
         rows = _Buffers.get(("local", rank), (rpl * (hi - lo),) + row_shape, dtype, device)
         compute(li[:, lo:hi], rows)
         return rows, row_ptr[lo:hi + 1] - rpl * lo, (lo, hi)

@@ -227,6 +227,14 @@ def test_sharded_precompute_with_the_engine_world1_nccl(mode, chunks):
             compute, torch.from_numpy(links).to(eng.device), rank=0, world_size=1, cost=cost,
             rows_per_link=2, chunks=chunks, row_shape=(K + 1, 7), device=eng.device)
         assert (lo, hi) == (0, links.shape[1]) and torch.equal(rows, whole)
+        # the pipelined pieces + IN-PLACE all_gather_into_tensor + compaction, on real RCCL
+        for _ in range(2):          # the second call reuses the cached slots
+            rows_c, ptr_c, _ = parallel.sharded_precompute(
+                compute, torch.from_numpy(links).to(eng.device), rank=0, world_size=1, cost=cost,
+                rows_per_link=2, chunks=chunks, row_shape=(K + 1, 7), device=eng.device,
+                collective_at_world1=True)
+            torch.cuda.synchronize()
+            assert torch.equal(rows_c, whole) and ptr_c.tolist() == list(range(0, 2 * links.shape[1] + 1, 2))
         probe = whole[:8].clone()
         out = torch.empty_like(probe)
         dist.all_gather_into_tensor(out, probe)
