@@ -477,7 +477,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   // PoS has no common-neighbour rows: the LDS classes are known without a round trip
   if (!plus)
     S3GRL_TRY(launch_classify(ctx, g, 1, K, plan->n_nodes, p_nodes, lvl_max, L, class_count, class_list,
-                              !sampling, e_cap));
+                              !sampling, e_cap, stash ? slot : 0));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs, ds, 8 * 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs + 32, ds + 32, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_stats + 3 * kStatRow, st + 3 * kStatRow, kStatRow * sizeof(int64_t),
@@ -500,7 +500,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   const int cn_cap = (int)std::max<int64_t>(max_R - 2, 0) + 1;
   if (plus) {
     S3GRL_TRY(launch_classify(ctx, g, cn_cap, K, plan->n_nodes, p_nodes, lvl_max, L, class_count,
-                              class_list, !sampling, e_cap));
+                              class_list, !sampling, e_cap, stash ? slot : 0));
     S3GRL_HIP_TRY(hipMemcpyAsync(hs + 32, ds + 32, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
     S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
   }

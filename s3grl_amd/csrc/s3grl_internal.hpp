@@ -222,7 +222,8 @@ s3grl_status launch_scan_i32_to_i64(s3grl_context* ctx, const int32_t* in, int64
 s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_cap, int K,
                              const int32_t* n_nodes, const int32_t* p_nodes,
                              const int32_t* lvl_max, int64_t L, int32_t* class_count,
-                             int32_t* class_list, bool allow_hash = true, const int32_t* e_cap = nullptr);
+                             int32_t* class_list, bool allow_hash = true, const int32_t* e_cap = nullptr,
+                             int stash_slot = 0);
 // one-hop plans on big graphs (s3grl_onehop.inl): degree-oriented rows of the graph, and the
 // sizing pass that needs no bitmaps
 bool onehop_mode_for(const s3grl_graph* g);

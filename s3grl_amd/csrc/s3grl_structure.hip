@@ -458,7 +458,7 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
                                 const int32_t* __restrict__ p_nodes,
                                 const int32_t* __restrict__ lvl_max, int64_t L, ClassBounds bound,
                                 int sparse_mode, ClassBounds sbound, const int32_t* __restrict__ e_cap,
-                                ClassBounds fbound, int bm_limit,
+                                ClassBounds fbound, int bm_limit, int dm_max_n, int dm_min_need,
                                 int32_t* __restrict__ class_count, int32_t* __restrict__ class_list) {
   const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int n = l < L ? n_nodes[l] : 0;
@@ -483,7 +483,16 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
       atomicMax(&class_count[30], need_b);   // and its LDS
     }
   }
-  if (!sparse && sparse_mode && n > 0 && lvl_max[l] <= kSparseLevelMax) {
+  if (!sparse && sparse_mode == 2 && n > 0 && n <= dm_max_n && need > dm_min_need) {
+    // direct-map flavour: sbound = what the map leaves of the LDS; the list must be in the stash
+    if (need <= sbound.b[kNumClasses - 1]) {
+      sparse = true;
+#pragma unroll
+      for (int k = 0; k < kNumClasses; ++k) c += need > sbound.b[k] ? 1 : 0;
+      c += kSparseBase;
+    }
+  }
+  if (!sparse && sparse_mode == 1 && n > 0 && lvl_max[l] <= kSparseLevelMax) {
     const int sneed = link_lds_need_sparse(n, p);
     if (sneed <= sbound.b[kNumClasses - 1]) {
       sparse = true;
@@ -531,7 +540,12 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
 // whose bitmaps alone would take tens of KB of LDS per workgroup.  Same node lists, rows and
 // statistics bit for bit; the sums agree to fp32 round-off (small fully-reached subgraphs are
 // propagated through an LDS adjacency bit matrix in this flavour: another summation order).
-template <int T, int K, int G, bool GS, bool HS>
+// DM = true (with HS): the visited set is a direct map, one uint16 per node of the GRAPH holding the
+// node's position in the hop-major list (0xFFFF = not in S): a neighbour visit is one LDS read instead
+// of two bitmap words + a rank prefix + a popcount.  For graphs whose map (2N bytes) leaves most of
+// the LDS free; the list comes from count_kernel's stash (the host sends no other link here).  Rows
+// are walked in the same order by the same lanes as in the bitmap flavour: same sums bit for bit.
+template <int T, int K, int G, bool GS, bool HS, bool DM = false>
 __global__ __launch_bounds__(T) void link_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int W,
     const int64_t* __restrict__ links, const int32_t* __restrict__ class_list, int hops, int plus,
@@ -568,12 +582,15 @@ __global__ __launch_bounds__(T) void link_kernel(
   // visited set: three bitmaps of W words, or (HS) keys + vals of C words each
   uint32_t hmask = 0;
   int set_words = 3 * W;
-  if constexpr (HS) {
+  if constexpr (DM) {
+    set_words = 16 * W;   // 32 W uint16 entries
+  } else if constexpr (HS) {
     int C = 64;
     while (C < 2 * n_alloc) C <<= 1;
     hmask = (uint32_t)(C - 1);
     set_words = 2 * C;
   }
+  uint16_t* dmap = reinterpret_cast<uint16_t*>(smem);
   uint32_t* vis = smem;
   uint32_t* inP = smem + W;
   uint32_t* wpreP = smem + 2 * W;
@@ -605,12 +622,14 @@ __global__ __launch_bounds__(T) void link_kernel(
   // ---- BFS on the unmasked graph (reference utils.py:53-74) --------------------------------
   int nlev;
   int n;
-  if (stash && n_alloc - 2 <= slot) {
+  if (DM || (stash && n_alloc - 2 <= slot)) {
     // count_kernel left this link's node list (hop-major, ascending id inside a hop) and its
     // level ends in HBM: rebuild the LDS state from them instead of walking the graph again
     const int32_t* __restrict__ st = stash + (int64_t)l * slot;
     const int32_t* lv = lvl_out + (int64_t)l * kMaxLevels;   // rewritten below, after the barriers
-    if constexpr (HS) {
+    if constexpr (DM) {
+      for (int t = tid; t < 16 * W; t += T) smem[t] = 0xffffffffu;
+    } else if constexpr (HS) {
       for (uint32_t t = tid; t <= hmask; t += T) hkeys[t] = -1;
     } else {
       for (int t = tid; t < W; t += T) {
@@ -629,7 +648,9 @@ __global__ __launch_bounds__(T) void link_kernel(
     for (int t = tid; t < n_alloc; t += T) {
       const int v = t < 2 ? list[t] : st[t - 2];
       if (t >= 2) list[t] = v;
-      if constexpr (HS) {
+      if constexpr (DM) {
+        dmap[v] = (uint16_t)t;
+      } else if constexpr (HS) {
         hs_insert(hkeys, hmask, v);
         hvals[hs_find(hkeys, hmask, v)] = t;
       } else {
@@ -648,7 +669,8 @@ __global__ __launch_bounds__(T) void link_kernel(
   // set queries of the passes below: membership in S; index into the P-state arrays (+ is it in P);
   // the P-state index of list entry t (= node v)
   auto in_s = [&](int u) -> bool {
-    if constexpr (HS) return hs_find(hkeys, hmask, u) >= 0;
+    if constexpr (DM) return dmap[u] != 0xffffu;
+    else if constexpr (HS) return hs_find(hkeys, hmask, u) >= 0;
     else return test_bit(vis, u);
   };
   auto p_index_of_row = [&](int t, int v) -> int {
@@ -747,7 +769,7 @@ __global__ __launch_bounds__(T) void link_kernel(
   // measured a loss: USAir's 1-hop subgraphs are nearly as dense as their global rows (+20 % on
   // the link kernel), and on PubMed K=5 the matrix of a 300-500-node subgraph pushes the link
   // into a bigger LDS class (+10 %); the collab-scale config gains 12 %.
-  const bool use_bm = HS && !GS && K >= 2 && p == n && p_alloc == n_alloc && n <= kBmMaxNodes;
+  const bool use_bm = HS && !DM && !GS && K >= 2 && p == n && p_alloc == n_alloc && n <= kBmMaxNodes;
   uint32_t* bm = reinterpret_cast<uint32_t*>(nxs + p_alloc);              // [n][WB]
   uint16_t* pos_of_rank = reinterpret_cast<uint16_t*>(bm + (use_bm ? n * WB : 0));   // bitmap flavour
   uint16_t* rank_of_pos = pos_of_rank + n;
@@ -783,7 +805,8 @@ __global__ __launch_bounds__(T) void link_kernel(
     __syncthreads();
     if (tid == 0) {
       auto p_index = [&](int v) -> int {
-        if constexpr (HS) return hvals[hs_find(hkeys, hmask, v)];
+        if constexpr (DM) return (int)dmap[v];
+        else if constexpr (HS) return hvals[hs_find(hkeys, hmask, v)];
         else return rank_of(inP, wpreP, v);
       };
       const int la = p_index(node_a);
@@ -864,7 +887,13 @@ __global__ __launch_bounds__(T) void link_kernel(
             float2 sv;
             bool member;
             int col;   // list position of u (meaningful for members)
-            if constexpr (HS) {
+            if constexpr (DM) {
+              const int r = dmap[u];   // list position; 0xFFFF (>= p) = not in S
+              sv = s_in[min(r, p - 1)];
+              member = valid && r != 0xffff;
+              on = valid && r < p;
+              col = r;
+            } else if constexpr (HS) {
               const int slot = hs_find(hkeys, hmask, u);
               const int r = hvals[max(slot, 0)];
               sv = s_in[min(max(r, 0), p - 1)];
@@ -931,7 +960,12 @@ __global__ __launch_bounds__(T) void link_kernel(
           [&](RowAcc& a, int v, int u, bool valid) {
             bool member, on;
             float2 sv;
-            if constexpr (HS) {
+            if constexpr (DM) {
+              const int r = dmap[u];
+              sv = s_in[min(r, p - 1)];
+              member = valid && r != 0xffff;
+              on = valid && r < p;
+            } else if constexpr (HS) {
               const int slot = hs_find(hkeys, hmask, u);
               const int r = hvals[max(slot, 0)];
               sv = s_in[min(max(r, 0), p - 1)];
@@ -1244,11 +1278,50 @@ static ClassBounds class_bounds_full(int cn_cap, int K) {
   return cb;
 }
 
+static inline int link_fixed_words_dm(int64_t num_nodes, int cn_cap, int K) {
+  return 16 * words_for(num_nodes) + cn_cap + kMaxLevels + 4 * K + 32 + kHubWords;
+}
+static ClassBounds class_bounds_dm(int64_t num_nodes, int cn_cap, int K) {
+  static const int nominal[kNumClasses] = S3GRL_CLASS_BOUNDS;
+  const int avail = 163840 - 4 * link_fixed_words_dm(num_nodes, cn_cap, K);
+  ClassBounds cb;
+  for (int c = 0; c < kNumClasses; ++c) cb.b[c] = std::min(nominal[c], avail);
+  cb.b[kNumClasses - 1] = avail;
+  return cb;
+}
+
 // The hash flavour pays off when the bitmaps alone would hold a CU to a few workgroups.
 bool sparse_mode_for(const s3grl_graph* g) {
   if (getenv("S3GRL_FORCE_HASH")) return true;   // test hook
   if (getenv("S3GRL_NO_HASH")) return false;
   return 3 * (size_t)words_for(g->num_nodes) * 4 > 24 * 1024;
+}
+
+// The direct-map flavour: graphs whose 2N-byte map leaves most of a CU's LDS to the lists.
+static bool dm_mode_for(const s3grl_graph* g) {
+  if (sparse_mode_for(g) || getenv("S3GRL_NO_DM")) return false;
+  if (getenv("S3GRL_FORCE_DM")) return g->num_nodes <= 65535;   // test hook
+  return g->num_nodes <= 24576;
+}
+
+// Links of the small classes stay in the bitmap flavour where the map would cost resident wavefronts:
+// the largest class bound at which the direct-map flavour fits less than 4/5 of the waves the bitmap
+// flavour fits on a CU (PubMed, 39 KB of map: the class up to 6 KB; Cora, 5 KB: none).
+static int waves_per_cu(size_t lds) {
+  const int t = lds <= 40 * 1024 ? 256 : (lds <= 80 * 1024 ? 512 : 1024);
+  return std::min<int>(32, (int)(163840 / std::max<size_t>(lds, 1)) * (t / 64));
+}
+static int dm_min_need_for(const s3grl_graph* g, int cn_cap, int K) {
+  if (const char* e = getenv("S3GRL_DM_MIN_NEED")) return atoi(e);   // tuning hook
+  const ClassBounds bb = class_bounds(g->num_nodes, cn_cap, K), bd = class_bounds_dm(g->num_nodes, cn_cap, K);
+  int min_need = 0;
+  for (int c = 0; c < kNumClasses; ++c) {
+    if (bb.b[c] <= 0 || bd.b[c] <= 0) continue;
+    const int wb = waves_per_cu((size_t)4 * link_fixed_words(g->num_nodes, cn_cap, K) + bb.b[c]);
+    const int wd = waves_per_cu((size_t)4 * link_fixed_words_dm(g->num_nodes, cn_cap, K) + bd.b[c]);
+    if (5 * wd < 4 * wb) min_need = std::min(bb.b[c], bd.b[c]);   // measured: a loss of up to 1/5 is paid back
+  }
+  return min_need;
 }
 
 int num_class_lists() { return kNumLists; }
@@ -1309,9 +1382,10 @@ s3grl_status launch_count1(s3grl_context* ctx, const s3grl_graph* g, const int64
 s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_cap, int K,
                              const int32_t* n_nodes, const int32_t* p_nodes,
                              const int32_t* lvl_max, int64_t L, int32_t* class_count,
-                             int32_t* class_list, bool allow_hash, const int32_t* e_cap) {
+                             int32_t* class_list, bool allow_hash, const int32_t* e_cap, int stash_slot) {
   if (L == 0) return S3GRL_OK;
   ClassBounds cb = class_bounds(g->num_nodes, cn_cap, K);
+  const bool dm = allow_hash && stash_slot > 0 && dm_mode_for(g);
   if (cb.b[kNumClasses - 1] < 0) {
     // the N-bit bitmaps of the bitmap flavour do not fit: only the hash / one-hop classes exist
     if (!(allow_hash && sparse_mode_for(g))) {
@@ -1322,9 +1396,11 @@ s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_ca
     for (int c = 0; c < kNumClasses; ++c) cb.b[c] = -1;   // every link "overflows" them
   }
   hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream,
-                     n_nodes, p_nodes, lvl_max, L, cb, (allow_hash && sparse_mode_for(g)) ? 1 : 0,
-                     class_bounds_sparse(cn_cap, K), e_cap, class_bounds_full(cn_cap, K),
+                     n_nodes, p_nodes, lvl_max, L, cb, dm ? 2 : ((allow_hash && sparse_mode_for(g)) ? 1 : 0),
+                     dm ? class_bounds_dm(g->num_nodes, cn_cap, K) : class_bounds_sparse(cn_cap, K), e_cap,
+                     class_bounds_full(cn_cap, K),
                      getenv("S3GRL_FORCE_BM_HBM") ? 0 : (1 << 30),   // test hook: bit matrices in HBM
+                     dm ? std::min(stash_slot + 2, 65535) : 0, dm ? dm_min_need_for(g, cn_cap, K) : 0,
                      class_count, class_list);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
@@ -1388,18 +1464,21 @@ s3grl_status launch_full_class(s3grl_context* ctx, const LinkArgs& a, int64_t L,
   return S3GRL_OK;
 }
 
-template <int T, int K, int G, bool GS, bool HS>
+template <int T, int K, int G, bool GS, bool HS, bool DM = false>
 s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t L, int cls, int count,
                                  hipStream_t stream) {
   const int W = words_for(a.g->num_nodes);
   size_t lds;
-  if (HS)
+  if (DM)
+    lds = (size_t)4 * link_fixed_words_dm(a.g->num_nodes, a.cn_cap, K) +
+          class_bounds_dm(a.g->num_nodes, a.cn_cap, K).b[cls - kSparseBase];
+  else if (HS)
     lds = (size_t)4 * link_fixed_words_sparse(a.cn_cap, K) +
           class_bounds_sparse(a.cn_cap, K).b[cls - kSparseBase];
   else
     lds = (size_t)4 * link_fixed_words(a.g->num_nodes, a.cn_cap, K) +
           (GS ? 0 : (size_t)class_bounds(a.g->num_nodes, a.cn_cap, K).b[cls]);
-  auto kern = link_kernel<T, K, G, GS, HS>;
+  auto kern = link_kernel<T, K, G, GS, HS, DM>;
   S3GRL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(T), lds, stream, a.g->indptr,
@@ -1425,6 +1504,10 @@ s3grl_status launch_link_class(s3grl_context* ctx, const LinkArgs& a, int64_t L,
   if (cls == kNumClasses) {   // HBM-scratch overflow class
     if (gsel <= 4) return launch_link_class_g<1024, K, 4, true, false>(ctx, a, L, cls, count, stream);
     return launch_link_class_g<1024, K, 8, true, false>(ctx, a, L, cls, count, stream);
+  }
+  if (cls >= kSparseBase && dm_mode_for(a.g)) {   // direct-map flavour
+    if (gsel <= 4) return launch_link_class_g<T, K, 4, false, true, true>(ctx, a, L, cls, count, stream);
+    return launch_link_class_g<T, K, 8, false, true, true>(ctx, a, L, cls, count, stream);
   }
   if (cls >= kSparseBase) {   // hash flavour
     if (gsel <= 4) return launch_link_class_g<256, K, 4, false, true>(ctx, a, L, cls, count, stream);
@@ -1486,9 +1569,20 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
     else
       S3GRL_TRY((launch_full_class<1024, K, false>(ctx, a, L, c, count, next_stream(), nullptr, 0, count)));
   }
-  for (int c = kFullBase - 1; c >= kSparseBase; --c)
-    if (class_count_host[c] > 0)
+  for (int c = kFullBase - 1; c >= kSparseBase; --c) {
+    if (class_count_host[c] == 0) continue;
+    if (dm_mode_for(a.g)) {
+      static const int force_t = getenv("S3GRL_DM_T") ? atoi(getenv("S3GRL_DM_T")) : 0;   // tuning hook
+      const size_t lds = (size_t)4 * link_fixed_words_dm(a.g->num_nodes, a.cn_cap, K) +
+                         class_bounds_dm(a.g->num_nodes, a.cn_cap, K).b[c - kSparseBase];
+      const int t = force_t ? force_t : (lds <= 40 * 1024 ? 256 : (lds <= 80 * 1024 ? 512 : 1024));
+      if (t <= 256) S3GRL_TRY((launch_link_class<256, K>(ctx, a, L, c, class_count_host[c], next_stream())));
+      else if (t <= 512) S3GRL_TRY((launch_link_class<512, K>(ctx, a, L, c, class_count_host[c], next_stream())));
+      else S3GRL_TRY((launch_link_class<1024, K>(ctx, a, L, c, class_count_host[c], next_stream())));
+    } else {
       S3GRL_TRY((launch_link_class<256, K>(ctx, a, L, c, class_count_host[c], next_stream())));
+    }
+  }
   for (int c = kNumClasses - 1; c >= 0; --c) {
     const int count = class_count_host[c];
     if (count == 0) continue;

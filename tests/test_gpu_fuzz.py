@@ -74,6 +74,8 @@ def test_random_configuration(eng, monkeypatch, case):
         monkeypatch.setenv("S3GRL_LDS_BUDGET", "3072")                 # pushes links into the HBM-scratch class
     if case % 7 == 3:
         monkeypatch.setenv("S3GRL_STASH_SLOT", "16")                   # most lists overflow their slot
+    if case % 6 == 4:
+        monkeypatch.setenv("S3GRL_NO_DM", "1")                         # bitmap flavour instead of the direct map
     G = eng.graph(A)
     f = eng.features(X, ["auto", "dense", "packed"][case % 3])
     res = eng.precompute(G, f, eng.links(links.T), mode="pos_plus" if plus else "pos", num_hops=hops, sign_k=K)

@@ -1076,6 +1076,37 @@ def test_packed_gather_on_tiny_subgraphs(eng, name, K):
     G.close()
 
 
+
+@pytest.mark.parametrize("name,hops", [("rand300", 2), ("cora", 3), ("usair", 1)])
+@pytest.mark.parametrize("mode", ["pos", "pos_plus"])
+def test_direct_map_flavour_equals_bitmap_flavour(eng, monkeypatch, name, hops, mode):
+    """Small graphs keep the visited set as a direct map (one uint16 per graph node = list position);
+    S3GRL_NO_DM sends the same links through the three-bitmap flavour.  Same rows walked by the same
+    lanes in the same order: every output is equal bit for bit, statistics included."""
+    import torch
+
+    g = load_extract(name)
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = np.random.default_rng(77).standard_normal((n, 21))
+    links = np.concatenate([g["links"], g["links"][:4, ::-1]])
+    G = eng.graph(A)
+    f = eng.features(X)
+    L = eng.links(links.T)
+    for K in (1, 3, 5):
+        monkeypatch.delenv("S3GRL_NO_DM", raising=False)
+        a = eng.precompute(G, f, L, mode=mode, num_hops=hops, sign_k=K)
+        a = (a.rows.clone(), a.row_ptr.clone(), a.row_nodes.clone(), dict(a.stats))
+        monkeypatch.setenv("S3GRL_NO_DM", "1")
+        b = eng.precompute(G, f, L, mode=mode, num_hops=hops, sign_k=K)
+        assert torch.equal(a[0], b.rows) and torch.equal(a[1], b.row_ptr) and torch.equal(a[2], b.row_nodes)
+        sa, sb = a[3], dict(b.stats)
+        sa.pop("workspace_bytes", None), sb.pop("workspace_bytes", None)
+        assert sa == sb
+    monkeypatch.delenv("S3GRL_NO_DM", raising=False)
+    G.close()
+
+
 @pytest.mark.parametrize("flavour", ["bitmap", "hash"])
 def test_node_list_handover_and_its_fallback(eng, monkeypatch, flavour):
     """count_kernel hands every link's node list to link_kernel through an HBM slot; a list longer
