@@ -458,7 +458,7 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
                                 const int32_t* __restrict__ p_nodes,
                                 const int32_t* __restrict__ lvl_max, int64_t L, ClassBounds bound,
                                 int sparse_mode, ClassBounds sbound, const int32_t* __restrict__ e_cap,
-                                ClassBounds fbound, int bm_limit, int dm_max_n, int dm_min_need,
+                                ClassBounds fbound, int bm_limit, int dm_max_n, int dm_class_mask,
                                 int32_t* __restrict__ class_count, int32_t* __restrict__ class_list) {
   const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int n = l < L ? n_nodes[l] : 0;
@@ -483,13 +483,15 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
       atomicMax(&class_count[30], need_b);   // and its LDS
     }
   }
-  if (!sparse && sparse_mode == 2 && n > 0 && n <= dm_max_n && need > dm_min_need) {
-    // direct-map flavour: sbound = what the map leaves of the LDS; the list must be in the stash
-    if (need <= sbound.b[kNumClasses - 1]) {
-      sparse = true;
+  if (!sparse && sparse_mode == 2 && n > 0 && n <= dm_max_n && need <= sbound.b[kNumClasses - 1]) {
+    // direct-map flavour: sbound = what the map leaves of the LDS; the list must be in the stash;
+    // class by class where the host found the map to pay (dm_class_mask)
+    int k_dm = 0;
 #pragma unroll
-      for (int k = 0; k < kNumClasses; ++k) c += need > sbound.b[k] ? 1 : 0;
-      c += kSparseBase;
+    for (int k = 0; k < kNumClasses; ++k) k_dm += need > sbound.b[k] ? 1 : 0;
+    if ((dm_class_mask >> k_dm) & 1) {
+      sparse = true;
+      c = k_dm + kSparseBase;
     }
   }
   if (!sparse && sparse_mode == 1 && n > 0 && lvl_max[l] <= kSparseLevelMax) {
@@ -1249,10 +1251,28 @@ static inline int link_fixed_words_sparse(int cn_cap, int K) {
   return cn_cap + kMaxLevels + 4 * K + 32 + kHubWords;
 }
 
+// nominal class bounds (S3GRL_BOUNDS = "b0,b1,..." is a tuning hook)
+static const int* nominal_bounds() {
+  static int b[kNumClasses] = S3GRL_CLASS_BOUNDS;
+  static bool parsed = false;
+  if (!parsed) {
+    parsed = true;
+    if (const char* e = getenv("S3GRL_BOUNDS")) {
+      int k = 0;
+      for (const char* q = e; *q && k < kNumClasses; ++k) {
+        b[k] = atoi(q);
+        while (*q && *q != ',') ++q;
+        if (*q == ',') ++q;
+      }
+    }
+  }
+  return b;
+}
+
 // class c holds the links whose variable LDS need is <= bound[c] bytes; the last bound is
 // whatever the 160 KiB of a CU leave after the fixed part
 static ClassBounds class_bounds(int64_t num_nodes, int cn_cap, int K) {
-  static const int nominal[kNumClasses] = S3GRL_CLASS_BOUNDS;
+  const int* nominal = nominal_bounds();
   int avail = 163840 - 4 * link_fixed_words(num_nodes, cn_cap, K);
   if (const char* e = getenv("S3GRL_LDS_BUDGET")) avail = std::min(avail, atoi(e));  // test hook
   ClassBounds cb;
@@ -1278,11 +1298,22 @@ static ClassBounds class_bounds_full(int cn_cap, int K) {
   return cb;
 }
 
+// threads per link of an LDS class (S3GRL_T_CLASS<c> = tuning hook)
+static int threads_for_class(size_t lds, int c) {
+  char name[32];
+  snprintf(name, sizeof(name), "S3GRL_T_CLASS%d", c);
+  if (const char* e = getenv(name)) return atoi(e);
+  // the smallest subgraphs (a few hundred nodes at most): two wavefronts per link — the uniform part
+  // of the kernel is most of their cost, and ten such links fit a CU either way
+  if (c == 0 && lds <= 40 * 1024) return 128;
+  return lds <= 40 * 1024 ? 256 : (lds <= 80 * 1024 ? 512 : 1024);
+}
+
 static inline int link_fixed_words_dm(int64_t num_nodes, int cn_cap, int K) {
   return 16 * words_for(num_nodes) + cn_cap + kMaxLevels + 4 * K + 32 + kHubWords;
 }
 static ClassBounds class_bounds_dm(int64_t num_nodes, int cn_cap, int K) {
-  static const int nominal[kNumClasses] = S3GRL_CLASS_BOUNDS;
+  const int* nominal = nominal_bounds();
   const int avail = 163840 - 4 * link_fixed_words_dm(num_nodes, cn_cap, K);
   ClassBounds cb;
   for (int c = 0; c < kNumClasses; ++c) cb.b[c] = std::min(nominal[c], avail);
@@ -1304,24 +1335,28 @@ static bool dm_mode_for(const s3grl_graph* g) {
   return g->num_nodes <= 24576;
 }
 
-// Links of the small classes stay in the bitmap flavour where the map would cost resident wavefronts:
-// the largest class bound at which the direct-map flavour fits less than 4/5 of the waves the bitmap
-// flavour fits on a CU (PubMed, 39 KB of map: the class up to 6 KB; Cora, 5 KB: none).
-static int waves_per_cu(size_t lds) {
-  const int t = lds <= 40 * 1024 ? 256 : (lds <= 80 * 1024 ? 512 : 1024);
-  return std::min<int>(32, (int)(163840 / std::max<size_t>(lds, 1)) * (t / 64));
+// The map costs LDS, i.e. resident wavefronts: class by class, the direct-map flavour is used where
+// it fits at least 4/5 of the waves the bitmap flavour fits on a CU (measured: a loss of up to 1/5
+// is paid back by the cheaper visits; PubMed, 39 KB of map: every class but the smallest).
+static int waves_per_cu(size_t lds, int c) {
+  return std::min<int>(32, (int)(163840 / std::max<size_t>(lds, 1)) * (threads_for_class(lds, c) / 64));
 }
-static int dm_min_need_for(const s3grl_graph* g, int cn_cap, int K) {
-  if (const char* e = getenv("S3GRL_DM_MIN_NEED")) return atoi(e);   // tuning hook
+static int dm_class_mask_for(const s3grl_graph* g, int cn_cap, int K) {
+  if (const char* e = getenv("S3GRL_DM_CLASS_MASK")) return atoi(e);   // tuning hook
   const ClassBounds bb = class_bounds(g->num_nodes, cn_cap, K), bd = class_bounds_dm(g->num_nodes, cn_cap, K);
-  int min_need = 0;
+  int mask = 0;
   for (int c = 0; c < kNumClasses; ++c) {
-    if (bb.b[c] <= 0 || bd.b[c] <= 0) continue;
-    const int wb = waves_per_cu((size_t)4 * link_fixed_words(g->num_nodes, cn_cap, K) + bb.b[c]);
-    const int wd = waves_per_cu((size_t)4 * link_fixed_words_dm(g->num_nodes, cn_cap, K) + bd.b[c]);
-    if (5 * wd < 4 * wb) min_need = std::min(bb.b[c], bd.b[c]);   // measured: a loss of up to 1/5 is paid back
+    if (bd.b[c] <= 0) continue;
+    if (bb.b[c] <= 0) { mask |= 1 << c; continue; }
+    const int wb = waves_per_cu((size_t)4 * link_fixed_words(g->num_nodes, cn_cap, K) + bb.b[c], c);
+    const int wd = waves_per_cu((size_t)4 * link_fixed_words_dm(g->num_nodes, cn_cap, K) + bd.b[c], c);
+    // the smallest class is bound by links in flight, not by waves: at least half as many must fit
+    const size_t lb = (size_t)4 * link_fixed_words(g->num_nodes, cn_cap, K) + bb.b[c];
+    const size_t ld = (size_t)4 * link_fixed_words_dm(g->num_nodes, cn_cap, K) + bd.b[c];
+    if (c == 0 && 2 * std::min<size_t>(163840 / ld, 16) < std::min<size_t>(163840 / lb, 16)) continue;
+    if (5 * wd >= 4 * wb) mask |= 1 << c;
   }
-  return min_need;
+  return mask;
 }
 
 int num_class_lists() { return kNumLists; }
@@ -1400,7 +1435,7 @@ s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_ca
                      dm ? class_bounds_dm(g->num_nodes, cn_cap, K) : class_bounds_sparse(cn_cap, K), e_cap,
                      class_bounds_full(cn_cap, K),
                      getenv("S3GRL_FORCE_BM_HBM") ? 0 : (1 << 30),   // test hook: bit matrices in HBM
-                     dm ? std::min(stash_slot + 2, 65535) : 0, dm ? dm_min_need_for(g, cn_cap, K) : 0,
+                     dm ? std::min(stash_slot + 2, 65535) : 0, dm ? dm_class_mask_for(g, cn_cap, K) : 0,
                      class_count, class_list);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
@@ -1572,11 +1607,12 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
   for (int c = kFullBase - 1; c >= kSparseBase; --c) {
     if (class_count_host[c] == 0) continue;
     if (dm_mode_for(a.g)) {
-      static const int force_t = getenv("S3GRL_DM_T") ? atoi(getenv("S3GRL_DM_T")) : 0;   // tuning hook
       const size_t lds = (size_t)4 * link_fixed_words_dm(a.g->num_nodes, a.cn_cap, K) +
                          class_bounds_dm(a.g->num_nodes, a.cn_cap, K).b[c - kSparseBase];
-      const int t = force_t ? force_t : (lds <= 40 * 1024 ? 256 : (lds <= 80 * 1024 ? 512 : 1024));
-      if (t <= 256) S3GRL_TRY((launch_link_class<256, K>(ctx, a, L, c, class_count_host[c], next_stream())));
+      const int t = threads_for_class(lds, c - kSparseBase);
+      if (t <= 64) S3GRL_TRY((launch_link_class<64, K>(ctx, a, L, c, class_count_host[c], next_stream())));
+      else if (t <= 128) S3GRL_TRY((launch_link_class<128, K>(ctx, a, L, c, class_count_host[c], next_stream())));
+      else if (t <= 256) S3GRL_TRY((launch_link_class<256, K>(ctx, a, L, c, class_count_host[c], next_stream())));
       else if (t <= 512) S3GRL_TRY((launch_link_class<512, K>(ctx, a, L, c, class_count_host[c], next_stream())));
       else S3GRL_TRY((launch_link_class<1024, K>(ctx, a, L, c, class_count_host[c], next_stream())));
     } else {
@@ -1590,8 +1626,11 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
     // graph whose three N-bit bitmaps alone take tens of KB): give each more waves then.
     const size_t lds = (size_t)4 * link_fixed_words(a.g->num_nodes, a.cn_cap, K) +
                        class_bounds(a.g->num_nodes, a.cn_cap, K).b[c];
-    if (lds <= 40 * 1024) S3GRL_TRY((launch_link_class<256, K>(ctx, a, L, c, count, next_stream())));
-    else if (lds <= 80 * 1024) S3GRL_TRY((launch_link_class<512, K>(ctx, a, L, c, count, next_stream())));
+    const int t = threads_for_class(lds, c);
+    if (t <= 64) S3GRL_TRY((launch_link_class<64, K>(ctx, a, L, c, count, next_stream())));
+    else if (t <= 128) S3GRL_TRY((launch_link_class<128, K>(ctx, a, L, c, count, next_stream())));
+    else if (t <= 256) S3GRL_TRY((launch_link_class<256, K>(ctx, a, L, c, count, next_stream())));
+    else if (t <= 512) S3GRL_TRY((launch_link_class<512, K>(ctx, a, L, c, count, next_stream())));
     else S3GRL_TRY((launch_link_class<1024, K>(ctx, a, L, c, count, next_stream())));
   }
   if (fork)
