@@ -298,6 +298,13 @@ s3grl_status s3grl_graph_create(s3grl_context* ctx, int64_t num_nodes, const int
       return st;
     }
   }
+  if (num_nodes <= kMaxNodesLds) {   // the graphs the multi-hop kernels take: their degree order
+    const s3grl_status st = build_degree_order(ctx, g);
+    if (st != S3GRL_OK) {
+      s3grl_graph_destroy(g);
+      return st;
+    }
+  }
   *out = g;
   return S3GRL_OK;
 }
@@ -309,6 +316,10 @@ s3grl_status s3grl_graph_destroy(s3grl_graph* g) {
   g->ctx->arena.release(g->fwd_indptr);
   g->ctx->arena.release(g->fwd_indices);
   g->ctx->arena.release(g->fwd_deg);
+  g->ctx->arena.release(g->r_indptr);
+  g->ctx->arena.release(g->r_indices);
+  g->ctx->arena.release(g->new_of_old);
+  g->ctx->arena.release(g->old_of_new);
   delete g;
   return S3GRL_OK;
 }
@@ -450,6 +461,21 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   while (slot > 256 && (int64_t)L * slot * 4 > ((int64_t)6 << 30)) slot >>= 1;
   if (!onehop && slot > 0 && (int64_t)L * slot * 4 <= ((int64_t)6 << 30))
     S3GRL_TRY(arena_alloc(ctx, (size_t)L * slot, &stash, tr));
+  // Plain multi-hop plans walk the graph in its degree order (s3grl_relabel.hip): links translated
+  // on the way in, everything the plan hands out translated back by link_kernel.  Sampled and
+  // random-walk plans draw by the caller's ids and stay on the original order.
+  const bool relabel = !onehop && rw_len == 0 && !sampling && g->r_indptr && !getenv("S3GRL_NO_RELABEL");
+  s3grl_graph g_walk = *g;   // what count_kernel / link_kernel see
+  const int64_t* links_walk = plan->links;
+  if (relabel) {
+    g_walk.indptr = g->r_indptr;
+    g_walk.indices = g->r_indices;
+    int64_t* lr = nullptr;
+    S3GRL_TRY(arena_alloc(ctx, (size_t)std::max<int64_t>(2 * L, 1), &lr, tr));
+    S3GRL_TRY(launch_translate_links(ctx, g, plan->links, L, lr));
+    links_walk = lr;
+  }
+  plan->relabelled = relabel;
   int32_t* e_cap = nullptr;
   if (onehop) {
     S3GRL_TRY(arena_alloc(ctx, (size_t)L, &e_cap, own));
@@ -462,7 +488,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
                      std::to_string(kMaxNodesLds) + " of multi-hop / sampled / random-walk plans");
       return S3GRL_ERR_GRAPH_TOO_LARGE;
     }
-    S3GRL_TRY(launch_count(ctx, g, plan->links, L, cfg->num_hops, plus ? 1 : 0, K, rw_raw, rw_len,
+    S3GRL_TRY(launch_count(ctx, &g_walk, links_walk, L, cfg->num_hops, plus ? 1 : 0, K, rw_raw, rw_len,
                            partner, mirror_of,
                            plan->n_nodes, p_nodes, n_rows, n_jobs, lvl_max,
                            reinterpret_cast<int32_t*>(ds), st + 3 * kStatRow, smp, stash, slot, plan->lvl));
@@ -497,7 +523,8 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   }
   const int64_t max_n = hs[1], max_R = hs[5];
   const int64_t tot_n = hs[16], tot_rows = hs[17], njobs = hs[18];
-  const int cn_cap = (int)std::max<int64_t>(max_R - 2, 0) + 1;
+  // (a relabelled PoS Plus plan sorts its common neighbours by the caller's ids inside cn[]: 3x)
+  const int cn_cap = ((int)std::max<int64_t>(max_R - 2, 0) + 1) * ((relabel && plus) ? 3 : 1);
   if (plus) {
     S3GRL_TRY(launch_classify(ctx, g, cn_cap, K, plan->n_nodes, p_nodes, lvl_max, L, class_count,
                               class_list, !sampling, e_cap, stash ? slot : 0));
@@ -569,12 +596,14 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   S3GRL_TRY(arena_alloc(ctx, (size_t)std::max<int64_t>(njobs * K, 1), &plan->job_lim, own));
   S3GRL_TRY(arena_alloc(ctx, (size_t)tot_rows, &plan->row_nodes, own));
   S3GRL_TRY(record(ctx, 1));
-  S3GRL_TRY(launch_links(ctx, g, plan->links, L, class_list, class_count_host, cfg->num_hops,
+  S3GRL_TRY(launch_links(ctx, onehop ? g : &g_walk, onehop ? plan->links : links_walk, L, class_list,
+                         class_count_host, cfg->num_hops,
                          plus ? 1 : 0, cn_cap, (cfg->flags & S3GRL_FLAG_FULL_STATS) ? 1 : 0, K, rw_raw, rw_len, p_nodes,
                          plan->node_off,
                          plan->row_ptr, plan->job_off, coef_off, mirror_of, plan->c_ids,
                          plan->c_coef, plan->jobs, plan->job_z, plan->job_lim, plan->row_nodes, plan->lvl, st,
-                         st + kStatRow, st + 2 * kStatRow, smp, stash, slot, e_cap, max_n));
+                         st + kStatRow, st + 2 * kStatRow, smp, stash, slot, e_cap, max_n,
+                         relabel ? g->old_of_new : nullptr, relabel ? g->new_of_old : nullptr));
   S3GRL_TRY(record(ctx, 2));
   S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_stats, st, 3 * kStatRow * sizeof(int64_t), hipMemcpyDeviceToHost,
                                ctx->stream));
@@ -675,6 +704,8 @@ s3grl_status s3grl_plan_export_subgraphs(const s3grl_plan* p, int64_t* node_ptr,
     return S3GRL_ERR_INVALID_ARGUMENT;
   }
   if (nodes && n) S3GRL_HIP_TRY(hipMemcpyAsync(nodes, p->c_ids, n * 4, hipMemcpyDeviceToDevice, st));
+  // the lists of a plan that walked the degree order are hop-major but not ascending inside a hop
+  if (nodes && n && p->relabelled) S3GRL_TRY(launch_sort_hops(p->ctx, p, nodes));
   if (dists && n) S3GRL_TRY(launch_dists(p->ctx, p->node_off, p->lvl, p->L, dists));
   return S3GRL_OK;
 }

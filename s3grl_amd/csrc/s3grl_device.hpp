@@ -162,13 +162,29 @@ __device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      // longer rows: two neighbours per lane in flight per trip
-      for (int c = c0[u] + 2 * G; c < e1[u]; c += 2 * G) {
-        const bool vb = c + G < e1[u];
-        const int ua = indices[(uint32_t)c];
-        const int ub = indices[(uint32_t)(vb ? c + G : c)];
-        visit(acc[u], v[u], ua, true);
-        visit(acc[u], v[u], ub, vb);
+      // longer rows: two neighbours per lane and step, and the pair of the NEXT step already in
+      // flight while this one is visited — a step is a dependent global load, and the longest row of
+      // the wavefront sets the length of the trip (same visits in the same order as a plain loop)
+      int c = c0[u] + 2 * G;
+      if (c < e1[u]) {
+        int ua = indices[(uint32_t)c];
+        int ub = indices[(uint32_t)(c + G < e1[u] ? c + G : c)];
+        for (;;) {
+          const int cn = c + 2 * G;
+          const bool more = cn < e1[u];
+          uint32_t an = (uint32_t)(more ? cn : c), bn = (uint32_t)(more && cn + G < e1[u] ? cn + G : c);
+          // opaque to the optimiser: it would otherwise prove (read-only memory) that loading the next
+          // pair here equals loading it at the top of the next step, and undo the pipelining
+          asm volatile("" : "+v"(an), "+v"(bn));
+          const int na = indices[an];
+          const int nb = indices[bn];
+          visit(acc[u], v[u], ua, true);
+          visit(acc[u], v[u], ub, c + G < e1[u]);
+          if (!more) break;
+          c = cn;
+          ua = na;
+          ub = nb;
+        }
       }
     }
     // The xor tree leaves the row total in EVERY lane of the group, so lane u of a group can

@@ -120,6 +120,12 @@ struct s3grl_graph {
   int32_t* fwd_indptr = nullptr;   // [N+1]
   int32_t* fwd_indices = nullptr;  // [nnz / 2 (+ self-loops)]
   uint16_t* fwd_deg = nullptr;     // [N] length of the oriented rows, for the sizing pass
+  // the same graph with ids in descending degree order (s3grl_relabel.hip): what the multi-hop
+  // kernels walk; null when the graph is beyond their reach
+  int32_t* r_indptr = nullptr;     // [N+1]
+  int32_t* r_indices = nullptr;    // [nnz], rows ascending in the new ids
+  int32_t* new_of_old = nullptr;   // [N]
+  int32_t* old_of_new = nullptr;   // [N]
 };
 
 struct s3grl_plan {
@@ -136,7 +142,8 @@ struct s3grl_plan {
   int64_t* job_off = nullptr;    // [L+1]
   int32_t* lvl = nullptr;        // [L, kMaxLevels] cumulative node count per BFS level
   int32_t* e_cap = nullptr;      // [L] bound of the induced entries (one-hop plans on big graphs), else null
-  int32_t* c_ids = nullptr;      // [Σn] subgraph nodes, hop-major, ascending id inside a hop
+  bool relabelled = false;       // the kernels walked the graph's degree order (s3grl_relabel.hip)
+  int32_t* c_ids = nullptr;      // [Σn] subgraph nodes, hop-major (ascending id inside a hop unless relabelled)
   // per job (row pair)
   s3grl::Job* jobs = nullptr;    // [njobs]
   int64_t njobs = 0;
@@ -196,6 +203,12 @@ struct Transient {  // released on scope exit (stream-ordered reuse is safe: one
   }
 };
 
+// relabel.hip
+s3grl_status build_degree_order(s3grl_context* ctx, s3grl_graph* g);
+s3grl_status launch_translate_links(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
+                                    int64_t* out);
+s3grl_status launch_sort_hops(s3grl_context* ctx, const s3grl_plan* p, int32_t* nodes);
+
 // structure.hip
 s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                           int hops, int plus, int K, const int32_t* rw_raw, int rw_len,
@@ -242,7 +255,8 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           int32_t* lvl,
                           int64_t* tot_edges, int64_t* tot_support, int64_t* tot_vol,
                           HopSampling smp = HopSampling{1.0, 0, 0}, const int32_t* stash = nullptr,
-                          int slot = 0, const int32_t* e_cap = nullptr, int64_t max_nodes = 0);
+                          int slot = 0, const int32_t* e_cap = nullptr, int64_t max_nodes = 0,
+                          const int32_t* old_of_new = nullptr, const int32_t* new_of_old = nullptr);
 s3grl_status launch_dists(s3grl_context* ctx, const int64_t* node_off, const int32_t* lvl, int64_t L,
                           int8_t* dists);
 // gather.hip

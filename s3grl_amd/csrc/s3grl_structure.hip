@@ -561,8 +561,11 @@ __global__ __launch_bounds__(T) void link_kernel(
     int32_t* __restrict__ lvl_out, unsigned long long* __restrict__ tot_edges,
     unsigned long long* __restrict__ tot_support, unsigned long long* __restrict__ tot_vol,
     char* __restrict__ scratch, int64_t scratch_stride, unsigned long long* __restrict__ dbg,
-    HopSampling smp, const int32_t* __restrict__ stash, int slot) {
+    HopSampling smp, const int32_t* __restrict__ stash, int slot,
+    const int32_t* __restrict__ old_of_new, const int32_t* __restrict__ new_of_old) {
   extern __shared__ uint32_t smem[];
+  // the caller's id of an internal id (the graph is walked in its degree order, s3grl_relabel.hip)
+  auto ext = [&](int v) -> int { return old_of_new ? old_of_new[v] : v; };
   // diagnostic only (S3GRL_DEBUG_STAMPS): cycles per phase, summed over workgroups; the extra
   // barriers change the timing of the build they run in — read shares, not totals
   unsigned long long t_prev = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -697,10 +700,31 @@ __global__ __launch_bounds__(T) void link_kernel(
   int vol_local = 0;   // vol(S) = Σ global degrees, the 4·vol(S) term of the algorithmic bytes
   for (int t = tid; t < n; t += T) {
     const int v = list[t];
-    c_ids[noff + t] = v;
+    c_ids[noff + t] = ext(v);
     vol_local += indptr[v + 1] - indptr[v];
   }
-  if (plus && wave_id() == 0) common_neighbours(indptr, indices, in_s, src, dst, cn);
+  if (plus && wave_id() == 0) {
+    const int c = common_neighbours(indptr, indices, in_s, src, dst, cn);
+    if (old_of_new && c > 1) {
+      // the common-neighbour rows go out in ascending order of the CALLER's ids: rank sort by one
+      // wavefront; the host sized cn[] three times over for it (keys and the sorted copy behind the list)
+      int* key = cn + c;
+      int* tmp = cn + 2 * c;
+      const int lane = lane_id();
+      for (int i = lane; i < c; i += 64) key[i] = old_of_new[cn[i]];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      for (int i = lane; i < c; i += 64) {
+        const int k = key[i];
+        int r = 0;
+        for (int j = 0; j < c; ++j) r += key[j] < k ? 1 : 0;
+        tmp[r] = cn[i];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      for (int i = lane; i < c; i += 64) cn[i] = tmp[i];
+    }
+  }
   __syncthreads();
   if constexpr (!HS) rank_prefix<T>(inP, wpreP, W, sh);
   __syncthreads();
@@ -708,8 +732,8 @@ __global__ __launch_bounds__(T) void link_kernel(
     for (int d = 0; d < kMaxLevels; ++d)
       lvl_out[(int64_t)l * kMaxLevels + d] = d < nlev ? lvl_end[d] : n;
   for (int r = tid; r < R; r += T) {
-    row_nodes[rp + r] = r == 0 ? src : (r == 1 ? dst : cn[r - 2]);
-    if (mirror >= 0) row_nodes[mrp + r] = r == 0 ? dst : (r == 1 ? src : cn[r - 2]);
+    row_nodes[rp + r] = ext(r == 0 ? src : (r == 1 ? dst : cn[r - 2]));
+    if (mirror >= 0) row_nodes[mrp + r] = ext(r == 0 ? dst : (r == 1 ? src : cn[r - 2]));
   }
 
   S3GRL_STAMP(1)
@@ -1018,8 +1042,8 @@ __global__ __launch_bounds__(T) void link_kernel(
       j.out_row = rp + 2 * pr;
       j.link = l;
       j.support = support;
-      j.node_a = node_a;
-      j.node_b = node_b;
+      j.node_a = ext(node_a);
+      j.node_b = node_b >= 0 ? ext(node_b) : -1;
       j.z_a = (node_a == src || node_a == dst) ? 1 : 0;
       j.z_b = (node_b == src || node_b == dst) ? 1 : 0;
       j.mirror_row = mirror >= 0 ? mrp + 2 * pr : -1;
@@ -1472,6 +1496,7 @@ struct LinkArgs {
   int64_t bm_stride_words;
   int bm_grid;
   int big_need;   // LDS need of the biggest link of the class whose matrix / columns sit in HBM
+  const int32_t *old_of_new, *new_of_old;   // non-null: the graph is walked in its degree order
 };
 
 // One-hop full-reach classes (link_full_kernel).  Small classes run one wavefront per link (no
@@ -1524,7 +1549,7 @@ s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t 
                      reinterpret_cast<unsigned long long*>(a.tot_edges),
                      reinterpret_cast<unsigned long long*>(a.tot_support),
                      reinterpret_cast<unsigned long long*>(a.tot_vol), a.scratch, a.scratch_stride,
-                     a.dbg, a.smp, a.stash, a.slot);
+                     a.dbg, a.smp, a.stash, a.slot, a.old_of_new, a.new_of_old);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -1566,8 +1591,12 @@ static s3grl_status side_streams(s3grl_context* ctx) {
 
 template <int K>
 s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
-                            const int32_t* class_count_host) {
+                            const int32_t* class_count_in) {
   static const bool serial = getenv("S3GRL_SERIAL_CLASSES") != nullptr;
+  // diagnostic only (with S3GRL_DEBUG_STAMPS): launch one class list, the results are incomplete
+  static const int only = getenv("S3GRL_ONLY_CLASS") ? atoi(getenv("S3GRL_ONLY_CLASS")) : -1;
+  int32_t class_count_host[32];
+  for (int c = 0; c < 32; ++c) class_count_host[c] = (only < 0 || c == only || c >= kNumLists) ? class_count_in[c] : 0;
   int launches = 0;
   for (int c = 0; c < kNumLists; ++c) launches += class_count_host[c] > 0 && c != kNumClasses + 1;
   const bool fork = !serial && launches > 1;
@@ -1653,7 +1682,7 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           int32_t* lvl,
                           int64_t* tot_edges, int64_t* tot_support, int64_t* tot_vol,
                           HopSampling smp, const int32_t* stash, int slot, const int32_t* e_cap,
-                          int64_t max_nodes) {
+                          int64_t max_nodes, const int32_t* old_of_new, const int32_t* new_of_old) {
   if (L == 0) return S3GRL_OK;
   // links too large for LDS keep their lists in HBM scratch: one 256-byte aligned slice each
   Transient scratch_owner{ctx, {}};
@@ -1671,7 +1700,7 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
              job_off, coef_off, mirror_of, c_ids, c_coef, jobs, job_z, job_lim, row_nodes, lvl, tot_edges,
              tot_support, tot_vol, scratch, scratch_stride,
              getenv("S3GRL_DEBUG_STAMPS") ? reinterpret_cast<unsigned long long*>(ctx->d_scalars + 16) : nullptr,
-             smp, stash, slot, e_cap, nullptr, 0, 0, 0};
+             smp, stash, slot, e_cap, nullptr, 0, 0, 0, old_of_new, new_of_old};
   // the class whose bit matrix does not fit LDS: one slice per resident workgroup of a persistent grid
   if (class_count_host[kFullBig] > 0) {
     // slice = list of found edges (uint32, at most ecap / 2) + CSR columns (uint16 x ecap) of the

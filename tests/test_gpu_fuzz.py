@@ -74,6 +74,8 @@ def test_random_configuration(eng, monkeypatch, case):
         monkeypatch.setenv("S3GRL_LDS_BUDGET", "3072")                 # pushes links into the HBM-scratch class
     if case % 7 == 3:
         monkeypatch.setenv("S3GRL_STASH_SLOT", "16")                   # most lists overflow their slot
+    if case % 4 == 3:
+        monkeypatch.setenv("S3GRL_NO_RELABEL", "1")                    # the caller's node order instead of the degree order
     if case % 6 == 4:
         monkeypatch.setenv("S3GRL_NO_DM", "1")                         # bitmap flavour instead of the direct map
     G = eng.graph(A)

@@ -62,7 +62,8 @@ def test_onehop_path_equals_bitmap_flavour(eng, monkeypatch, name, K, bm_hbm):
         s0, s1 = dict(p0.stats), dict(p1.stats)
         s0.pop("workspace_bytes"), s1.pop("workspace_bytes")
         assert s0 == s1                                   # n, vol(S), induced edges, support: exact
-        assert rel_err(r1.cpu().numpy(), r0.cpu().numpy()) < 1e-6
+        # two summation orders of the same fp32 sums (the multi-hop path walks the degree order)
+        assert rel_err(r1.cpu().numpy(), r0.cpu().numpy()) < 3e-6
         # bit-reproducible against itself
         r1b = p1.run(f)
         assert torch.equal(r1, r1b)

@@ -122,7 +122,11 @@ def test_feature_widths(eng, F):
     n = int(g["num_nodes"])
     A = csr_from_undirected(n, g["edges"])
     rng = np.random.default_rng(F)
-    X = rng.standard_normal((n, F))
+    X = rng.standard_normal((n, F)).astype(np.float32).astype(np.float64)   # what the engine holds, exactly
+    if F == 1:
+        # one column: the row norm the tolerance scales with IS the element, and a sum of signed terms
+        # that cancels has no 1e-5 bar in fp32 under any summation order — keep the terms one-signed
+        X = np.abs(X)
     links = g["links"][:12].T
     kw = {"sign_k": 3, "k_node_set_strategy": "intersection"}
     G = eng.graph(A)
@@ -1075,6 +1079,46 @@ def test_packed_gather_on_tiny_subgraphs(eng, name, K):
             assert rel_err(res.rows.cpu().numpy(), ref) < TOL, (name, K, h, mode)
     G.close()
 
+
+
+@pytest.mark.parametrize("name,hops", [("rand300", 2), ("cora", 3), ("usair", 2), ("star_iso", 2)])
+@pytest.mark.parametrize("mode", ["pos", "pos_plus"])
+def test_degree_order_is_invisible(eng, monkeypatch, name, hops, mode):
+    """Plain multi-hop plans walk the graph with its ids in descending degree order
+    (csrc/s3grl_relabel.hip); S3GRL_NO_RELABEL walks the caller's order.  Everything a plan hands out
+    is in the caller's ids either way: row pointers, row nodes (common-neighbour rows ascending),
+    exported node lists (hop-major, ascending inside a hop), distances and statistics are equal
+    exactly, the rows to fp32 round-off (another summation order)."""
+    import torch
+
+    g = load_extract(name)
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = np.random.default_rng(5).standard_normal((n, 33))
+    links = np.concatenate([g["links"], g["links"][:4, ::-1]])
+    G = eng.graph(A)
+    f = eng.features(X)
+    L = eng.links(links.T)
+    out = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("S3GRL_NO_RELABEL", "1")
+        else:
+            monkeypatch.delenv("S3GRL_NO_RELABEL", raising=False)
+        plan = eng.plan(G, L, mode=mode, num_hops=hops, sign_k=3, full_stats=True)
+        exp = [t.clone() for t in plan.export_subgraphs()]
+        st = dict(plan.stats)
+        st.pop("workspace_bytes", None)
+        plan.close()
+        res = eng.precompute(G, f, L, mode=mode, num_hops=hops, sign_k=3)
+        out.append((exp, st, res.rows.clone(), res.row_ptr.clone(), res.row_nodes.clone()))
+    monkeypatch.delenv("S3GRL_NO_RELABEL", raising=False)
+    (ea, sa, ra, pa, na), (eb, sb, rb, pb, nb) = out
+    assert all(torch.equal(x, y) for x, y in zip(ea, eb))
+    assert sa == sb
+    assert torch.equal(pa, pb) and torch.equal(na, nb)
+    assert rel_err(ra.cpu().numpy(), rb.cpu().numpy()) < 3e-6
+    G.close()
 
 
 @pytest.mark.parametrize("name,hops", [("rand300", 2), ("cora", 3), ("usair", 1)])
