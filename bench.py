@@ -522,8 +522,8 @@ def main():
                  "aggregate L2 bandwidth"),
                 ("fabric", traffic, mall_peak,
                  "bytes that leave the L2s (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE: Infinity-Cache hits "
-                 "included; the x2 is the guide's correction for full 16-byte-per-lane reads, an upper "
-                 "bound here) against the Infinity-Cache random-row rate for an operand of %.0f MB"
+                 "included; FETCH_SIZE tallies 128-byte line requests at 64 B — calibrated, "
+                 "profiles/*pmc_calibration.json) against the Infinity-Cache random-row rate for an operand of %.0f MB"
                  % (operand_bytes / 1e6)),
                 ("hbm", stream or None, HBM_PEAK_GBS,
                  "bytes that must cross HBM: the node-id and coefficient lists the link kernels wrote "
