@@ -291,15 +291,27 @@ s3grl_status s3grl_graph_create(s3grl_context* ctx, int64_t num_nodes, const int
   S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
   g->max_degree = (int32_t)ctx->h_scalars[0];
-  if (onehop_mode_for(g)) {
-    const s3grl_status st = build_forward_rows(ctx, g);
+  {   // the same graph in descending degree order: what the link kernels walk
+    const s3grl_status st = build_degree_order(ctx, g);
     if (st != S3GRL_OK) {
       s3grl_graph_destroy(g);
       return st;
     }
   }
-  if (num_nodes <= kMaxNodesLds) {   // the graphs the multi-hop kernels take: their degree order
-    const s3grl_status st = build_degree_order(ctx, g);
+  if (onehop_mode_for(g)) {
+    s3grl_status st = build_forward_rows(ctx, g);
+    if (st == S3GRL_OK) {
+      s3grl_graph t = *g;   // and the oriented rows of the degree order
+      t.indptr = g->r_indptr;
+      t.indices = g->r_indices;
+      t.fwd_indptr = nullptr;
+      t.fwd_indices = nullptr;
+      t.fwd_deg = nullptr;
+      st = build_forward_rows(ctx, &t);
+      g->r_fwd_indptr = t.fwd_indptr;
+      g->r_fwd_indices = t.fwd_indices;
+      g->r_fwd_deg = t.fwd_deg;
+    }
     if (st != S3GRL_OK) {
       s3grl_graph_destroy(g);
       return st;
@@ -320,6 +332,9 @@ s3grl_status s3grl_graph_destroy(s3grl_graph* g) {
   g->ctx->arena.release(g->r_indices);
   g->ctx->arena.release(g->new_of_old);
   g->ctx->arena.release(g->old_of_new);
+  g->ctx->arena.release(g->r_fwd_indptr);
+  g->ctx->arena.release(g->r_fwd_indices);
+  g->ctx->arena.release(g->r_fwd_deg);
   delete g;
   return S3GRL_OK;
 }
@@ -461,15 +476,19 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   while (slot > 256 && (int64_t)L * slot * 4 > ((int64_t)6 << 30)) slot >>= 1;
   if (!onehop && slot > 0 && (int64_t)L * slot * 4 <= ((int64_t)6 << 30))
     S3GRL_TRY(arena_alloc(ctx, (size_t)L * slot, &stash, tr));
-  // Plain multi-hop plans walk the graph in its degree order (s3grl_relabel.hip): links translated
-  // on the way in, everything the plan hands out translated back by link_kernel.  Sampled and
-  // random-walk plans draw by the caller's ids and stay on the original order.
-  const bool relabel = !onehop && rw_len == 0 && !sampling && g->r_indptr && !getenv("S3GRL_NO_RELABEL");
+  // Plain plans walk the graph in its degree order (s3grl_relabel.hip): links translated on the way
+  // in, everything the plan hands out translated back by the link kernels.  Sampled and random-walk
+  // plans draw by the caller's ids and stay on the original order.
+  const bool relabel = rw_len == 0 && !sampling && g->r_indptr && (!onehop || g->r_fwd_indptr) &&
+                       !getenv("S3GRL_NO_RELABEL");
   s3grl_graph g_walk = *g;   // what count_kernel / link_kernel see
   const int64_t* links_walk = plan->links;
   if (relabel) {
     g_walk.indptr = g->r_indptr;
     g_walk.indices = g->r_indices;
+    g_walk.fwd_indptr = g->r_fwd_indptr;
+    g_walk.fwd_indices = g->r_fwd_indices;
+    g_walk.fwd_deg = g->r_fwd_deg;
     int64_t* lr = nullptr;
     S3GRL_TRY(arena_alloc(ctx, (size_t)std::max<int64_t>(2 * L, 1), &lr, tr));
     S3GRL_TRY(launch_translate_links(ctx, g, plan->links, L, lr));
@@ -480,7 +499,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   if (onehop) {
     S3GRL_TRY(arena_alloc(ctx, (size_t)L, &e_cap, own));
     plan->e_cap = e_cap;
-    S3GRL_TRY(launch_count1(ctx, g, plan->links, L, plus ? 1 : 0, K, partner, mirror_of, plan->n_nodes, p_nodes,
+    S3GRL_TRY(launch_count1(ctx, &g_walk, links_walk, L, plus ? 1 : 0, K, partner, mirror_of, plan->n_nodes, p_nodes,
                             n_rows, n_jobs, lvl_max, e_cap, reinterpret_cast<int32_t*>(ds), st + 3 * kStatRow));
   } else {
     if (g->num_nodes > kMaxNodesLds) {
@@ -596,7 +615,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   S3GRL_TRY(arena_alloc(ctx, (size_t)std::max<int64_t>(njobs * K, 1), &plan->job_lim, own));
   S3GRL_TRY(arena_alloc(ctx, (size_t)tot_rows, &plan->row_nodes, own));
   S3GRL_TRY(record(ctx, 1));
-  S3GRL_TRY(launch_links(ctx, onehop ? g : &g_walk, onehop ? plan->links : links_walk, L, class_list,
+  S3GRL_TRY(launch_links(ctx, &g_walk, links_walk, L, class_list,
                          class_count_host, cfg->num_hops,
                          plus ? 1 : 0, cn_cap, (cfg->flags & S3GRL_FLAG_FULL_STATS) ? 1 : 0, K, rw_raw, rw_len, p_nodes,
                          plan->node_off,

@@ -188,10 +188,12 @@ __global__ __launch_bounds__(T) void link_full_kernel(
     int32_t* __restrict__ lvl_out, unsigned long long* __restrict__ tot_edges,
     unsigned long long* __restrict__ tot_support, unsigned long long* __restrict__ tot_vol,
     uint32_t* __restrict__ bm_scratch, int64_t bm_stride_words, int lds_bytes,
-    unsigned long long* __restrict__ dbg) {
+    unsigned long long* __restrict__ dbg, const int32_t* __restrict__ old_of_new) {
   extern __shared__ uint32_t smem[];
   const int tid = threadIdx.x;
   constexpr int G = 4;
+  // the caller's id of an internal id (the graph is walked in its degree order, s3grl_relabel.hip)
+  auto ext = [&](int v) -> int { return old_of_new ? old_of_new[v] : v; };
   // diagnostic only (S3GRL_DEBUG_STAMPS): cycles per phase summed over workgroups, slots 8..15
   unsigned long long t_prev = dbg ? __builtin_amdgcn_s_memtime() : 0ull;
 #define S3GRL_FSTAMP(idx)                                                             \
@@ -329,22 +331,40 @@ __global__ __launch_bounds__(T) void link_full_kernel(
       const int v = list[t];
       hs_insert(hkeys, hmask, v);
       hvals[hs_find(hkeys, hmask, v)] = t;
-      c_ids[noff + t] = v;
+      c_ids[noff + t] = ext(v);
       vol_local += indptr[v + 1] - indptr[v];
     }
     const int64_t rp = row_ptr[l];
     const int R = (int)(row_ptr[l + 1] - rp);
     __syncthreads();
-    if (plus && tid < 64)
-      common_neighbours(indptr, indices, [&](int x) { return hs_find(hkeys, hmask, x) >= 0; }, src, dst, cn);
+    if (plus && tid < 64) {
+      const int c =
+          common_neighbours(indptr, indices, [&](int x) { return hs_find(hkeys, hmask, x) >= 0; }, src, dst, cn);
+      if (old_of_new && c > 1) {   // rows in ascending order of the caller's ids (see link_kernel)
+        int* key = cn + c;
+        int* srt = cn + 2 * c;
+        for (int i = tid; i < c; i += 64) key[i] = old_of_new[cn[i]];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int i = tid; i < c; i += 64) {
+          const int k = key[i];
+          int r = 0;
+          for (int j = 0; j < c; ++j) r += key[j] < k ? 1 : 0;
+          srt[r] = cn[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int i = tid; i < c; i += 64) cn[i] = srt[i];
+      }
+    }
     if (tid == 0)
       for (int dd = 0; dd < kMaxLevels; ++dd)
         lvl_out[(int64_t)l * kMaxLevels + dd] = dd == 0 ? 2 : n;
     __syncthreads();
     for (int r = tid; r < R; r += T) {
       const int node = r == 0 ? src : (r == 1 ? dst : cn[r - 2]);
-      row_nodes[rp + r] = node;
-      if (mirror >= 0) row_nodes[mrp + r] = r == 0 ? dst : (r == 1 ? src : cn[r - 2]);
+      row_nodes[rp + r] = ext(node);
+      if (mirror >= 0) row_nodes[mrp + r] = ext(r == 0 ? dst : (r == 1 ? src : cn[r - 2]));
       if (r >= 2) cnpos[r - 2] = hvals[hs_find(hkeys, hmask, node)];
     }
     const int pos_src = src < dst ? 0 : 1, pos_dst = 1 - pos_src;
@@ -597,8 +617,8 @@ __global__ __launch_bounds__(T) void link_full_kernel(
         j.out_row = rp + 2 * pr;
         j.link = l;
         j.support = n;
-        j.node_a = node_a;
-        j.node_b = node_b;
+        j.node_a = ext(node_a);
+        j.node_b = node_b >= 0 ? ext(node_b) : -1;
         j.z_a = (node_a == src || node_a == dst) ? 1 : 0;
         j.z_b = (node_b == src || node_b == dst) ? 1 : 0;
         j.mirror_row = mirror >= 0 ? mrp + 2 * pr : -1;

@@ -12,9 +12,10 @@
 // the permuted CSR has its rows ascending in NEW ids (the kernels bisect rows).  Everything a plan
 // hands out stays in the caller's ids: link_kernel translates the node lists, row nodes and job
 // endpoints on the way out, common-neighbour rows are ordered by the caller's ids, and
-// s3grl_plan_export_subgraphs restores "ascending id inside a hop".  SoP, one-hop plans on big
-// graphs, sampled and random-walk plans keep the original order (their random draws are keyed by
-// the caller's ids).
+// s3grl_plan_export_subgraphs restores "ascending id inside a hop".  One-hop plans on big graphs
+// (s3grl_onehop.inl) walk the same order through oriented rows built from the permuted CSR
+// (collab-scale link kernels 46.9 -> 42.1 ms).  SoP, sampled and random-walk plans keep the
+// original order (their random draws are keyed by the caller's ids).
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>

@@ -1519,7 +1519,7 @@ s3grl_status launch_full_class(s3grl_context* ctx, const LinkArgs& a, int64_t L,
                      reinterpret_cast<unsigned long long*>(a.tot_support),
                      reinterpret_cast<unsigned long long*>(a.tot_vol), bm_scratch, bm_stride_words,
                      getenv("S3GRL_BIG_COLS_HBM") ? 0 : (int)lds,   // test hook: big class, columns in HBM
-                     (BMG && a.dbg) ? a.dbg : nullptr);
+                     (BMG && a.dbg) ? a.dbg : nullptr, a.old_of_new);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }

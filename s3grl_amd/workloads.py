@@ -47,7 +47,17 @@ def chung_lu(n, m, gamma=2.5, d_max=700, seed=3):
     e = np.unique(e, axis=0)
     if len(e) > m:
         e = e[rng.choice(len(e), m, replace=False)]
-    return n, e.astype(np.int64)
+    e = e.astype(np.int64)
+    import os
+    if os.environ.get("S3GRL_EXPERIMENT_RELABEL"):   # experiment: node ids in descending degree order
+        deg = np.bincount(e.ravel(), minlength=n)
+        order = np.argsort(-deg if os.environ["S3GRL_EXPERIMENT_RELABEL"] == "desc" else deg, kind="stable")
+        new = np.empty(n, np.int64)
+        new[order] = np.arange(n)
+        e = new[e]
+        e = np.stack([e.min(1), e.max(1)], 1)
+        e = e[np.lexsort((e[:, 1], e[:, 0]))]
+    return n, e
 
 
 def csr_from_undirected(n, edges):

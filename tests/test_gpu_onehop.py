@@ -70,6 +70,35 @@ def test_onehop_path_equals_bitmap_flavour(eng, monkeypatch, name, K, bm_hbm):
         p0.close(), p1.close(), G0.close(), G1.close()
 
 
+@pytest.mark.parametrize("name", ["usair", "rand300", "star_iso"])
+@pytest.mark.parametrize("bm_hbm", [False, "lds"])
+def test_onehop_path_degree_order_is_invisible(eng, monkeypatch, name, bm_hbm):
+    """The one-hop path walks the graph's degree order too (csrc/s3grl_relabel.hip); with
+    S3GRL_NO_RELABEL it walks the caller's order.  Same node lists, rows nodes and statistics."""
+    import torch
+
+    g = load_extract(name)
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    f = eng.features(np.random.default_rng(3).standard_normal((n, 11)).astype(np.float32))
+    links = eng.links(np.concatenate([g["links"], g["links"][:3, ::-1]]).T)
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("S3GRL_NO_RELABEL", "1")
+        (G0, p0), (G1, p1) = _plans(eng, monkeypatch, A, links, "pos_plus", 3, bm_hbm)
+        st = dict(p1.stats)
+        st.pop("workspace_bytes")
+        outs.append((p1.run(f).clone(), p1.row_ptr().clone(), p1.row_nodes().clone(),
+                     [t.clone() for t in p1.export_subgraphs()], st))
+        p0.close(), p1.close(), G0.close(), G1.close()
+    monkeypatch.delenv("S3GRL_NO_RELABEL", raising=False)
+    a, b = outs
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and a[4] == b[4]
+    assert all(torch.equal(x, y) for x, y in zip(a[3], b[3]))
+    assert rel_err(a[0].cpu().numpy(), b[0].cpu().numpy()) < 3e-6
+
+
 @pytest.mark.parametrize("name", ["usair", "rand300", "probe5"])
 def test_onehop_path_node_sets_vs_reference_fixture(eng, monkeypatch, name):
     """Hop-1 node sets and CN rows against what the reference's own k_hop_subgraph produced."""
