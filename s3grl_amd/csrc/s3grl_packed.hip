@@ -208,7 +208,21 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
     for (int u = 0; u < U; ++u) h[u] = th[id[u]];
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto issue = [&](const PackedHdr(&h)[U], float4_t(&v)[U][CH]) {   // 2U unconditional loads
+  // phase B's form: the ids pass through an opaque statement — without it the header addresses
+  // (plain arithmetic on the ids) are computed right behind the id load of the step before, and
+  // the wait moves there with them
+  auto hdrs_from_late = [&](const uint32_t(&id)[U], PackedHdr(&h)[U]) {
+    uint32_t idv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) idv[u] = id[u];
+    asm volatile("" : "+s"(idv[0]), "+s"(idv[1]), "+s"(idv[2]), "+s"(idv[3]));
+    static_assert(U == 4, "the opaque statement above lists four ids");
+#pragma unroll
+    for (int u = 0; u < U; ++u) h[u] = th[idv[u]];
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // (valid = false: a group beyond the end of the list — every lane reads as zero)
+  auto issue = [&](const PackedHdr(&h)[U], float4_t(&v)[U][CH], bool valid = true) {   // 2U unconditional loads
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t base = (uint32_t)h[u].off;
@@ -216,12 +230,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
       const uint32_t a1 = (base + (uint32_t)__popcll(h[u].m0) + (uint32_t)below(h[u].m1)) << 4;
       if constexpr (MASKED) {
         v[u][0] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(
-                                                   rsrc, (int)select_or_oob(h[u].m0, a0, oobv), 0, 0));
+                                                   rsrc, (int)select_or_oob(valid ? h[u].m0 : 0ull, a0, oobv), 0, 0));
         v[u][1] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(
-                                                   rsrc, (int)select_or_oob(h[u].m1, a1, oobv), 0, 0));
+                                                   rsrc, (int)select_or_oob(valid ? h[u].m1 : 0ull, a1, oobv), 0, 0));
       } else {
-        v[u][0] = *reinterpret_cast<const float4_t*>(bytes + select_by_mask(h[u].m0, a0));
-        v[u][1] = *reinterpret_cast<const float4_t*>(bytes + select_by_mask(h[u].m1, a1));
+        v[u][0] = *reinterpret_cast<const float4_t*>(bytes + select_by_mask(valid ? h[u].m0 : 0ull, a0));
+        v[u][1] = *reinterpret_cast<const float4_t*>(bytes + select_by_mask(valid ? h[u].m1 : 0ull, a1));
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -250,10 +264,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
     // (a variant without the first operator for the rows it cannot reach costs more registers
     // than the multiply-adds it saves: K = 3 goes from 3 waves per SIMD to 2)
     fma_from(std::integral_constant<int, 0>{}, g, v);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto fma_B = [&](int g, const float4_t(&v)[U][CH]) {
-    fma_from(std::integral_constant<int, K - 1>{}, g, v);
     __builtin_amdgcn_sched_barrier(0);
   };
   auto tail_rows = [&](auto first, int j0) {   // at most U-1 rows, operators first+1 .. K
@@ -301,15 +311,53 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
     if (gA > 1) load_hdrs(1, hB);
     if (gA > 2) load_ids(2, idn);
     // steady state: vA = group g in flight, hB = headers of group g+1, idn = ids of group g+2
+    // every scalar load of a half-step (next headers, next ids, this group's coefficients) goes
+    // out before the chunk loads are issued, so that the one wait at the multiply-adds has the
+    // address arithmetic and the other waves between it and them (see phase B)
+    float2 qa[K][U];
+    auto load_qa = [&](int gq) {
+#pragma unroll
+      for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int u = 0; u < U; ++u) qa[i][u] = cf[(int64_t)i * cnt + gq * U + u];
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto fma_qa = [&](const float4_t(&v)[U][CH]) {
+#pragma unroll
+      for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            acc[i][0][c] += qa[i][u].x * v[u][c];
+            acc[i][1][c] += qa[i][u].y * v[u][c];
+          }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // (K <= 3: beyond that the coefficients of a group, 2·K·U scalars, no longer fit next to the
+    // headers — K = 5 measured 6 % slower this way)
     for (; g + 4 < gA; g += 2) {
-      issue(hB, vB);
-      hdrs_from(idn, hA);
-      load_ids(g + 3, idn);
-      fma_A(g, vA);
-      issue(hA, vA);
-      hdrs_from(idn, hB);
-      load_ids(g + 4, idn);
-      fma_A(g + 1, vB);
+      if constexpr (K <= 3) {
+        hdrs_from(idn, hA);
+        load_ids(g + 3, idn);
+        load_qa(g);
+        issue(hB, vB);
+        fma_qa(vA);
+        hdrs_from(idn, hB);
+        load_ids(g + 4, idn);
+        load_qa(g + 1);
+        issue(hA, vA);
+        fma_qa(vB);
+      } else {
+        issue(hB, vB);
+        hdrs_from(idn, hA);
+        load_ids(g + 3, idn);
+        fma_A(g, vA);
+        issue(hA, vA);
+        hdrs_from(idn, hB);
+        load_ids(g + 4, idn);
+        fma_A(g + 1, vB);
+      }
     }
     fma_A(g, vA);
     ++g;
@@ -326,48 +374,67 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- phase B ----------------------------------------------------------------------------
+  // Every scalar load is issued a whole step before its first use.  A wavefront can only wait for
+  // ALL of its outstanding scalar loads (they return out of order: lgkmcnt(0)), so a step that loads
+  // ids, then headers through them, then coefficients at the multiply-adds exposes two scalar round
+  // trips (~800 cycles each through the scalar cache to L2) with four waves per SIMD to cover them
+  // — that, not bytes or cache misses, was two thirds of a step (with the whole operand resident in
+  // L2 the kernel ran 4 % faster).  Step k multiplies group k; at its top the ids of group k+3, the
+  // headers of k+2 and the coefficients of k are complete (loaded during step k-1): it loads the
+  // headers of k+3, the ids of k+4 and the coefficients of k+1, issues the chunk loads of k+2 and
+  // multiplies.  One wait per step, for loads that had a step to arrive.  Scalar buffers alternate
+  // (X/Y), chunk buffers rotate over three: six steps per trip.  Groups beyond the end are clamped
+  // to the last one and their chunk loads read as zero (out-of-range offsets): the multiply-adds
+  // stay unconditional — behind a branch the compiler sinks the scalar loads to their use.
   {
-    int g = gA;
-    PackedHdr h0[U], h1[U];                    // headers of the groups gA + even / gA + odd
-    float4_t v0[U][CH], v1[U][CH], v2[U][CH];  // chunk buffers of the groups gA + (k % 3)
-    if (ngf - gA >= 3) {
-      load_hdrs(g, h0);
-      issue(h0, v0);
-      load_hdrs(g + 1, h1);
-      issue(h1, v1);
-      load_hdrs(g + 2, h0);
-      // steady state (g - gA a multiple of 6): groups g, g+1 in flight in v0, v1; h0 = headers of g+2
-      // (fetching the ids a step ahead, as phase A does, measured 1 % slower here)
-      for (; g + 8 < ngf; g += 6) {
-        issue(h0, v2);
-        load_hdrs(g + 3, h1);
-        fma_B(g, v0);
-        issue(h1, v0);
-        load_hdrs(g + 4, h0);
-        fma_B(g + 1, v1);
-        issue(h0, v1);
-        load_hdrs(g + 5, h1);
-        fma_B(g + 2, v2);
-        issue(h1, v2);
-        load_hdrs(g + 6, h0);
-        fma_B(g + 3, v0);
-        issue(h0, v0);
-        load_hdrs(g + 7, h1);
-        fma_B(g + 4, v1);
-        issue(h1, v1);
-        load_hdrs(g + 8, h0);
-        fma_B(g + 5, v2);
+    const int nB = ngf - gA;
+    if (nB > 0) {
+      auto grp = [&](int k) { return gA + min(k, nB - 1); };
+      uint32_t idX[U], idY[U];
+      PackedHdr hX[U], hY[U];
+      float2 qX[U], qY[U];
+      float4_t v0[U][CH], v1[U][CH], v2[U][CH];
+      auto load_q = [&](int g, float2(&q)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) q[u] = cf[(int64_t)(K - 1) * cnt + g * U + u];
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto fma_q = [&](const float2(&q)[U], const float4_t(&v)[U][CH]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            acc[K - 1][0][c] += q[u].x * v[u][c];
+            acc[K - 1][1][c] += q[u].y * v[u][c];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      load_ids(grp(0), idX);
+      hdrs_from(idX, hX);
+      issue(hX, v0);
+      load_ids(grp(1), idX);
+      hdrs_from(idX, hY);
+      issue(hY, v1, 1 < nB);
+      load_ids(grp(2), idX);
+      hdrs_from(idX, hX);    // headers of group 2
+      load_ids(grp(3), idX);   // ids of group 3
+      load_q(grp(0), qX);
+#define S3GRL_GATHER_STEP(k, IDr, IDl, Hr, Hl, Qr, Ql, Vissue, Vfma) \
+  hdrs_from_late(IDr, Hl);                                            \
+  load_ids(grp((k) + 4), IDl);                                        \
+  load_q(grp((k) + 1), Ql);                                           \
+  issue(Hr, Vissue, (k) + 2 < nB);                                    \
+  fma_q(Qr, Vfma);
+      for (int k = 0; k < nB; k += 6) {
+        S3GRL_GATHER_STEP(k, idX, idY, hX, hY, qX, qY, v2, v0)
+        S3GRL_GATHER_STEP(k + 1, idY, idX, hY, hX, qY, qX, v0, v1)
+        S3GRL_GATHER_STEP(k + 2, idX, idY, hX, hY, qX, qY, v1, v2)
+        S3GRL_GATHER_STEP(k + 3, idY, idX, hY, hX, qY, qX, v2, v0)
+        S3GRL_GATHER_STEP(k + 4, idX, idY, hX, hY, qX, qY, v0, v1)
+        S3GRL_GATHER_STEP(k + 5, idY, idX, hY, hX, qY, qX, v1, v2)
       }
-      issue(h0, v2);
-      fma_B(g, v0);
-      fma_B(g + 1, v1);
-      fma_B(g + 2, v2);
-      g += 3;
-    }
-    for (; g < ngf; ++g) {   // fewer than 3 groups in all, or the last 0..5 of a long list
-      load_hdrs(g, h0);
-      issue(h0, v0);
-      fma_B(g, v0);
+#undef S3GRL_GATHER_STEP
     }
   }
   if (!tail_in_A) tail_rows(std::integral_constant<int, K - 1>{}, ngf * U);
@@ -436,9 +503,11 @@ s3grl_status launch_packed_k(s3grl_context* ctx, const s3grl_plan* p, const s3gr
   const unsigned gx = (unsigned)((p->njobs + kWavesPerBlock - 1) / kWavesPerBlock);
   static const bool masked = !getenv("S3GRL_GATHER_UNMASKED");   // comparison hook: the unconditional loads
   const uint32_t data_bytes = (uint32_t)((f->pk_chunks + 1) * 16);
+  // experiment hook: dynamic LDS per workgroup caps the resident waves (timing only)
+  static const size_t lds_cap = getenv("S3GRL_GATHER_LDS") ? (size_t)atoi(getenv("S3GRL_GATHER_LDS")) : 0;
   if (masked)
     hipLaunchKernelGGL((gather_packed_kernel<K, true>), dim3(gx, (unsigned)f->tiles), dim3(kWavesPerBlock * 64),
-                       0, ctx->stream, p->jobs, (int)p->njobs, p->c_ids, p->c_coef, p->job_z, p->job_lim,
+                       lds_cap, ctx->stream, p->jobs, (int)p->njobs, p->c_ids, p->c_coef, p->job_z, p->job_lim,
                        p->job_order, static_cast<const PackedHdr*>(f->pk_hdr),
                        static_cast<const float4_t*>(f->pk_data), data_bytes, f->N, f->dense, f->ld, (int)f->F, rows);
   else
