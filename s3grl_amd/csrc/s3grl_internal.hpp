@@ -242,6 +242,7 @@ s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_ca
                              int stash_slot = 0);
 // one-hop plans on big graphs (s3grl_onehop.inl): degree-oriented rows of the graph, and the
 // sizing pass that needs no bitmaps
+bool sparse_mode_for(const s3grl_graph* g);
 bool onehop_mode_for(const s3grl_graph* g);
 s3grl_status build_forward_rows(s3grl_context* ctx, s3grl_graph* g);
 s3grl_status launch_count1(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,

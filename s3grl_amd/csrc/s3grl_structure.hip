@@ -1084,6 +1084,7 @@ __global__ void dists_kernel(const int64_t* __restrict__ node_off, const int32_t
 // ---------------------------------------------------------------------------------------
 static inline int words_for(int64_t N) { return (int)((N + 31) / 32); }
 
+#ifndef S3GRL_LINKS_PART   // (the link-kernel translation units compile only the launch code, see the end of the file)
 int64_t mirror_table_slots(int64_t L) {
   int64_t s = 1024;
   while (s < 2 * L) s <<= 1;
@@ -1267,6 +1268,7 @@ s3grl_status launch_scan_i32_to_i64(s3grl_context* ctx, const int32_t* in, int64
   return S3GRL_OK;
 }
 
+#endif  // !S3GRL_LINKS_PART
 // fixed part of link_kernel's LDS: 3 bitmaps + cn + lvl_end + zbuf + scan scratch + hub list
 static inline int link_fixed_words(int64_t num_nodes, int cn_cap, int K) {
   return 3 * words_for(num_nodes) + cn_cap + kMaxLevels + 4 * K + 32 + kHubWords;
@@ -1346,11 +1348,13 @@ static ClassBounds class_bounds_dm(int64_t num_nodes, int cn_cap, int K) {
 }
 
 // The hash flavour pays off when the bitmaps alone would hold a CU to a few workgroups.
+#ifndef S3GRL_LINKS_PART
 bool sparse_mode_for(const s3grl_graph* g) {
   if (getenv("S3GRL_FORCE_HASH")) return true;   // test hook
   if (getenv("S3GRL_NO_HASH")) return false;
   return 3 * (size_t)words_for(g->num_nodes) * 4 > 24 * 1024;
 }
+#endif
 
 // The direct-map flavour: graphs whose 2N-byte map leaves most of a CU's LDS to the lists.
 static bool dm_mode_for(const s3grl_graph* g) {
@@ -1383,6 +1387,7 @@ static int dm_class_mask_for(const s3grl_graph* g, int cn_cap, int K) {
   return mask;
 }
 
+#ifndef S3GRL_LINKS_PART
 int num_class_lists() { return kNumLists; }
 
 // One-hop plans take the row-intersection path on graphs where the hash flavour is in use anyway.
@@ -1464,6 +1469,8 @@ s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_ca
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
+
+#endif  // !S3GRL_LINKS_PART
 
 namespace {
 
@@ -1573,8 +1580,7 @@ s3grl_status launch_link_class(s3grl_context* ctx, const LinkArgs& a, int64_t L,
     if (gsel <= 4) return launch_link_class_g<256, K, 4, false, true>(ctx, a, L, cls, count, stream);
     return launch_link_class_g<256, K, 8, false, true>(ctx, a, L, cls, count, stream);
   }
-  if (gsel == 2) return launch_link_class_g<T, K, 2, false, false>(ctx, a, L, cls, count, stream);
-  if (gsel == 4) return launch_link_class_g<T, K, 4, false, false>(ctx, a, L, cls, count, stream);
+  if (gsel <= 4) return launch_link_class_g<T, K, 4, false, false>(ctx, a, L, cls, count, stream);
   return launch_link_class_g<T, K, 8, false, false>(ctx, a, L, cls, count, stream);
 }
 
@@ -1639,8 +1645,7 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
       const size_t lds = (size_t)4 * link_fixed_words_dm(a.g->num_nodes, a.cn_cap, K) +
                          class_bounds_dm(a.g->num_nodes, a.cn_cap, K).b[c - kSparseBase];
       const int t = threads_for_class(lds, c - kSparseBase);
-      if (t <= 64) S3GRL_TRY((launch_link_class<64, K>(ctx, a, L, c, class_count_host[c], next_stream())));
-      else if (t <= 128) S3GRL_TRY((launch_link_class<128, K>(ctx, a, L, c, class_count_host[c], next_stream())));
+      if (t <= 128) S3GRL_TRY((launch_link_class<128, K>(ctx, a, L, c, class_count_host[c], next_stream())));
       else if (t <= 256) S3GRL_TRY((launch_link_class<256, K>(ctx, a, L, c, class_count_host[c], next_stream())));
       else if (t <= 512) S3GRL_TRY((launch_link_class<512, K>(ctx, a, L, c, class_count_host[c], next_stream())));
       else S3GRL_TRY((launch_link_class<1024, K>(ctx, a, L, c, class_count_host[c], next_stream())));
@@ -1656,8 +1661,7 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
     const size_t lds = (size_t)4 * link_fixed_words(a.g->num_nodes, a.cn_cap, K) +
                        class_bounds(a.g->num_nodes, a.cn_cap, K).b[c];
     const int t = threads_for_class(lds, c);
-    if (t <= 64) S3GRL_TRY((launch_link_class<64, K>(ctx, a, L, c, count, next_stream())));
-    else if (t <= 128) S3GRL_TRY((launch_link_class<128, K>(ctx, a, L, c, count, next_stream())));
+    if (t <= 128) S3GRL_TRY((launch_link_class<128, K>(ctx, a, L, c, count, next_stream())));
     else if (t <= 256) S3GRL_TRY((launch_link_class<256, K>(ctx, a, L, c, count, next_stream())));
     else if (t <= 512) S3GRL_TRY((launch_link_class<512, K>(ctx, a, L, c, count, next_stream())));
     else S3GRL_TRY((launch_link_class<1024, K>(ctx, a, L, c, count, next_stream())));
@@ -1671,6 +1675,31 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
 }
 
 }  // namespace
+
+// The link kernels are instantiated per sign_k, thread count, lanes per row and flavour — most of
+// this file's compile time.  They are spread over four translation units that compile in parallel:
+// this file itself (sign_k 3, 4) and s3grl_links_{a,b,c}.hip, which include it with
+// S3GRL_LINKS_PART defined and export one launcher each for their sign_k values.
+#ifdef S3GRL_LINKS_PART
+}  // namespace s3grl
+extern "C" s3grl_status S3GRL_LINKS_PART(s3grl_context* ctx, const void* args, int64_t L,
+                                          const int32_t* class_count_host, int K) {
+  const s3grl::LinkArgs& a = *static_cast<const s3grl::LinkArgs*>(args);
+  switch (K) {
+    case S3GRL_LINKS_K0: return s3grl::launch_links_k<S3GRL_LINKS_K0>(ctx, a, L, class_count_host);
+    case S3GRL_LINKS_K1: return s3grl::launch_links_k<S3GRL_LINKS_K1>(ctx, a, L, class_count_host);
+    default: return S3GRL_ERR_INVALID_ARGUMENT;
+  }
+}
+namespace s3grl {
+#else
+}  // namespace s3grl
+extern "C" {
+s3grl_status s3grl_links_part_a(s3grl_context*, const void*, int64_t, const int32_t*, int);   // sign_k 1, 2
+s3grl_status s3grl_links_part_b(s3grl_context*, const void*, int64_t, const int32_t*, int);   // sign_k 5, 6
+s3grl_status s3grl_links_part_c(s3grl_context*, const void*, int64_t, const int32_t*, int);   // sign_k 7, 8
+}
+namespace s3grl {
 
 s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                           const int32_t* class_list, const int32_t* class_count_host, int hops,
@@ -1718,14 +1747,14 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
     a.bm_scratch = static_cast<uint32_t*>(q);
   }
   switch (K) {
-    case 1: return launch_links_k<1>(ctx, a, L, class_count_host);
-    case 2: return launch_links_k<2>(ctx, a, L, class_count_host);
+    case 1:
+    case 2: return s3grl_links_part_a(ctx, &a, L, class_count_host, K);
     case 3: return launch_links_k<3>(ctx, a, L, class_count_host);
     case 4: return launch_links_k<4>(ctx, a, L, class_count_host);
-    case 5: return launch_links_k<5>(ctx, a, L, class_count_host);
-    case 6: return launch_links_k<6>(ctx, a, L, class_count_host);
-    case 7: return launch_links_k<7>(ctx, a, L, class_count_host);
-    case 8: return launch_links_k<8>(ctx, a, L, class_count_host);
+    case 5:
+    case 6: return s3grl_links_part_b(ctx, &a, L, class_count_host, K);
+    case 7:
+    case 8: return s3grl_links_part_c(ctx, &a, L, class_count_host, K);
     default:
       set_last_error("sign_k must be in 1..8");
       return S3GRL_ERR_INVALID_ARGUMENT;
@@ -1740,5 +1769,6 @@ s3grl_status launch_dists(s3grl_context* ctx, const int64_t* node_off, const int
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
+#endif  // S3GRL_LINKS_PART
 
 }  // namespace s3grl

@@ -1081,6 +1081,33 @@ def test_packed_gather_on_tiny_subgraphs(eng, name, K):
 
 
 
+@pytest.mark.parametrize("K", [1, 2, 4, 6, 7, 8])
+@pytest.mark.parametrize("hops", [1, 2])
+def test_every_sign_k_up_to_the_limit(eng, monkeypatch, K, hops):
+    """sign_k = 1..8 are separate kernel instantiations (spread over four translation units): each
+    against the C restatement, on the general path and on the one-hop path of big graphs."""
+    from oracle import c_oracle
+
+    g = load_extract("rand300")
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = np.abs(np.random.default_rng(K).standard_normal((n, 9))).astype(np.float32)
+    links = g["links"][:40].T
+    ref, ptr, nodes, _ = c_oracle.pos_rows(links, hops, A, X.astype(np.float64), K, plus=True)
+    for onehop in ([False, True] if hops == 1 else [False]):
+        if onehop:
+            monkeypatch.setenv("S3GRL_FORCE_ONEHOP", "1")
+            monkeypatch.setenv("S3GRL_FORCE_HASH", "1")
+        G = eng.graph(A)
+        res = eng.precompute(G, eng.features(X), eng.links(links), mode="pos_plus", num_hops=hops, sign_k=K)
+        np.testing.assert_array_equal(res.row_ptr.cpu().numpy(), ptr)
+        np.testing.assert_array_equal(res.row_nodes.cpu().numpy(), nodes)
+        assert rel_err(res.rows.cpu().numpy(), ref) < TOL
+        G.close()
+    monkeypatch.delenv("S3GRL_FORCE_ONEHOP", raising=False)
+    monkeypatch.delenv("S3GRL_FORCE_HASH", raising=False)
+
+
 @pytest.mark.parametrize("name,hops", [("rand300", 2), ("cora", 3), ("usair", 2), ("star_iso", 2)])
 @pytest.mark.parametrize("mode", ["pos", "pos_plus"])
 def test_degree_order_is_invisible(eng, monkeypatch, name, hops, mode):
