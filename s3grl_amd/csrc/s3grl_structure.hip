@@ -64,10 +64,15 @@ __device__ __forceinline__ int common_neighbours(const int32_t* __restrict__ ind
 // utils.py:53-74: `fringe = neighbors(fringe, A) - visited`, early break on an empty fringe).
 // Outputs per link: n = |S|, R rows, and p = |P|, the hop-major prefix of S that can carry a
 // non-zero entry of r_{K-1}: the only nodes link_kernel keeps propagation state for.
-constexpr int kCountList = 3072;
+// Frontier list of count_kernel and its threads per link.  Most links are small (PubMed: two thirds
+// have under 250 nodes) and pay for the uniform part of the kernel once per wavefront: two waves
+// and a 1 024-entry list (12 KB of LDS per link on PubMed, 12 links per CU) measured 1.34 ms
+// against 1.70 for four waves and 3 072 entries, 1.60 for one wave; graphs whose bitmaps leave
+// room for only a few workgroups per CU get four waves per link.
+constexpr int kCountList = 1024;
 
-template <int G>
-__global__ __launch_bounds__(kBlock) void count_kernel(
+template <int G, int kCountBlock>
+__global__ __launch_bounds__(kCountBlock) void count_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int N, int W,
     const int64_t* __restrict__ links, int hops, int plus, int K, int hubs,
     const int32_t* __restrict__ rw_raw, int rw_len, const int32_t* __restrict__ partner, const int32_t* __restrict__ mirror_of,
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
   int32_t* stash_l = stash ? stash + (int64_t)l * slot : nullptr;
   int32_t* lvl_l = stash ? lvl_stash + (int64_t)l * kMaxLevels : nullptr;
   if (lvl_l && tid == 0) lvl_l[0] = 2;
-  for (int t = tid; t < W; t += kBlock) {
+  for (int t = tid; t < W; t += kCountBlock) {
     vis[t] = 0;
     if (cur) cur[t] = 0;
     nxt[t] = 0;
@@ -149,14 +154,14 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
   if (rw_raw) hops = 1;  // ScaLed: the "hop" is what the cached random walks of src and dst visited
   for (int d = 1; d <= hops; ++d) {
     if (rw_raw) {
-      for (int i = tid; i < 2 * rw_len; i += kBlock) {
+      for (int i = tid; i < 2 * rw_len; i += kCountBlock) {
         const int u = rw_raw[(int64_t)(i < rw_len ? src : dst) * rw_len + (i < rw_len ? i : i - rw_len)];
         const uint32_t m = 1u << (u & 31);
         const uint32_t old = atomicOr(&vis[u >> 5], m);
         if (!(old & m)) atomicOr(&nxt[u >> 5], m);
       }
     } else if (use_list) {
-      walk_rows<kBlock, G, 2>(
+      walk_rows<kCountBlock, G, 2>(
           f0, f1, list, indptr, indices, hub,
           [&](RowAcc&, int, int u, bool valid) {
             if (valid) {
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
           },
           [](RowAcc&, int, int) {});
     } else {
-      for (int t = tid; t < W; t += kBlock) {
+      for (int t = tid; t < W; t += kCountBlock) {
         uint32_t w = cur[t];
         while (w) {
           const int b = __ffs(w) - 1;
@@ -185,21 +190,21 @@ __global__ __launch_bounds__(kBlock) void count_kernel(
     }
     __syncthreads();
     // every thread owns a contiguous run of bitmap words: one block scan per level
-    const int C = (W + kBlock - 1) / kBlock;
+    const int C = (W + kCountBlock - 1) / kCountBlock;
     const int w0 = min(tid * C, W), w1 = min(w0 + C, W);
     int mine = 0;
     for (int t = w0; t < w1; ++t) mine += __popc(nxt[t]);
     int added;
-    int pos = f1 + block_excl_scan<kBlock>(mine, sh, added);
+    int pos = f1 + block_excl_scan<kCountBlock>(mine, sh, added);
     if (added == 0) break;
     if (sampling) {  // utils.py:66-70, the same draw link_kernel's BFS makes
       const int keep = hop_keep(smp, added);
       if (keep == 0) break;                     // utils.py:71-72
       if (keep < added) {
-        sample_level<kBlock>(nxt, W, keep, smp.seed, min(src, dst), max(src, dst), sh);
+        sample_level<kCountBlock>(nxt, W, keep, smp.seed, min(src, dst), max(src, dst), sh);
         mine = 0;
         for (int t = w0; t < w1; ++t) mine += __popc(nxt[t]);
-        pos = f1 + block_excl_scan<kBlock>(mine, sh, added);
+        pos = f1 + block_excl_scan<kCountBlock>(mine, sh, added);
       }
       for (int t = w0; t < w1; ++t) mem[t] |= nxt[t];
     }
@@ -1142,10 +1147,12 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
     return S3GRL_ERR_GRAPH_TOO_LARGE;
   }
   const bool sparse = (double)g->nnz / (double)std::max<int64_t>(g->num_nodes, 1) <= 6.0;
-  auto kern = sparse ? count_kernel<4> : count_kernel<8>;
+  const bool small = lds <= 24 * 1024;
+  auto kern = small ? (sparse ? count_kernel<4, 128> : count_kernel<8, 128>)
+                    : (sparse ? count_kernel<4, 256> : count_kernel<8, 256>);
   S3GRL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)L), dim3(kBlock), lds, ctx->stream, g->indptr,
+  hipLaunchKernelGGL(kern, dim3((unsigned)L), dim3(small ? 128 : 256), lds, ctx->stream, g->indptr,
                      g->indices, (int)g->num_nodes, W, links, hops, plus, K,
                      g->max_degree > kHubArmDegree ? 1 : 0, rw_raw, rw_len, partner, mirror_of, n_nodes,
                      p_nodes, n_rows, n_jobs, lvl_max, err_flag,
