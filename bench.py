@@ -90,14 +90,19 @@ def collect_pmc(args, kernel_family):
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not Path(rocprof).exists():
         return None
+    # never under a profiler already (a trace of this command must not start counter passes of its own)
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or \
+            "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
+        sys.stderr.write("[bench] running under a profiler: counter passes skipped\n")
+        return None
     merged, disp = {}, {}
     base = Path(tempfile.mkdtemp(prefix="s3grl_pmc_", dir="/tmp"))
     env = dict(os.environ, TMPDIR="/tmp")
     for grp in (["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"]):
         d = base / grp[0]
-        cmd = ["timeout", "-k", "10", "240", rocprof, "--pmc", *grp, "--output-format", "csv", "-d", str(d),
+        cmd = ["timeout", "-k", "10", "150", rocprof, "--pmc", *grp, "--output-format", "csv", "-d", str(d),
                "--", sys.executable, str(REPO / "bench.py"), "--steps", "1", "--warmup", "0",
-               "--no-cpu-baseline", "--no-api", "--workload", args.workload]
+               "--no-cpu-baseline", "--no-api", "--no-pmc", "--workload", args.workload]
         r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if r.returncode != 0:
             sys.stderr.write(f"[bench] counter pass {grp} failed rc={r.returncode}\n")
@@ -271,7 +276,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true", help="skip the end_to_end_api measurement")
     ap.add_argument("--collect-pmc", action="store_true",
-                    help="collect FETCH_SIZE / WRITE_SIZE / L2 hit rate of this command in child rocprofv3 passes")
+                    help="(default at N = 1) collect FETCH_SIZE / WRITE_SIZE / L2 hit rate of this command in child "
+                         "rocprofv3 passes, about 40 s; falls back to the newest summary under profiles/, labelled")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the counter passes (quick runs)")
     ap.add_argument("--max-links", type=int, default=0, help="truncate the link list (debug)")
     ap.add_argument("--chunks", type=int, default=2,
                     help="N > 1: pieces per rank (all-gather of piece c overlaps the compute of c+1)")
@@ -280,6 +287,7 @@ def main():
     ap.add_argument("--verify", action="store_true",
                     help="N > 1: check the reassembled tensor bit for bit against an unsharded run")
     args = ap.parse_args()
+    args.collect_pmc = args.collect_pmc or not args.no_pmc   # single-GPU runs only (checked where it is used)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
@@ -495,7 +503,7 @@ def main():
             gather_ms = tm["gather_ms"] / launches
             kname = "gather_packed_kernel" if x.is_packed else "gather_kernel"
             traffic, traffic_source, l2_hit = None, None, None
-            if args.collect_pmc:
+            if args.collect_pmc and world == 1:
                 rec = collect_pmc(args, kname)
                 if rec:
                     traffic, l2_hit = rec["hbm_bytes_per_launch"], rec.get("l2_hit_rate")
@@ -570,7 +578,7 @@ def main():
             out_bytes = L * 2 * (K + 1) * 4 * (F + 1)
             table = (K + 1) * N * ldy * 8
             traffic, traffic_source, l2_hit = None, None, None
-            if args.collect_pmc:
+            if args.collect_pmc and world == 1:
                 rec = collect_pmc(args, "sop_rows_kernel")
                 if rec:
                     traffic, l2_hit = rec["hbm_bytes_per_launch"], rec.get("l2_hit_rate")

@@ -22,15 +22,6 @@ DATA = Path(__file__).resolve().parent / "data"
 def load_topology(name):
     t = np.load(DATA / f"topo_{name}.npz")
     n, e = int(t["num_nodes"]), t["edges"].astype(np.int64)
-    import os
-    if os.environ.get("S3GRL_EXPERIMENT_RELABEL"):   # experiment: node ids in descending degree order
-        deg = np.bincount(e.ravel(), minlength=n)
-        order = np.argsort(-deg if os.environ["S3GRL_EXPERIMENT_RELABEL"] == "desc" else deg, kind="stable")
-        new = np.empty(n, np.int64)
-        new[order] = np.arange(n)
-        e = new[e]
-        e = np.stack([e.min(1), e.max(1)], 1)
-        e = e[np.lexsort((e[:, 1], e[:, 0]))]
     return n, e
 
 
@@ -48,15 +39,6 @@ def chung_lu(n, m, gamma=2.5, d_max=700, seed=3):
     if len(e) > m:
         e = e[rng.choice(len(e), m, replace=False)]
     e = e.astype(np.int64)
-    import os
-    if os.environ.get("S3GRL_EXPERIMENT_RELABEL"):   # experiment: node ids in descending degree order
-        deg = np.bincount(e.ravel(), minlength=n)
-        order = np.argsort(-deg if os.environ["S3GRL_EXPERIMENT_RELABEL"] == "desc" else deg, kind="stable")
-        new = np.empty(n, np.int64)
-        new[order] = np.arange(n)
-        e = new[e]
-        e = np.stack([e.min(1), e.max(1)], 1)
-        e = e[np.lexsort((e[:, 1], e[:, 0]))]
     return n, e
 
 

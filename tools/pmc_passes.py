@@ -20,7 +20,7 @@ for i, grp in enumerate(a.groups):
     d = base / f"g{i}"
     print(f"[pmc_passes] pass {i}: {grp}", flush=True)
     cmd = ["timeout", "-k", "10", "150", "rocprofv3", "--pmc", *grp.split(), "--output-format", "csv", "-d", str(d),
-           "--", sys.executable, str(REPO / "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-api",
+           "--", sys.executable, str(REPO / "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-api", "--no-pmc",
            "--workload", a.workload]
     r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode:

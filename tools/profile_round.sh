@@ -15,7 +15,7 @@ rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 rc=0
 for wl in pubmed_pos_k3 pubmed_pos_k3_dense pubmed_sop_k3 pubmed_pos_k5 collab_pos_k3; do
-  timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$wl -- python3 $R/bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --no-api > $O/trace_$wl.log 2>&1 || rc=1
+  timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$wl -- python3 $R/bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline --no-api --no-pmc > $O/trace_$wl.log 2>&1 || rc=1
   f=$(find $O/trace_$wl -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_$wl.csv
   rm -rf $O/trace_$wl
 done
@@ -27,7 +27,7 @@ for wl in pubmed_pos_k3 pubmed_pos_k3_dense pubmed_sop_k3; do
   timeout -k 10 420 python3 bench.py --workload $wl --collect-pmc > $O/bench_$wl.json 2> $O/bench_$wl.err || rc=1
 done
 for wl in pubmed_pos_k5 collab_pos_k3 cora_posplus_k3 usair_pos_k2; do
-  timeout -k 10 300 python3 bench.py --workload $wl > $O/bench_$wl.json 2> $O/bench_$wl.err || rc=1
+  timeout -k 10 300 python3 bench.py --workload $wl --no-pmc > $O/bench_$wl.json 2> $O/bench_$wl.err || rc=1
 done
 echo "profile_round rc=$rc"; ls $O
 exit $rc
