@@ -960,6 +960,35 @@ def test_collab_scale_sampled_links(eng):
     _all_links_vs_c(eng, w, "pos", links_sel=sel, chunk=10000)
 
 
+@pytest.mark.parametrize("mode", ["pos", "pos_plus"])
+def test_big_graph_two_hops_vs_c(eng, mode):
+    """A 150 000-node power-law graph, two hops: the big-graph flavours of the general path (bitmaps
+    of 56 KB per link in the sizing pass, four wavefronts per link there; hash-set and HBM-scratch
+    classes in the link kernels; the degree order of a graph with hubs) against the C restatement."""
+    from oracle import c_oracle
+    from s3grl_amd import workloads
+
+    n, e = workloads.chung_lu(150000, 420000, d_max=400, seed=11)
+    A = csr_from_undirected(n, e)
+    rng = np.random.default_rng(12)
+    X = (rng.random((n, 24)) * (rng.random((n, 24)) < 0.4)).astype(np.float32)
+    deg = np.diff(A.indptr)
+    pos = e[rng.choice(len(e), 150, replace=False)]
+    hub = e[np.argsort(-(deg[e[:, 0]] + deg[e[:, 1]]))[:20]]
+    neg = rng.integers(0, n, size=(150, 2))
+    neg = neg[neg[:, 0] != neg[:, 1]]
+    links = np.concatenate([pos, hub, neg, pos[:10, ::-1]]).T
+    G = eng.graph(A)
+    res = eng.precompute(G, eng.features(X), eng.links(links), mode=mode, num_hops=2, sign_k=3)
+    ref, ptr, nodes, _ = c_oracle.pos_rows(links, 2, A, X.astype(np.float64), 3, plus=(mode == "pos_plus"))
+    np.testing.assert_array_equal(res.row_ptr.cpu().numpy(), ptr)
+    np.testing.assert_array_equal(res.row_nodes.cpu().numpy(), nodes)
+    got = res.rows.cpu().numpy()
+    report_errors(f"big_graph_two_hops[{mode}]", rel_err(got, ref), elem_rel_err(got, ref))
+    assert rel_err(got, ref) < TOL
+    G.close()
+
+
 # ------------------------------------------------------------------------------------------
 # per-hop sampling (reference utils.py:66-70: ratio_per_hop, max_nodes_per_hop)
 # ------------------------------------------------------------------------------------------
