@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
 #pragma unroll
       for (int c = 0; c < CH; ++c) acc[i][r][c] = (float4_t)(0.f);
 
-  auto load_hdrs = [&](int g, PackedHdr(&h)[U]) {   // scalar: ids (one wide load), then headers
+  auto load_hdrs = [&](int g, PackedHdr(&h)[U]) __attribute__((always_inline)) {   // scalar: ids (one wide load), then headers
     uint32_t id[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) id[u] = uid[g * U + u];
@@ -198,12 +198,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
   };
   // the same in two halves for the steady-state loops: the ids of a group are fetched one step
   // before its headers, so that no step waits for a scalar round trip it has just started
-  auto load_ids = [&](int g, uint32_t(&id)[U]) {
+  auto load_ids = [&](int g, uint32_t(&id)[U]) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < U; ++u) id[u] = uid[g * U + u];
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto hdrs_from = [&](const uint32_t(&id)[U], PackedHdr(&h)[U]) {
+  auto hdrs_from = [&](const uint32_t(&id)[U], PackedHdr(&h)[U]) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < U; ++u) h[u] = th[id[u]];
     __builtin_amdgcn_sched_barrier(0);
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
   // phase B's form: the ids pass through an opaque statement — without it the header addresses
   // (plain arithmetic on the ids) are computed right behind the id load of the step before, and
   // the wait moves there with them
-  auto hdrs_from_late = [&](const uint32_t(&id)[U], PackedHdr(&h)[U]) {
+  auto hdrs_from_late = [&](const uint32_t(&id)[U], PackedHdr(&h)[U]) __attribute__((always_inline)) {
     uint32_t idv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) idv[u] = id[u];
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
     __builtin_amdgcn_sched_barrier(0);
   };
   // (valid = false: a group beyond the end of the list — every lane reads as zero)
-  auto issue = [&](const PackedHdr(&h)[U], float4_t(&v)[U][CH], bool valid = true) {   // 2U unconditional loads
+  auto issue = [&](const PackedHdr(&h)[U], float4_t(&v)[U][CH], bool valid = true) __attribute__((always_inline)) {   // 2U unconditional loads
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t base = (uint32_t)h[u].off;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto fma_from = [&](auto first, int g, const float4_t(&v)[U][CH]) {   // operators first+1 .. K
+  auto fma_from = [&](auto first, int g, const float4_t(&v)[U][CH]) __attribute__((always_inline)) {   // operators first+1 .. K
     constexpr int I0 = decltype(first)::value;
 #pragma unroll
     for (int i = I0; i < K; ++i) {
@@ -255,18 +255,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
       }
     }
   };
-  // Two phases.  A: the list prefix that operators before the last can reach (rows < lim[K-2]),
-  // all accumulators live, two chunk buffers.  Then the rows of operators 1..K-1 are complete and
-  // are written out, which frees their 2(K-1)·CH·4 accumulator registers.  B: the rest of the list
-  // feeds the last operator only; the freed registers hold a third chunk buffer, so 8 rows are in
-  // flight under the multiply-adds of 4 instead of 4 — at the same 3 waves per SIMD.
-  auto fma_A = [&](int g, const float4_t(&v)[U][CH]) {
-    // (a variant without the first operator for the rows it cannot reach costs more registers
-    // than the multiply-adds it saves: K = 3 goes from 3 waves per SIMD to 2)
-    fma_from(std::integral_constant<int, 0>{}, g, v);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto tail_rows = [&](auto first, int j0) {   // at most U-1 rows, operators first+1 .. K
+  // Two phases.  The last NB operators all reach the whole list (lim[K-NB .. K-1] == cnt; NB = 1 when
+  // sign_k - 1 < num_hops, more when the operators outrun the BFS depth; capped at 3).  A: the list
+  // prefix the operators before them can reach (rows < lim[K-NB-1]), all accumulators live, two
+  // chunk buffers.  Then the rows of operators 1..K-NB are complete and are written out, which
+  // frees their accumulator registers.  B: the rest of the list feeds the last NB operators only;
+  // with NB = 1 the freed registers hold a third chunk buffer (8 rows in flight under the
+  // multiply-adds of 4), with NB = 2, 3 the rows do 2 or 3 operators' multiply-adds instead of K
+  // (PubMed sign_k = 5: four fifths of the rows, 3 operators instead of 5).
+  auto tail_rows = [&](auto first, int j0) __attribute__((always_inline)) {   // at most U-1 rows, operators first+1 .. K
     constexpr int I0 = decltype(first)::value;
     for (int j = j0; j < cnt; ++j) {
       const PackedHdr h = th[uid[j]];
@@ -295,49 +292,50 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
     }
   };
 
-  const int ngf = cnt / U;   // full groups
-  const int limA = K >= 2 ? lim[K >= 2 ? K - 2 : 0] : 0;
-  const int gA = min(ngf, (limA + U - 1) / U);       // groups [0, gA) belong to phase A
-  const bool tail_in_A = limA > ngf * U;             // then gA == ngf and phase B is empty
-
-  // ---- phase A ----------------------------------------------------------------------------
-  if (gA > 0) {
-    int g = 0;
+  // Groups [g0, g1) through two chunk buffers, operators first+1 .. K.  Every scalar load of a
+  // half-step (next headers, next ids, this group's coefficients) goes out before the chunk loads
+  // are issued, so that the one wait at the multiply-adds has the address arithmetic and the other
+  // waves between it and them (see pass3 below) — as long as the 2·(K-first)·U coefficient scalars
+  // of a group fit next to the headers (up to 3 operators; 5 measured 6 % slower this way).
+  auto pass2 = [&](auto first, int g0, int g1) __attribute__((always_inline)) {
+    constexpr int I0 = decltype(first)::value;
+    constexpr int NO = K - I0;
+    if (g1 <= g0) return;
+    int g = g0;
     PackedHdr hA[U], hB[U];
     float4_t vA[U][CH], vB[U][CH];
     uint32_t idn[U];
-    load_hdrs(0, hA);
+    load_hdrs(g0, hA);
     issue(hA, vA);
-    if (gA > 1) load_hdrs(1, hB);
-    if (gA > 2) load_ids(2, idn);
+    if (g1 - g0 > 1) load_hdrs(g0 + 1, hB);
+    if (g1 - g0 > 2) load_ids(g0 + 2, idn);
     // steady state: vA = group g in flight, hB = headers of group g+1, idn = ids of group g+2
-    // every scalar load of a half-step (next headers, next ids, this group's coefficients) goes
-    // out before the chunk loads are issued, so that the one wait at the multiply-adds has the
-    // address arithmetic and the other waves between it and them (see phase B)
-    float2 qa[K][U];
+    float2 qa[NO][U];
     auto load_qa = [&](int gq) {
 #pragma unroll
-      for (int i = 0; i < K; ++i)
+      for (int i = 0; i < NO; ++i)
 #pragma unroll
-        for (int u = 0; u < U; ++u) qa[i][u] = cf[(int64_t)i * cnt + gq * U + u];
+        for (int u = 0; u < U; ++u) qa[i][u] = cf[(int64_t)(I0 + i) * cnt + gq * U + u];
       __builtin_amdgcn_sched_barrier(0);
     };
     auto fma_qa = [&](const float4_t(&v)[U][CH]) {
 #pragma unroll
-      for (int i = 0; i < K; ++i)
+      for (int i = 0; i < NO; ++i)
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
           for (int c = 0; c < CH; ++c) {
-            acc[i][0][c] += qa[i][u].x * v[u][c];
-            acc[i][1][c] += qa[i][u].y * v[u][c];
+            acc[I0 + i][0][c] += qa[i][u].x * v[u][c];
+            acc[I0 + i][1][c] += qa[i][u].y * v[u][c];
           }
       __builtin_amdgcn_sched_barrier(0);
     };
-    // (K <= 3: beyond that the coefficients of a group, 2·K·U scalars, no longer fit next to the
-    // headers — K = 5 measured 6 % slower this way)
-    for (; g + 4 < gA; g += 2) {
-      if constexpr (K <= 3) {
+    auto fma_g = [&](int gq, const float4_t(&v)[U][CH]) {
+      fma_from(first, gq, v);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    for (; g + 4 < g1; g += 2) {
+      if constexpr (NO <= 3) {
         hdrs_from(idn, hA);
         load_ids(g + 3, idn);
         load_qa(g);
@@ -352,28 +350,23 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
         issue(hB, vB);
         hdrs_from(idn, hA);
         load_ids(g + 3, idn);
-        fma_A(g, vA);
+        fma_g(g, vA);
         issue(hA, vA);
         hdrs_from(idn, hB);
         load_ids(g + 4, idn);
-        fma_A(g + 1, vB);
+        fma_g(g + 1, vB);
       }
     }
-    fma_A(g, vA);
+    fma_g(g, vA);
     ++g;
-    for (; g < gA; ++g) {   // at most 3 groups
+    for (; g < g1; ++g) {   // at most 3 groups
       load_hdrs(g, hA);
       issue(hA, vA);
-      fma_A(g, vA);
+      fma_g(g, vA);
     }
-  }
-  if (tail_in_A) tail_rows(std::integral_constant<int, 0>{}, ngf * U);
-  // operators 0 .. K-1 of both rows are final
-  write_pair_rows_part<K, CH, 0, K - 1, true, false>(job, jid, acc, coff, cok, job_z, X, ldx, F, rows,
-                                                     blockIdx.y == 0);
-  __builtin_amdgcn_sched_barrier(0);
+  };
 
-  // ---- phase B ----------------------------------------------------------------------------
+  // Groups [g0, g1) through three chunk buffers, the last operator only.
   // Every scalar load is issued a whole step before its first use.  A wavefront can only wait for
   // ALL of its outstanding scalar loads (they return out of order: lgkmcnt(0)), so a step that loads
   // ids, then headers through them, then coefficients at the multiply-adds exposes two scalar round
@@ -386,60 +379,86 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
   // (X/Y), chunk buffers rotate over three: six steps per trip.  Groups beyond the end are clamped
   // to the last one and their chunk loads read as zero (out-of-range offsets): the multiply-adds
   // stay unconditional — behind a branch the compiler sinks the scalar loads to their use.
-  {
-    const int nB = ngf - gA;
-    if (nB > 0) {
-      auto grp = [&](int k) { return gA + min(k, nB - 1); };
-      uint32_t idX[U], idY[U];
-      PackedHdr hX[U], hY[U];
-      float2 qX[U], qY[U];
-      float4_t v0[U][CH], v1[U][CH], v2[U][CH];
-      auto load_q = [&](int g, float2(&q)[U]) {
+  auto pass3 = [&](int g0, int g1) __attribute__((always_inline)) {
+    const int nB = g1 - g0;
+    if (nB <= 0) return;
+    auto grp = [&](int k) { return g0 + min(k, nB - 1); };
+    uint32_t idX[U], idY[U];
+    PackedHdr hX[U], hY[U];
+    float2 qX[U], qY[U];
+    float4_t v0[U][CH], v1[U][CH], v2[U][CH];
+    auto load_q = [&](int g, float2(&q)[U]) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) q[u] = cf[(int64_t)(K - 1) * cnt + g * U + u];
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      auto fma_q = [&](const float2(&q)[U], const float4_t(&v)[U][CH]) {
+      for (int u = 0; u < U; ++u) q[u] = cf[(int64_t)(K - 1) * cnt + g * U + u];
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto fma_q = [&](const float2(&q)[U], const float4_t(&v)[U][CH]) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < U; ++u) {
 #pragma unroll
-          for (int c = 0; c < CH; ++c) {
-            acc[K - 1][0][c] += q[u].x * v[u][c];
-            acc[K - 1][1][c] += q[u].y * v[u][c];
-          }
+        for (int c = 0; c < CH; ++c) {
+          acc[K - 1][0][c] += q[u].x * v[u][c];
+          acc[K - 1][1][c] += q[u].y * v[u][c];
         }
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      load_ids(grp(0), idX);
-      hdrs_from(idX, hX);
-      issue(hX, v0);
-      load_ids(grp(1), idX);
-      hdrs_from(idX, hY);
-      issue(hY, v1, 1 < nB);
-      load_ids(grp(2), idX);
-      hdrs_from(idX, hX);    // headers of group 2
-      load_ids(grp(3), idX);   // ids of group 3
-      load_q(grp(0), qX);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    load_ids(grp(0), idX);
+    hdrs_from(idX, hX);
+    issue(hX, v0);
+    load_ids(grp(1), idX);
+    hdrs_from(idX, hY);
+    issue(hY, v1, 1 < nB);
+    load_ids(grp(2), idX);
+    hdrs_from(idX, hX);    // headers of group 2
+    load_ids(grp(3), idX);   // ids of group 3
+    load_q(grp(0), qX);
 #define S3GRL_GATHER_STEP(k, IDr, IDl, Hr, Hl, Qr, Ql, Vissue, Vfma) \
   hdrs_from_late(IDr, Hl);                                            \
   load_ids(grp((k) + 4), IDl);                                        \
   load_q(grp((k) + 1), Ql);                                           \
   issue(Hr, Vissue, (k) + 2 < nB);                                    \
   fma_q(Qr, Vfma);
-      for (int k = 0; k < nB; k += 6) {
-        S3GRL_GATHER_STEP(k, idX, idY, hX, hY, qX, qY, v2, v0)
-        S3GRL_GATHER_STEP(k + 1, idY, idX, hY, hX, qY, qX, v0, v1)
-        S3GRL_GATHER_STEP(k + 2, idX, idY, hX, hY, qX, qY, v1, v2)
-        S3GRL_GATHER_STEP(k + 3, idY, idX, hY, hX, qY, qX, v2, v0)
-        S3GRL_GATHER_STEP(k + 4, idX, idY, hX, hY, qX, qY, v0, v1)
-        S3GRL_GATHER_STEP(k + 5, idY, idX, hY, hX, qY, qX, v1, v2)
-      }
-#undef S3GRL_GATHER_STEP
+    for (int k = 0; k < nB; k += 6) {
+      S3GRL_GATHER_STEP(k, idX, idY, hX, hY, qX, qY, v2, v0)
+      S3GRL_GATHER_STEP(k + 1, idY, idX, hY, hX, qY, qX, v0, v1)
+      S3GRL_GATHER_STEP(k + 2, idX, idY, hX, hY, qX, qY, v1, v2)
+      S3GRL_GATHER_STEP(k + 3, idY, idX, hY, hX, qY, qX, v2, v0)
+      S3GRL_GATHER_STEP(k + 4, idX, idY, hX, hY, qX, qY, v0, v1)
+      S3GRL_GATHER_STEP(k + 5, idY, idX, hY, hX, qY, qX, v1, v2)
     }
+#undef S3GRL_GATHER_STEP
+  };
+
+  const int ngf = cnt / U;   // full groups
+  auto run = [&](auto nb_c) __attribute__((always_inline)) {
+    constexpr int NB = decltype(nb_c)::value;   // trailing operators that reach the whole list
+    const int limA = NB < K ? lim[NB < K ? K - NB - 1 : 0] : 0;
+    const int gA = min(ngf, (limA + U - 1) / U);       // groups [0, gA) belong to phase A
+    const bool tail_in_A = limA > ngf * U;             // then gA == ngf and phase B is empty
+    pass2(std::integral_constant<int, 0>{}, 0, gA);
+    if (tail_in_A) tail_rows(std::integral_constant<int, 0>{}, ngf * U);
+    // operators 0 .. K-NB of both rows are final
+    write_pair_rows_part<K, CH, 0, K - NB, true, false>(job, jid, acc, coff, cok, job_z, X, ldx, F, rows,
+                                                        blockIdx.y == 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NB == 1) pass3(gA, ngf);
+    else pass2(std::integral_constant<int, K - NB>{}, gA, ngf);
+    if (!tail_in_A) tail_rows(std::integral_constant<int, K - NB>{}, ngf * U);
+    write_pair_rows_part<K, CH, K - NB, K, false, true>(job, jid, acc, coff, cok, job_z, X, ldx, F, rows,
+                                                        blockIdx.y == 0);
+  };
+  int nb = 1;
+#pragma unroll
+  for (int i = K - 2; i >= 0; --i)
+    if (lim[i] == lim[K - 1] && nb == K - 1 - i) nb = K - i;
+  if constexpr (K >= 3) {
+    if (nb >= 3) return run(std::integral_constant<int, 3>{});
   }
-  if (!tail_in_A) tail_rows(std::integral_constant<int, K - 1>{}, ngf * U);
-  write_pair_rows_part<K, CH, K - 1, K, false, true>(job, jid, acc, coff, cok, job_z, X, ldx, F, rows,
-                                                     blockIdx.y == 0);
+  if constexpr (K >= 2) {
+    if (nb >= 2) return run(std::integral_constant<int, 2>{});
+  }
+  run(std::integral_constant<int, 1>{});
 }
 
 // Measurement only (s3grl_plan_gather_traffic): the bytes the gather launch of a plan requests,
@@ -479,11 +498,15 @@ __global__ __launch_bounds__(256) void gather_traffic_kernel(
   if (packed) {
     constexpr int U = 4;
     const int ngf = cnt / U;
-    const int limA = K >= 2 ? job_lim[(int64_t)jid * K + (K - 2)] : 0;
+    int nb = 1;   // trailing operators that reach the whole list, as gather_packed_kernel counts them
+    for (int i = K - 2; i >= 0; --i)
+      if (job_lim[(int64_t)jid * K + i] == job_lim[(int64_t)jid * K + K - 1] && nb == K - 1 - i) nb = K - i;
+    nb = min(nb, 3);
+    const int limA = nb < K ? job_lim[(int64_t)jid * K + (K - nb - 1)] : 0;
     const int gA = min(ngf, (limA + U - 1) / U);
     const bool tail_in_A = limA > ngf * U;
     const int nA = tail_in_A ? cnt : gA * U;
-    coef_entries = (unsigned long long)K * nA + (unsigned long long)(cnt - nA);
+    coef_entries = (unsigned long long)K * nA + (unsigned long long)nb * (cnt - nA);
   }
   const int nrow = job.node_b >= 0 ? 2 : 1;
   const int ncopy = job.mirror_row >= 0 ? 2 : 1;
