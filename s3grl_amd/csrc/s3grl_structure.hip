@@ -1639,11 +1639,20 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
     // threads per link by class: a wavefront for the smallest subgraphs; the classes whose LDS
     // leaves one or two workgroups per CU get 1024 / 512 threads (their probing trips are chains
     // of dependent loads: more rows per trip, more loads in flight)
-    if (c - kFullBase <= 1)
+    const int fc = c - kFullBase;
+    int t = fc <= 1 ? 64 : (fc <= 3 ? 256 : (fc == 4 ? 512 : 1024));
+    {
+      char name[32];   // tuning hook
+      snprintf(name, sizeof(name), "S3GRL_TF_CLASS%d", fc);
+      if (const char* e = getenv(name)) t = atoi(e);
+    }
+    if (t <= 64)
       S3GRL_TRY((launch_full_class<64, K, false>(ctx, a, L, c, count, next_stream(), nullptr, 0, count)));
-    else if (c - kFullBase <= 3)
+    else if (t <= 128)
+      S3GRL_TRY((launch_full_class<128, K, false>(ctx, a, L, c, count, next_stream(), nullptr, 0, count)));
+    else if (t <= 256)
       S3GRL_TRY((launch_full_class<256, K, false>(ctx, a, L, c, count, next_stream(), nullptr, 0, count)));
-    else if (c - kFullBase == 4)
+    else if (t <= 512)
       S3GRL_TRY((launch_full_class<512, K, false>(ctx, a, L, c, count, next_stream(), nullptr, 0, count)));
     else
       S3GRL_TRY((launch_full_class<1024, K, false>(ctx, a, L, c, count, next_stream(), nullptr, 0, count)));
