@@ -1110,6 +1110,36 @@ def test_packed_gather_on_tiny_subgraphs(eng, name, K):
 
 
 
+@pytest.mark.parametrize("onehop", [False, True])
+def test_many_common_neighbours(eng, monkeypatch, onehop):
+    """A dense graph: pairs with 100-200 common neighbours (more than a wavefront: the rank sort that
+    puts the common-neighbour rows into the caller's id order runs in several rounds), general path
+    and one-hop path, against the C restatement."""
+    from oracle import c_oracle
+
+    rng = np.random.default_rng(41)
+    n = 420
+    M = np.triu(rng.random((n, n)) < 0.55, 1)
+    e = np.argwhere(M)
+    A = csr_from_undirected(n, e)
+    X = rng.random((n, 7)).astype(np.float32)
+    links = np.concatenate([e[rng.choice(len(e), 24, replace=False)],
+                            np.argwhere(~M & np.triu(np.ones((n, n), bool), 1))[:12]]).T
+    ref, ptr, nodes, _ = c_oracle.pos_rows(links, 1, A, X.astype(np.float64), 2, plus=True)
+    assert np.diff(ptr).max() > 66          # more common neighbours than lanes
+    if onehop:
+        monkeypatch.setenv("S3GRL_FORCE_ONEHOP", "1")
+        monkeypatch.setenv("S3GRL_FORCE_HASH", "1")
+    G = eng.graph(A)
+    res = eng.precompute(G, eng.features(X), eng.links(links), mode="pos_plus", num_hops=1, sign_k=2)
+    np.testing.assert_array_equal(res.row_ptr.cpu().numpy(), ptr)
+    np.testing.assert_array_equal(res.row_nodes.cpu().numpy(), nodes)
+    assert rel_err(res.rows.cpu().numpy(), ref) < TOL
+    G.close()
+    monkeypatch.delenv("S3GRL_FORCE_ONEHOP", raising=False)
+    monkeypatch.delenv("S3GRL_FORCE_HASH", raising=False)
+
+
 @pytest.mark.parametrize("K", [1, 2, 4, 6, 7, 8])
 @pytest.mark.parametrize("hops", [1, 2])
 def test_every_sign_k_up_to_the_limit(eng, monkeypatch, K, hops):
