@@ -16,6 +16,10 @@
 #include <cstring>
 #include <memory>
 
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "s3grl_internal.hpp"
 #include "s3grl_device.hpp"
 
@@ -213,18 +217,40 @@ __global__ __launch_bounds__(T) void sop_scalar_kernel(
 // independent loads in flight per trip, every row of the f64 table read exactly once per link.
 // (Operator-outer, the first version, re-read the two X rows for each operator: 14 row reads per
 // link instead of 8 at K = 3, all of them beyond L2 — 29 GB of fabric traffic against 16 GB.)
+// Launch order: the links sorted by (src, dst) — `order`.  A node is an endpoint of ~16 links of a
+// PubMed split, and in the caller's (permuted) order every one of them fetches its 2(K+1) table
+// rows from HBM again (the f64 table is 4x the Infinity Cache).  Sorted, the four wavefronts of a
+// workgroup and the workgroups next to them share their src rows out of L1 / L2 / Infinity Cache;
+// only the dst rows still come from HBM.  The output keeps the caller's order (rows of link l at 2l).
+__global__ void sop_order_keys_kernel(const int64_t* __restrict__ links, int64_t L, uint64_t* __restrict__ keys,
+                                      int32_t* __restrict__ vals) {
+  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L) return;
+  keys[l] = ((uint64_t)(uint32_t)links[2 * l] << 32) | (uint64_t)(uint32_t)links[2 * l + 1];
+  vals[l] = (int32_t)l;
+}
+
 template <int KT>
 __global__ __launch_bounds__(256) void sop_rows_kernel(
-    const int64_t* __restrict__ links, int64_t L, const double* __restrict__ Y, int64_t N,
+    const int64_t* __restrict__ links, const int32_t* __restrict__ order,
+    const int32_t* __restrict__ partner, const int32_t* __restrict__ mirror_of, int64_t L,
+    const double* __restrict__ Y, int64_t N,
     int64_t ldy, int F, int K, const double* __restrict__ scal, float* __restrict__ rows) {
   const int lane = threadIdx.x & 63;
-  const int64_t l = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (l >= L) return;
+  const int64_t pos = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pos >= L) return;
+  const int64_t l = order ? (int64_t)order[pos] : pos;
+  // Reversed duplicates (both directions of a train edge are in the reference's list): the link
+  // (d,s) has the rows of (s,d) swapped (Â^i is symmetric) — the primary writes both outputs.
+  if (partner && partner[l] >= 0) return;
+  const int64_t m = mirror_of ? (int64_t)mirror_of[l] : -1;
   const int KK = KT > 0 ? KT : K;
   const int64_t s = links[2 * l], d = links[2 * l + 1];
   const int Fp = F + 1;
   float* __restrict__ out_s = rows + (2 * l) * (int64_t)(KK + 1) * Fp;
   float* __restrict__ out_d = out_s + (int64_t)(KK + 1) * Fp;
+  float* __restrict__ mir_s = m >= 0 ? rows + (2 * m) * (int64_t)(KK + 1) * Fp : nullptr;   // = our dst row
+  float* __restrict__ mir_d = m >= 0 ? mir_s + (int64_t)(KK + 1) * Fp : nullptr;            // = our src row
   const double* __restrict__ x_s = Y + s * ldy;
   const double* __restrict__ x_d = Y + d * ldy;
   const int64_t plane = N * ldy;
@@ -243,17 +269,32 @@ __global__ __launch_bounds__(256) void sop_rows_kernel(
     }
     out_s[1 + c] = (float)xs;   // operator 0: x = [[1|X[s]],[1|X[d]]]  (tuned_SIGN.py:119-125)
     out_d[1 + c] = (float)xd;
+    if (m >= 0) {
+      mir_s[1 + c] = (float)xd;
+      mir_d[1 + c] = (float)xs;
+    }
 #pragma unroll
     for (int i = 0; i < (KT > 0 ? KT : kMaxSignK); ++i) {
       if (i < KK) {
-        out_s[(int64_t)(i + 1) * Fp + 1 + c] = (float)(ys[i] - sd[i] * xd);
-        out_d[(int64_t)(i + 1) * Fp + 1 + c] = (float)(yd[i] - sd[i] * xs);
+        const float vs = (float)(ys[i] - sd[i] * xd), vd = (float)(yd[i] - sd[i] * xs);
+        out_s[(int64_t)(i + 1) * Fp + 1 + c] = vs;
+        out_d[(int64_t)(i + 1) * Fp + 1 + c] = vd;
+        if (m >= 0) {
+          mir_s[(int64_t)(i + 1) * Fp + 1 + c] = vd;
+          mir_d[(int64_t)(i + 1) * Fp + 1 + c] = vs;
+        }
       }
     }
   }
   if (lane <= KK) {
-    out_s[(int64_t)lane * Fp] = lane == 0 ? 1.f : (float)scal[(l * KK + (lane - 1)) * 3 + 1];
-    out_d[(int64_t)lane * Fp] = lane == 0 ? 1.f : (float)scal[(l * KK + (lane - 1)) * 3 + 2];
+    const float zs = lane == 0 ? 1.f : (float)scal[(l * KK + (lane - 1)) * 3 + 1];
+    const float zd = lane == 0 ? 1.f : (float)scal[(l * KK + (lane - 1)) * 3 + 2];
+    out_s[(int64_t)lane * Fp] = zs;
+    out_d[(int64_t)lane * Fp] = zd;
+    if (m >= 0) {
+      mir_s[(int64_t)lane * Fp] = zd;
+      mir_d[(int64_t)lane * Fp] = zs;
+    }
   }
 }
 
@@ -288,11 +329,14 @@ static inline int words_for(int64_t N) { return (int)((N + 31) / 32); }
 
 // bins links by LDS need of sop_scalar_kernel (4 + 16·HB bytes per ball node)
 __global__ void sop_classify_kernel(const int32_t* __restrict__ n_nodes, int64_t L, int per_node,
-                                    int b0, int b1, int b2, int32_t* __restrict__ class_count,
+                                    int b0, int b1, int b2, const int32_t* __restrict__ partner,
+                                    int32_t* __restrict__ class_count,
                                     int32_t* __restrict__ class_list) {
   const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int need = l < L ? n_nodes[l] * per_node + 64 : 0;
-  const int c = l >= L ? -1 : (need <= b0 ? 0 : (need <= b1 ? 1 : (need <= b2 ? 2 : 3)));
+  // a reversed duplicate (d,s) of a link (s,d) of the same list needs no scalars of its own
+  const bool skip = l >= L || (partner && partner[l] >= 0);
+  const int c = skip ? -1 : (need <= b0 ? 0 : (need <= b1 ? 1 : (need <= b2 ? 2 : 3)));
   // one atomic per (wave, class) instead of one per link
   const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -426,12 +470,48 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
   S3GRL_TRY(alloc((size_t)(L + 1) * 8, &q)); node_off = (int64_t*)q;
   S3GRL_TRY(alloc((size_t)scan_workspace_elems(L) * 8, &q)); scan_ws = (int64_t*)q;
   S3GRL_TRY(alloc((size_t)L * K * 3 * 8, &q)); scal = (double*)q;
+  // launch order of the row kernel (see sop_order_keys_kernel)
+  int32_t* order = nullptr;
+  uint64_t *sort_ka = nullptr, *sort_kb = nullptr;
+  int32_t* sort_va = nullptr;
+  void* sort_tmp = nullptr;
+  size_t sort_bytes = 0;
+  if (!getenv("S3GRL_SOP_UNSORTED")) {   // comparison hook
+    uint64_t *ka, *kb;
+    int32_t *va, *vb;
+    S3GRL_TRY(alloc((size_t)L * 8, &q)); ka = (uint64_t*)q;
+    S3GRL_TRY(alloc((size_t)L * 8, &q)); kb = (uint64_t*)q;
+    S3GRL_TRY(alloc((size_t)L * 4, &q)); va = (int32_t*)q;
+    S3GRL_TRY(alloc((size_t)L * 4, &q)); vb = (int32_t*)q;
+    S3GRL_HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, ka, kb, va, vb, (size_t)L, 0, 64, ctx->stream));
+    S3GRL_TRY(alloc(std::max<size_t>(sort_bytes, 16), &sort_tmp));
+    order = vb;
+    sort_ka = ka, sort_kb = kb, sort_va = va;
+  }
 
   int64_t* ds = ctx->d_scalars;
   int64_t* hs = ctx->h_scalars;
   int32_t* class_count = reinterpret_cast<int32_t*>(ds + 8);
   if (ctx->profiling) S3GRL_HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
   S3GRL_HIP_TRY(hipMemsetAsync(ds, 0, 32 * sizeof(int64_t), ctx->stream));
+  int32_t *partner = nullptr, *mirror_of = nullptr;
+  if (!getenv("S3GRL_NO_MIRROR")) {
+    uint64_t* mk;
+    int32_t* mv;
+    const int64_t slots = mirror_table_slots(L);
+    S3GRL_TRY(alloc((size_t)slots * 8, &q)); mk = (uint64_t*)q;
+    S3GRL_TRY(alloc((size_t)slots * 4, &q)); mv = (int32_t*)q;
+    S3GRL_TRY(alloc((size_t)L * 4, &q)); partner = (int32_t*)q;
+    S3GRL_TRY(alloc((size_t)L * 4, &q)); mirror_of = (int32_t*)q;
+    S3GRL_TRY(launch_find_mirrors(ctx, links, L, g->num_nodes, mk, mv, slots, partner, mirror_of, ds + 7));
+  }
+  if (order) {
+    hipLaunchKernelGGL(sop_order_keys_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream, links,
+                       L, sort_ka, sort_va);
+    S3GRL_HIP_TRY(hipGetLastError());
+    S3GRL_HIP_TRY(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, sort_ka, sort_kb, sort_va, order, (size_t)L, 0, 64,
+                                            ctx->stream));
+  }
   // capacity of every link's ball: the sizing BFS of the PoS path, or a degree bound for radius <= 1
   if (RB <= 1) {
     hipLaunchKernelGGL(sop_ball_bound_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -446,7 +526,7 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
   const int per_node = 4 + 16 * HB;
   const int b2 = 163840 - fixed, b1 = std::min(b2, 49152), b0 = std::min(b2, 12288);
   hipLaunchKernelGGL(sop_classify_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream,
-                     n_nodes, L, per_node, b0, b1, b2, class_count, class_list);
+                     n_nodes, L, per_node, b0, b1, b2, partner, class_count, class_list);
   S3GRL_HIP_TRY(hipGetLastError());
   S3GRL_HIP_TRY(hipMemcpyAsync(hs, ds, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -494,7 +574,8 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
   {
     const dim3 grid((unsigned)((L + 3) / 4)), block(256);
 #define S3GRL_ROWS(KT)                                                                            \
-  hipLaunchKernelGGL(sop_rows_kernel<KT>, grid, block, 0, ctx->stream, links, L, s->Y, g->num_nodes, \
+  hipLaunchKernelGGL(sop_rows_kernel<KT>, grid, block, 0, ctx->stream, links, order, partner, mirror_of, L, \
+                     s->Y, g->num_nodes, \
                      s->ldy, (int)s->F, K, scal, rows)
     switch (K) {   // the common sign_k get their loops unrolled (2K + 2 loads in registers)
       case 1: S3GRL_ROWS(1); break;

@@ -297,6 +297,35 @@ def test_sop_sign_k_range(eng, K):
     G.close()
 
 
+@pytest.mark.parametrize("K", [2, 3])
+def test_sop_reversed_duplicates_and_launch_order(eng, monkeypatch, K):
+    """SoP folds a reversed duplicate (d,s) into its (s,d) (rows swapped) and runs its row kernel in
+    (src, dst) order; the output keeps the caller's order.  Against the oracle, and against the
+    unfolded / unsorted run of the same list."""
+    g = load_extract("rand300")
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = np.random.default_rng(50 + K).random((n, 29)).astype(np.float32)
+    base = g["links"]
+    rng = np.random.default_rng(K)
+    links = np.concatenate([base, base[::2, ::-1], base[:5]])       # reversed duplicates, exact duplicates
+    links = links[rng.permutation(len(links))].T
+    G = eng.graph(A)
+    f = eng.features(X)
+    res = eng.precompute(G, f, eng.links(links), mode="sop", sign_k=K).rows.clone()
+    ref, _, _ = oracle.collate_rows(
+        oracle.get_SoP_prepped_ds(oracle.global_normalized_powers(A, K, np.float64), links, A,
+                                  X.astype(np.float64), 1, dtype=np.float64), K)
+    assert rel_err(res.cpu().numpy(), ref) < TOL
+    monkeypatch.setenv("S3GRL_NO_MIRROR", "1")
+    monkeypatch.setenv("S3GRL_SOP_UNSORTED", "1")
+    plain = eng.precompute(G, f, eng.links(links), mode="sop", sign_k=K).rows
+    monkeypatch.delenv("S3GRL_NO_MIRROR")
+    monkeypatch.delenv("S3GRL_SOP_UNSORTED")
+    assert rel_err(res.cpu().numpy(), plain.cpu().numpy()) < 1e-6
+    G.close()
+
+
 def test_sop_known_answers_and_exact_cancellation(eng):
     # (iv) triangle: Â = ½(J−I), Â² = ¼(J+I); link (0,1)
     A = csr_from_undirected(3, [[0, 1], [0, 2], [1, 2]])
