@@ -47,7 +47,9 @@ def _graph(rng, kind, n):
     return n, e
 
 
-CASES = list(range(36))
+import os
+
+CASES = list(range(int(os.environ.get("S3GRL_FUZZ_CASES", "36"))))   # more for a one-off soak
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -87,4 +89,36 @@ def test_random_configuration(eng, monkeypatch, case):
     err = rel_err(res.rows.cpu().numpy(), ref)
     assert err < TOL, (case, kind, n, hops, K, plus, F, density, err)
     f.close()
+    G.close()
+
+
+@pytest.mark.parametrize("case", list(range(16)))
+def test_random_sop_configuration(eng, monkeypatch, case):
+    """The same sweep for SoP, against the reference-structured Python restatement (global powers
+    materialised, row with the partner's column zeroed times X): small graphs, sign_k 1..6, lists
+    with reversed and exact duplicates, isolated endpoints."""
+    import oracle
+
+    rng = np.random.default_rng(5000 + case)
+    kind = ["uniform", "powerlaw", "isolated"][case % 3]
+    n, edges = _graph(rng, kind, int(rng.choice([30, 120, 400])))
+    A = csr_from_undirected(n, edges)
+    K = int(rng.integers(1, 7))
+    F = int(rng.choice([1, 9, 64, 130]))
+    X = (rng.random((n, F)) * (rng.random((n, F)) < float(rng.choice([1.0, 0.3])))).astype(np.float32)
+    pos = edges[rng.choice(len(edges), min(25, len(edges)), replace=False)]
+    neg = rng.integers(0, n, size=(40, 2))
+    neg = neg[neg[:, 0] != neg[:, 1]]
+    links = np.concatenate([pos, neg, pos[:8, ::-1], neg[:3]])
+    links = links[rng.permutation(len(links))].T
+    if case % 4 == 1:
+        monkeypatch.setenv("S3GRL_NO_MIRROR", "1")
+    if case % 4 == 2:
+        monkeypatch.setenv("S3GRL_SOP_UNSORTED", "1")
+    G = eng.graph(A)
+    res = eng.precompute(G, eng.features(X), eng.links(links), mode="sop", sign_k=K)
+    ref, _, _ = oracle.collate_rows(
+        oracle.get_SoP_prepped_ds(oracle.global_normalized_powers(A, K, np.float64), links, A,
+                                  X.astype(np.float64), 1, dtype=np.float64), K)
+    assert rel_err(res.rows.cpu().numpy(), ref) < TOL, (case, kind, n, K, F)
     G.close()
