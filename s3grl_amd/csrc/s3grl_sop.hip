@@ -122,7 +122,12 @@ __global__ __launch_bounds__(T) void sop_scalar_kernel(
   int32_t* list = reinterpret_cast<int32_t*>(smem + red_off + 96);
   double2* r = reinterpret_cast<double2*>(smem + ((red_off + 96 + n_alloc + 3) & ~3));  // [HB][n]
 
-  const int src = (int)links[2 * (int64_t)l], dst = (int)links[2 * (int64_t)l + 1];
+  // the scalars are formed for the pair in canonical orientation (lower id first) and handed out in
+  // the link's own: (d,s) then gets bit for bit what (s,d) gets — a folded reversed duplicate, a
+  // pair split over two ranks and a pair computed twice all agree exactly
+  const int l_s = (int)links[2 * (int64_t)l], l_d = (int)links[2 * (int64_t)l + 1];
+  const bool swp = l_s > l_d;
+  const int src = swp ? l_d : l_s, dst = swp ? l_s : l_d;
   const int g = tid & (G - 1);
   int nlev;
   // ball of radius RB: HB = ⌈K/2⌉ when K is even; HB - 1 when K is odd — r_HB then only ever meets
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(T) void sop_scalar_kernel(
     if (tid < 3) {
       double acc = 0.0;
       for (int w = 0; w < T / 64; ++w) acc += red[w * 3 + tid];   // fixed order
-      scal[((int64_t)l * K + (i - 1)) * 3 + tid] = acc;
+      scal[((int64_t)l * K + (i - 1)) * 3 + ((swp && tid) ? 3 - tid : tid)] = acc;   // ss <-> dd when swapped
     }
     __syncthreads();
   }

@@ -300,8 +300,8 @@ def test_sop_sign_k_range(eng, K):
 @pytest.mark.parametrize("K", [2, 3])
 def test_sop_reversed_duplicates_and_launch_order(eng, monkeypatch, K):
     """SoP folds a reversed duplicate (d,s) into its (s,d) (rows swapped) and runs its row kernel in
-    (src, dst) order; the output keeps the caller's order.  Against the oracle, and against the
-    unfolded / unsorted run of the same list."""
+    (src, dst) order; the output keeps the caller's order.  Against the oracle, and bit for bit
+    against the unfolded / unsorted run of the same list."""
     g = load_extract("rand300")
     n = int(g["num_nodes"])
     A = csr_from_undirected(n, g["edges"])
@@ -322,7 +322,10 @@ def test_sop_reversed_duplicates_and_launch_order(eng, monkeypatch, K):
     plain = eng.precompute(G, f, eng.links(links), mode="sop", sign_k=K).rows
     monkeypatch.delenv("S3GRL_NO_MIRROR")
     monkeypatch.delenv("S3GRL_SOP_UNSORTED")
-    assert rel_err(res.cpu().numpy(), plain.cpu().numpy()) < 1e-6
+    import torch
+
+    # the scalars are formed in canonical orientation of the pair: folding changes no bit
+    assert torch.equal(res, plain)
     G.close()
 
 
