@@ -139,7 +139,10 @@ __device__ __forceinline__ uint32_t select_or_oob(uint64_t mask, uint32_t if_set
   return r;
 }
 
-template <int K, bool MASKED>
+// MINNB = 2: a plan whose last two operators reach the whole list in every job (sign_k - 1 >=
+// num_hops): the variant that holds every operator's accumulators at once (NB = 1) is left out, and
+// with it its registers — PubMed sign_k = 5: 128 instead of 166 VGPRs, four waves per SIMD.
+template <int K, bool MASKED, int MINNB>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
     const Job* __restrict__ jobs, int njobs, const int32_t* __restrict__ c_ids,
     const float* __restrict__ c_coef, const float* __restrict__ job_z,
@@ -240,10 +243,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto fma_from = [&](auto first, int g, const float4_t(&v)[U][CH]) __attribute__((always_inline)) {   // operators first+1 .. K
-    constexpr int I0 = decltype(first)::value;
+  auto fma_from = [&](auto first, auto last, int g, const float4_t(&v)[U][CH]) __attribute__((always_inline)) {   // operators first+1 .. last
+    constexpr int I0 = decltype(first)::value, I1 = decltype(last)::value;
 #pragma unroll
-    for (int i = I0; i < K; ++i) {
+    for (int i = I0; i < I1; ++i) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const float2 q = cf[(int64_t)i * cnt + g * U + u];
@@ -263,8 +266,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
   // with NB = 1 the freed registers hold a third chunk buffer (8 rows in flight under the
   // multiply-adds of 4), with NB = 2, 3 the rows do 2 or 3 operators' multiply-adds instead of K
   // (PubMed sign_k = 5: four fifths of the rows, 3 operators instead of 5).
-  auto tail_rows = [&](auto first, int j0) __attribute__((always_inline)) {   // at most U-1 rows, operators first+1 .. K
-    constexpr int I0 = decltype(first)::value;
+  auto tail_rows = [&](auto first, auto last, int j0) __attribute__((always_inline)) {   // at most U-1 rows, operators first+1 .. last
+    constexpr int I0 = decltype(first)::value, I1 = decltype(last)::value;
     for (int j = j0; j < cnt; ++j) {
       const PackedHdr h = th[uid[j]];
       const uint32_t base = (uint32_t)h.off;
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
         v[1] = *reinterpret_cast<const float4_t*>(bytes + select_by_mask(h.m1, a1));
       }
 #pragma unroll
-      for (int i = I0; i < K; ++i) {
+      for (int i = I0; i < I1; ++i) {
         const float2 q = cf[(int64_t)i * cnt + j];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -297,9 +300,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
   // are issued, so that the one wait at the multiply-adds has the address arithmetic and the other
   // waves between it and them (see pass3 below) — as long as the 2·(K-first)·U coefficient scalars
   // of a group fit next to the headers (up to 3 operators; 5 measured 6 % slower this way).
-  auto pass2 = [&](auto first, int g0, int g1) __attribute__((always_inline)) {
+  auto pass2 = [&](auto first, auto last, int g0, int g1) __attribute__((always_inline)) {
     constexpr int I0 = decltype(first)::value;
-    constexpr int NO = K - I0;
+    constexpr int NO_RAW = decltype(last)::value - I0;
+    constexpr int NO = NO_RAW > 0 ? NO_RAW : 1;   // (an empty operator range, NB == K: nothing to do)
+    if (NO_RAW <= 0) return;
     if (g1 <= g0) return;
     int g = g0;
     PackedHdr hA[U], hB[U];
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
       __builtin_amdgcn_sched_barrier(0);
     };
     auto fma_g = [&](int gq, const float4_t(&v)[U][CH]) {
-      fma_from(first, gq, v);
+      fma_from(first, last, gq, v);
       __builtin_amdgcn_sched_barrier(0);
     };
     for (; g + 4 < g1; g += 2) {
@@ -433,18 +438,34 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
   const int ngf = cnt / U;   // full groups
   auto run = [&](auto nb_c) __attribute__((always_inline)) {
     constexpr int NB = decltype(nb_c)::value;   // trailing operators that reach the whole list
+    using IC0 = std::integral_constant<int, 0>;
+    using ICS = std::integral_constant<int, K - NB>;   // first trailing operator
+    using ICK = std::integral_constant<int, K>;
     const int limA = NB < K ? lim[NB < K ? K - NB - 1 : 0] : 0;
-    const int gA = min(ngf, (limA + U - 1) / U);       // groups [0, gA) belong to phase A
-    const bool tail_in_A = limA > ngf * U;             // then gA == ngf and phase B is empty
-    pass2(std::integral_constant<int, 0>{}, 0, gA);
-    if (tail_in_A) tail_rows(std::integral_constant<int, 0>{}, ngf * U);
-    // operators 0 .. K-NB of both rows are final
-    write_pair_rows_part<K, CH, 0, K - NB, true, false>(job, jid, acc, coff, cok, job_z, X, ldx, F, rows,
-                                                        blockIdx.y == 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (NB == 1) pass3(gA, ngf);
-    else pass2(std::integral_constant<int, K - NB>{}, gA, ngf);
-    if (!tail_in_A) tail_rows(std::integral_constant<int, K - NB>{}, ngf * U);
+    const int gA = min(ngf, (limA + U - 1) / U);       // groups [0, gA): the prefix the leading operators reach
+    const bool tail_in_A = limA > ngf * U;
+    if constexpr (NB == 1) {
+      // A: every operator on the prefix; B: the last operator on the rest through three chunk buffers
+      pass2(IC0{}, ICK{}, 0, gA);
+      if (tail_in_A) tail_rows(IC0{}, ICK{}, ngf * U);
+      write_pair_rows_part<K, CH, 0, K - NB, true, false>(job, jid, acc, coff, cok, job_z, X, ldx, F, rows,
+                                                          blockIdx.y == 0);
+      __builtin_amdgcn_sched_barrier(0);
+      pass3(gA, ngf);
+      if (!tail_in_A) tail_rows(ICS{}, ICK{}, ngf * U);
+    } else {
+      // A: the LEADING operators only, on the prefix; B: the trailing ones on the WHOLE list (the
+      // prefix rows are fetched twice — a fifth more row loads on PubMed sign_k = 5 — but no phase
+      // holds more than max(K-NB, NB) operators' accumulators: 128 instead of 166 VGPRs there,
+      // four waves per SIMD instead of three)
+      pass2(IC0{}, ICS{}, 0, gA);
+      if (tail_in_A) tail_rows(IC0{}, ICS{}, ngf * U);
+      write_pair_rows_part<K, CH, 0, K - NB, true, false>(job, jid, acc, coff, cok, job_z, X, ldx, F, rows,
+                                                          blockIdx.y == 0);
+      __builtin_amdgcn_sched_barrier(0);
+      pass2(ICS{}, ICK{}, 0, ngf);
+      tail_rows(ICS{}, ICK{}, ngf * U);
+    }
     write_pair_rows_part<K, CH, K - NB, K, false, true>(job, jid, acc, coff, cok, job_z, X, ldx, F, rows,
                                                         blockIdx.y == 0);
   };
@@ -456,9 +477,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
     if (nb >= 3) return run(std::integral_constant<int, 3>{});
   }
   if constexpr (K >= 2) {
-    if (nb >= 2) return run(std::integral_constant<int, 2>{});
+    if (nb >= 2 || MINNB >= 2) return run(std::integral_constant<int, 2>{});
   }
-  run(std::integral_constant<int, 1>{});
+  // (any NB gives the right sums — the coefficient lists hold zeros beyond an operator's reach —
+  // the choice only decides how many multiply-adds are skipped)
+  if constexpr (MINNB <= 1 || K < 2) run(std::integral_constant<int, 1>{});
 }
 
 // Measurement only (s3grl_plan_gather_traffic): the bytes the gather launch of a plan requests,
@@ -477,13 +500,28 @@ __global__ __launch_bounds__(256) void gather_traffic_kernel(
   const int tile_cols = packed ? kTile : (F <= 256 ? 256 : 512);
   const int tiles = (F + tile_cols - 1) / tile_cols;
   const unsigned long long chunks_row = (unsigned long long)((F + 3) / 4);   // 16-byte loads inside a row
+  // phase arithmetic of gather_packed_kernel: nb trailing operators reach the whole list; with nb >= 2
+  // the nA rows of the prefix are fetched twice (leading operators, then trailing ones)
+  int nb = 1, nA = 0;
+  if (packed) {
+    constexpr int U = 4;
+    const int ngf = cnt / U;
+    for (int i = K - 2; i >= 0; --i)
+      if (job_lim[(int64_t)jid * K + i] == job_lim[(int64_t)jid * K + K - 1] && nb == K - 1 - i) nb = K - i;
+    nb = min(nb, 3);
+    const int limA = nb < K ? job_lim[(int64_t)jid * K + (K - nb - 1)] : 0;
+    const int gA = min(ngf, (limA + U - 1) / U);
+    const bool tail_in_A = limA > ngf * U;
+    nA = tail_in_A ? cnt : gA * U;
+  }
+  const int twice = (packed && nb >= 2) ? nA : 0;
   unsigned long long feat = 0;
   if (packed) {
     for (int j = lane; j < cnt; j += 64) {
       const int id = ids[j];
       for (int t = 0; t < tiles; ++t) {
         const PackedHdr h = hdr[(int64_t)t * N + id];
-        feat += 16ull * (unsigned long long)(__popcll(h.m0) + __popcll(h.m1));
+        feat += (j < twice ? 32ull : 16ull) * (unsigned long long)(__popcll(h.m0) + __popcll(h.m1));
       }
     }
 #pragma unroll
@@ -492,26 +530,16 @@ __global__ __launch_bounds__(256) void gather_traffic_kernel(
     feat = 16ull * chunks_row * (unsigned long long)cnt;
   }
   if (lane != 0) return;
-  // coefficient entries read per tile: the packed kernel applies every operator to the phase-A
-  // prefix and only the last one beyond it (see gather_packed_kernel); the dense kernel all K
+  // coefficient entries read per tile: nb == 1: every operator on the prefix, the last one beyond it;
+  // nb >= 2: the leading operators on the prefix, the trailing ones everywhere; dense kernel: all K
   unsigned long long coef_entries = (unsigned long long)K * cnt;
-  if (packed) {
-    constexpr int U = 4;
-    const int ngf = cnt / U;
-    int nb = 1;   // trailing operators that reach the whole list, as gather_packed_kernel counts them
-    for (int i = K - 2; i >= 0; --i)
-      if (job_lim[(int64_t)jid * K + i] == job_lim[(int64_t)jid * K + K - 1] && nb == K - 1 - i) nb = K - i;
-    nb = min(nb, 3);
-    const int limA = nb < K ? job_lim[(int64_t)jid * K + (K - nb - 1)] : 0;
-    const int gA = min(ngf, (limA + U - 1) / U);
-    const bool tail_in_A = limA > ngf * U;
-    const int nA = tail_in_A ? cnt : gA * U;
-    coef_entries = (unsigned long long)K * nA + (unsigned long long)nb * (cnt - nA);
-  }
+  if (packed)
+    coef_entries = nb == 1 ? (unsigned long long)K * nA + (unsigned long long)(cnt - nA)
+                           : (unsigned long long)(K - nb) * nA + (unsigned long long)nb * cnt;
   const int nrow = job.node_b >= 0 ? 2 : 1;
   const int ncopy = job.mirror_row >= 0 ? 2 : 1;
-  atomicAdd(&out[0], 4ull * cnt * tiles);
-  atomicAdd(&out[1], packed ? 32ull * cnt * tiles : 0ull);
+  atomicAdd(&out[0], 4ull * (cnt + twice) * tiles);
+  atomicAdd(&out[1], packed ? 32ull * (cnt + twice) * tiles : 0ull);
   atomicAdd(&out[2], feat);
   atomicAdd(&out[3], 8ull * coef_entries * tiles);
   atomicAdd(&out[4], 4ull * nrow * ncopy * (K + 1) * (unsigned long long)(F + 1));
@@ -528,13 +556,24 @@ s3grl_status launch_packed_k(s3grl_context* ctx, const s3grl_plan* p, const s3gr
   const uint32_t data_bytes = (uint32_t)((f->pk_chunks + 1) * 16);
   // experiment hook: dynamic LDS per workgroup caps the resident waves (timing only)
   static const size_t lds_cap = getenv("S3GRL_GATHER_LDS") ? (size_t)atoi(getenv("S3GRL_GATHER_LDS")) : 0;
+  // every job's last two operators reach its whole list when sign_k - 1 >= the BFS depth (one hop for
+  // random-walk subgraphs)
+  const int depth = p->cfg.rw_m > 0 ? 1 : p->cfg.num_hops;
+  if (K >= 2 && K - 1 >= depth && masked) {
+    hipLaunchKernelGGL((gather_packed_kernel<K, true, (K >= 2 ? 2 : 1)>), dim3(gx, (unsigned)f->tiles),
+                       dim3(kWavesPerBlock * 64), lds_cap, ctx->stream, p->jobs, (int)p->njobs, p->c_ids, p->c_coef,
+                       p->job_z, p->job_lim, p->job_order, static_cast<const PackedHdr*>(f->pk_hdr),
+                       static_cast<const float4_t*>(f->pk_data), data_bytes, f->N, f->dense, f->ld, (int)f->F, rows);
+    S3GRL_HIP_TRY(hipGetLastError());
+    return S3GRL_OK;
+  }
   if (masked)
-    hipLaunchKernelGGL((gather_packed_kernel<K, true>), dim3(gx, (unsigned)f->tiles), dim3(kWavesPerBlock * 64),
+    hipLaunchKernelGGL((gather_packed_kernel<K, true, 1>), dim3(gx, (unsigned)f->tiles), dim3(kWavesPerBlock * 64),
                        lds_cap, ctx->stream, p->jobs, (int)p->njobs, p->c_ids, p->c_coef, p->job_z, p->job_lim,
                        p->job_order, static_cast<const PackedHdr*>(f->pk_hdr),
                        static_cast<const float4_t*>(f->pk_data), data_bytes, f->N, f->dense, f->ld, (int)f->F, rows);
   else
-    hipLaunchKernelGGL((gather_packed_kernel<K, false>), dim3(gx, (unsigned)f->tiles), dim3(kWavesPerBlock * 64),
+    hipLaunchKernelGGL((gather_packed_kernel<K, false, 1>), dim3(gx, (unsigned)f->tiles), dim3(kWavesPerBlock * 64),
                        0, ctx->stream, p->jobs, (int)p->njobs, p->c_ids, p->c_coef, p->job_z, p->job_lim,
                        p->job_order, static_cast<const PackedHdr*>(f->pk_hdr),
                        static_cast<const float4_t*>(f->pk_data), data_bytes, f->N, f->dense, f->ld, (int)f->F, rows);
