@@ -126,6 +126,7 @@ struct s3grl_graph {
   int32_t* r_indices = nullptr;    // [nnz], rows ascending in the new ids
   int32_t* new_of_old = nullptr;   // [N]
   int32_t* old_of_new = nullptr;   // [N]
+  int32_t deg_le2_from = 0;        // new ids >= this have at most two stored neighbours
   int32_t* r_fwd_indptr = nullptr;   // the degree-oriented rows of the relabelled graph (big graphs)
   int32_t* r_fwd_indices = nullptr;
   uint16_t* r_fwd_deg = nullptr;

@@ -59,6 +59,19 @@ __global__ void edge_keys_kernel(const int32_t* __restrict__ indptr, const int32
   keys[e] = ((uint64_t)(uint32_t)new_of_old[lo] << 32) | (uint64_t)(uint32_t)new_of_old[indices[e]];
 }
 
+// first position of the sorted node keys whose degree is <= d (keys ascend in max_degree - degree)
+__global__ void first_degree_le_kernel(const uint64_t* __restrict__ sorted, int64_t N, uint32_t max_degree,
+                                       uint32_t d, int64_t* __restrict__ out) {
+  if (threadIdx.x || blockIdx.x) return;
+  const uint64_t want = (uint64_t)(max_degree >= d ? max_degree - d : 0) << 32;
+  int64_t lo = 0, hi = N;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (sorted[mid] < want) lo = mid + 1; else hi = mid;
+  }
+  out[0] = lo;
+}
+
 __global__ void low_words_kernel(const uint64_t* __restrict__ keys, int64_t n, int32_t* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (int32_t)(keys[i] & 0xffffffffull);
@@ -161,6 +174,12 @@ s3grl_status build_degree_order(s3grl_context* ctx, s3grl_graph* g) {
   hipLaunchKernelGGL(perm_kernel, dim3(gn), dim3(256), 0, ctx->stream, keys_b, g->indptr, N, g->old_of_new,
                      g->new_of_old, static_cast<int32_t*>(dn));
   S3GRL_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(first_degree_le_kernel, dim3(1), dim3(1), 0, ctx->stream, keys_b, N, (uint32_t)g->max_degree, 2u,
+                     ctx->d_scalars);
+  S3GRL_HIP_TRY(hipGetLastError());
+  S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  g->deg_le2_from = (int32_t)ctx->h_scalars[0];
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, static_cast<int32_t*>(dn), N, static_cast<int64_t*>(off),
                                    static_cast<int64_t*>(ws)));
   hipLaunchKernelGGL(offsets_to_i32_kernel, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, ctx->stream,

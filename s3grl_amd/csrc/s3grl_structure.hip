@@ -567,7 +567,7 @@ __global__ __launch_bounds__(T) void link_kernel(
     unsigned long long* __restrict__ tot_support, unsigned long long* __restrict__ tot_vol,
     char* __restrict__ scratch, int64_t scratch_stride, unsigned long long* __restrict__ dbg,
     HopSampling smp, const int32_t* __restrict__ stash, int slot,
-    const int32_t* __restrict__ old_of_new, const int32_t* __restrict__ new_of_old) {
+    const int32_t* __restrict__ old_of_new, const int32_t* __restrict__ new_of_old, int lo_id) {
   extern __shared__ uint32_t smem[];
   // the caller's id of an internal id (the graph is walked in its degree order, s3grl_relabel.hip)
   auto ext = [&](int v) -> int { return old_of_new ? old_of_new[v] : v; };
@@ -816,6 +816,25 @@ __global__ __launch_bounds__(T) void link_kernel(
     }
     __syncthreads();
   }
+  // The graph is walked in descending degree order (lo_id >= 0: ids >= lo_id have at most two stored
+  // neighbours), so the rows of a hop are sorted by length and its leaves form its tail.  The tail of
+  // the LAST hop — a fifth of a PubMed subgraph's rows — is walked with one lane per row (both
+  // neighbours in the lane's two slots, no tail loop) instead of G; two terms add up to the same
+  // bits either way.
+  int lo_begin = n;
+  if (lo_id >= 0 && nlev >= 2 && !rw_raw) {
+    int lo = lvl_end[nlev - 2], hi = n;   // ascending ids inside the hop
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (list[mid] < lo_id) lo = mid + 1; else hi = mid;
+    }
+    lo_begin = lo;
+  }
+  auto walk_split = [&](int limit, auto visit, auto commit) __attribute__((always_inline)) {
+    const int a_end = min(limit, lo_begin);
+    walk_rows<T, G, 2>(0, a_end, list, indptr, indices, hub, visit, commit);
+    if (limit > a_end) walk_rows<T, 1, 2>(a_end, limit, list, indptr, indices, nullptr, visit, commit);
+  };
   const int npairs = (R + 1) / 2;
   for (int pr = 0; pr < npairs; ++pr) {
     const int64_t jid = job_off[l] + pr;
@@ -911,8 +930,8 @@ __global__ __launch_bounds__(T) void link_kernel(
         continue;
       }
       const bool build_bm = use_bm && !bm_ready && limit == n;   // first pass over all rows
-      walk_rows<T, G, 2>(
-          0, limit, list, indptr, indices, hub,
+      walk_split(
+          limit,
           [&](RowAcc& a, int v, int u, bool valid) {
             bool on;
             float2 sv;
@@ -986,8 +1005,8 @@ __global__ __launch_bounds__(T) void link_kernel(
     } else {  // last operator: degree and sum of every reachable row in one pass over its CSR row
       const int i = K - 1;
       int edges_pass = 0;
-      walk_rows<T, G, 2>(
-          0, last_rows, list, indptr, indices, hub,
+      walk_split(
+          last_rows,
           [&](RowAcc& a, int v, int u, bool valid) {
             bool member, on;
             float2 sv;
@@ -1513,6 +1532,7 @@ struct LinkArgs {
   int bm_grid;
   int big_need;   // LDS need of the biggest link of the class whose matrix / columns sit in HBM
   const int32_t *old_of_new, *new_of_old;   // non-null: the graph is walked in its degree order
+  int lo_id;                                // then: ids >= lo_id have at most two stored neighbours (else -1)
 };
 
 // One-hop full-reach classes (link_full_kernel).  Small classes run one wavefront per link (no
@@ -1565,7 +1585,7 @@ s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t 
                      reinterpret_cast<unsigned long long*>(a.tot_edges),
                      reinterpret_cast<unsigned long long*>(a.tot_support),
                      reinterpret_cast<unsigned long long*>(a.tot_vol), a.scratch, a.scratch_stride,
-                     a.dbg, a.smp, a.stash, a.slot, a.old_of_new, a.new_of_old);
+                     a.dbg, a.smp, a.stash, a.slot, a.old_of_new, a.new_of_old, a.lo_id);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -1747,7 +1767,8 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
              job_off, coef_off, mirror_of, c_ids, c_coef, jobs, job_z, job_lim, row_nodes, lvl, tot_edges,
              tot_support, tot_vol, scratch, scratch_stride,
              getenv("S3GRL_DEBUG_STAMPS") ? reinterpret_cast<unsigned long long*>(ctx->d_scalars + 16) : nullptr,
-             smp, stash, slot, e_cap, nullptr, 0, 0, 0, old_of_new, new_of_old};
+             smp, stash, slot, e_cap, nullptr, 0, 0, 0, old_of_new, new_of_old,
+             (old_of_new && !getenv("S3GRL_NO_LEAF_WALK")) ? g->deg_le2_from : -1};
   // the class whose bit matrix does not fit LDS: one slice per resident workgroup of a persistent grid
   if (class_count_host[kFullBig] > 0) {
     // slice = list of found edges (uint32, at most ecap / 2) + CSR columns (uint16 x ecap) of the
