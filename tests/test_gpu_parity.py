@@ -1239,6 +1239,30 @@ def test_degree_order_is_invisible(eng, monkeypatch, name, hops, mode):
     G.close()
 
 
+@pytest.mark.parametrize("name,hops", [("rand300", 2), ("cora", 3), ("star_iso", 2)])
+def test_leaf_tail_walk_changes_no_bit(eng, monkeypatch, name, hops):
+    """The last hop's rows of at most two neighbours are walked with one lane per row instead of
+    four (contiguous in the degree order); S3GRL_NO_LEAF_WALK walks them like the rest.  Two terms
+    add up to the same bits either way."""
+    import torch
+
+    g = load_extract(name)
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = np.random.default_rng(9).standard_normal((n, 17))
+    G = eng.graph(A)
+    f = eng.features(X)
+    L = eng.links(g["links"].T)
+    for K in (2, 3, 5):
+        monkeypatch.delenv("S3GRL_NO_LEAF_WALK", raising=False)
+        a = eng.precompute(G, f, L, mode="pos_plus", num_hops=hops, sign_k=K).rows.clone()
+        monkeypatch.setenv("S3GRL_NO_LEAF_WALK", "1")
+        b = eng.precompute(G, f, L, mode="pos_plus", num_hops=hops, sign_k=K).rows
+        assert torch.equal(a, b)
+    monkeypatch.delenv("S3GRL_NO_LEAF_WALK", raising=False)
+    G.close()
+
+
 @pytest.mark.parametrize("name,hops", [("rand300", 2), ("cora", 3), ("usair", 1)])
 @pytest.mark.parametrize("mode", ["pos", "pos_plus"])
 def test_direct_map_flavour_equals_bitmap_flavour(eng, monkeypatch, name, hops, mode):
