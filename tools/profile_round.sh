@@ -27,7 +27,7 @@ for wl in pubmed_pos_k3 pubmed_pos_k3_dense pubmed_sop_k3; do
   timeout -k 10 420 python3 bench.py --workload $wl --collect-pmc > $O/bench_$wl.json 2> $O/bench_$wl.err || rc=1
 done
 for wl in pubmed_pos_k5 collab_pos_k3 cora_posplus_k3 usair_pos_k2; do
-  timeout -k 10 300 python3 bench.py --workload $wl --no-pmc > $O/bench_$wl.json 2> $O/bench_$wl.err || rc=1
+  timeout -k 10 300 python3 bench.py --workload $wl > $O/bench_$wl.json 2> $O/bench_$wl.err || rc=1
 done
 echo "profile_round rc=$rc"; ls $O
 exit $rc
