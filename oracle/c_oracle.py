@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE ONLY — ctypes binding of oracle/s3grl_oracle_c.c (the plain-C, OpenMP
 restatement).  Same rules as the rest of `oracle/`: importable from tests/, smoke() and bench.py's
-cpu_baseline leg only.  `build()` compiles it with gcc into oracle/_build/ (git-ignored)."""
+cpu_baseline leg only.  `build()` runs oracle/Makefile (gcc) into oracle/_build/ (git-ignored)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -18,20 +18,23 @@ _lib = None
 
 
 def build(force=False):
-    if LIB.exists() and not force and LIB.stat().st_mtime >= SRC.stat().st_mtime:
-        return LIB
-    LIB.parent.mkdir(exist_ok=True)
-    subprocess.run(["gcc", "-O2", "-std=c11", "-fopenmp", "-fPIC", "-shared", "-Wall", "-Wextra",
-                    str(SRC), "-o", str(LIB), "-lm"], check=True)
+    """`make -C oracle` (the committed recipe, oracle/Makefile)."""
+    if force and LIB.exists():
+        LIB.unlink()
+    subprocess.run(["make", "-s", "-C", str(HERE), "all"], check=True)
     return LIB
 
 
 def lib():
     global _lib
     if _lib is None:
-        if not LIB.exists():
+        # S3GRL_ORACLE_C_LIB: another build of the same source (the sanitized one of `make asan`,
+        # tests/test_oracle_sanitized.py)
+        path = os.environ.get("S3GRL_ORACLE_C_LIB")
+        if not path:
             build()
-        _lib = C.CDLL(str(LIB))
+            path = str(LIB)
+        _lib = C.CDLL(path)
         _lib.s3grl_oracle_c_extract.restype = C.c_int64
     return _lib
 

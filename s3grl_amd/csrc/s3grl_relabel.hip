@@ -19,6 +19,7 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 
 #include "s3grl_internal.hpp"
 #include "s3grl_device.hpp"
@@ -132,6 +133,23 @@ __global__ __launch_bounds__(kSortBlock) void sort_hops_kernel(const int64_t* __
   }
 }
 
+// segment bounds of the (link, hop) pieces of the exported node lists, for the segmented sort below:
+// seg[l * kMaxLevels + d] = where hop d of link l starts, seg[L * kMaxLevels] = Σn
+__global__ void hop_segments_kernel(const int64_t* __restrict__ node_off, const int32_t* __restrict__ lvl,
+                                    int64_t L, int64_t* __restrict__ seg) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > L * kMaxLevels) return;
+  if (i == L * kMaxLevels) {
+    seg[i] = node_off[L];
+    return;
+  }
+  const int64_t l = i / kMaxLevels;
+  const int d = (int)(i - l * kMaxLevels);
+  const int64_t o = node_off[l];
+  const int n = (int)(node_off[l + 1] - o);
+  seg[i] = o + (d == 0 ? 0 : min(lvl[l * kMaxLevels + d - 1], n));
+}
+
 }  // namespace
 
 s3grl_status build_degree_order(s3grl_context* ctx, s3grl_graph* g) {
@@ -212,9 +230,37 @@ s3grl_status launch_translate_links(s3grl_context* ctx, const s3grl_graph* g, co
 s3grl_status launch_sort_hops(s3grl_context* ctx, const s3grl_plan* p, int32_t* nodes) {
   if (p->L == 0) return S3GRL_OK;
   const int W = (int)((p->graph->num_nodes + 31) / 32);
-  hipLaunchKernelGGL(sort_hops_kernel, dim3((unsigned)p->L), dim3(kSortBlock), (size_t)W * 4, ctx->stream,
-                     p->node_off, p->lvl, W, nodes);
+  const bool force_seg = getenv("S3GRL_FORCE_SEGSORT") != nullptr;   // test hook
+  if ((size_t)W * 4 <= 65536 && !force_seg) {
+    hipLaunchKernelGGL(sort_hops_kernel, dim3((unsigned)p->L), dim3(kSortBlock), (size_t)W * 4, ctx->stream,
+                       p->node_off, p->lvl, W, nodes);
+    S3GRL_HIP_TRY(hipGetLastError());
+    return S3GRL_OK;
+  }
+  // Graphs whose N-bit bitmap passes the default 64 KiB of dynamic LDS (num_nodes > 524 288; one-hop
+  // plans have no node limit): a segmented radix sort over the (link, hop) pieces, independent of N.
+  const int64_t n = p->stats.extracted_nodes;
+  if (n == 0) return S3GRL_OK;
+  const int64_t nseg = p->L * kMaxLevels;
+  Transient tmp{ctx, {}};
+  void *seg = nullptr, *sorted = nullptr, *rt = nullptr;
+  S3GRL_TRY(ctx->arena.alloc((size_t)(nseg + 1) * 8, &seg));
+  tmp.ptrs.push_back(seg);
+  S3GRL_TRY(ctx->arena.alloc((size_t)n * 4, &sorted));
+  tmp.ptrs.push_back(sorted);
+  int64_t* so = static_cast<int64_t*>(seg);
+  hipLaunchKernelGGL(hop_segments_kernel, dim3((unsigned)((nseg + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
+                     p->node_off, p->lvl, p->L, so);
   S3GRL_HIP_TRY(hipGetLastError());
+  size_t bytes = 0;
+  S3GRL_HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, bytes, nodes, static_cast<int32_t*>(sorted), (size_t)n,
+                                                   (unsigned)nseg, so, so + 1, 0, 32, ctx->stream));
+  S3GRL_TRY(ctx->arena.alloc(std::max<size_t>(bytes, 16), &rt));
+  tmp.ptrs.push_back(rt);
+  S3GRL_HIP_TRY(rocprim::segmented_radix_sort_keys(rt, bytes, nodes, static_cast<int32_t*>(sorted), (size_t)n,
+                                                   (unsigned)nseg, so, so + 1, 0, 32, ctx->stream));
+  S3GRL_HIP_TRY(hipMemcpyAsync(nodes, sorted, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));   // tmp is released on return
   return S3GRL_OK;
 }
 

@@ -4,7 +4,7 @@
 
 The reference's own `utils.py` / `sgrl_link_pred.py` can keep calling the drop-in operators
 (`s3grl_amd.tuned_SIGN`) unchanged; these twins exist for callers that do not carry PyG around —
-the harness, the tests, the benchmark — and restate the decision table line for line:
+the harness, the tests, the benchmark — and hold the same decision table (`_FLOW_TABLE`):
 
     sign_kwargs, powers_of_A, optimize_sign, sign_type == 'hybrid'      -> PoS + SoP, SoP x2..xK
                                                                           appended as x{K+1}..x{2K-1}
@@ -37,19 +37,47 @@ class GlobalOperators(list):
         super().__init__([None] * int(sign_k))
 
 
-def _hybrid_combine(sup_list, sop_list, sign_k):
-    """utils.py:472-480: the PoS elements keep their keys and gain x{K+1}..x{2K-1} = SoP x2..xK."""
-    if isinstance(sup_list, LinkDataList) and isinstance(sop_list, LinkDataList) \
-            and len(sup_list._chunks) == 1 and len(sop_list._chunks) == 1:
-        rows_p, ptr, y = sup_list._chunks[0]
-        rows_s = sop_list._chunks[0][0]
+def _hybrid_combine(pos_part, sop_part, sign_k):
+    """Hybrid elements = the PoS element plus the SoP operators 2..K under the keys x{K+1}..x{2K-1}
+    (reference utils.py:472-480).  Two lazy lists: one `cat` of their collated tensors."""
+    if isinstance(pos_part, LinkDataList) and isinstance(sop_part, LinkDataList) \
+            and len(pos_part._chunks) == 1 and len(sop_part._chunks) == 1:
+        rows_p, ptr, y = pos_part._chunks[0]
+        rows_s = sop_part._chunks[0][0]
         return LinkDataList([(torch.cat([rows_p, rows_s[:, 2:, :]], dim=1), ptr, y)], 2 * sign_k - 1)
-    combined = []
-    for sup_data, sop_data in zip(sup_list, sop_list):
-        for k in range(sign_k + 1, sign_k * 2):
-            sup_data[f'x{k}'] = sop_data[f'x{k - sign_k + 1}']
-        combined.append(sup_data)
-    return combined
+    merged = []
+    for elem, extra in zip(pos_part, sop_part):
+        for j in range(2, sign_k + 1):
+            elem[f'x{sign_k + j - 1}'] = extra[f'x{j}']
+        merged.append(elem)
+    return merged
+
+
+# The decision table of reference utils.py:454-496 as data.  A row matches when the caller did /
+# did not hand in global operators, and — where the column is not None — on sign_type and on the
+# truthiness of k_heuristic; first match wins.
+#            global operators   sign_type   k_heuristic   flow
+_FLOW_TABLE = ((True,            "hybrid",   None,         "hybrid"),
+               (True,            None,       None,         "sop"),
+               (False,           None,       False,        "pos"),
+               (False,           None,       True,         "pos_plus"))
+
+
+def select_flow(sign_kwargs, powers_of_A):
+    """Name of the optimised flow the reference's dispatch would take, or NotImplementedError for the
+    flows that are not part of the engine (per-link SIGN + SEAL graphs, plain SEAL)."""
+    if not sign_kwargs:
+        raise NotImplementedError("the SEAL flow without sign_kwargs (labelled subgraphs for the MPNN "
+                                  "baselines, reference utils.py:556-573) is not part of the MI355X engine")
+    if not sign_kwargs['optimize_sign']:
+        raise NotImplementedError("optimize_sign=False (per-link SIGN + SEAL graphs, reference "
+                                  "utils.py:497-550) is not part of the MI355X engine")
+    have_ops = bool(powers_of_A)
+    for need_ops, sign_type, heuristic, flow in _FLOW_TABLE:
+        if need_ops == have_ops and sign_type in (None, sign_kwargs['sign_type']) \
+                and heuristic in (None, bool(sign_kwargs['k_heuristic'])):
+            return flow
+    raise NotImplementedError("No matching configuration for model data prep found. Please check code.")
 
 
 def extract_enclosing_subgraphs(link_index, A, x, y, num_hops, node_label='drnl',
@@ -58,35 +86,25 @@ def extract_enclosing_subgraphs(link_index, A, x, y, num_hops, node_label='drnl'
                                 data=None):
     """Reference utils.py:446-554, same positional signature.  Returns the per-link list (a lazy
     `LinkDataList`, see s3grl_amd.tuned_SIGN)."""
-    if sign_kwargs:
-        if powers_of_A and sign_kwargs['optimize_sign'] and sign_kwargs['sign_type'] == 'hybrid':
-            sign_k = sign_kwargs['sign_k']
-            print("Prepping PoS (plus) data")
-            sup_data_list = OptimizedSignOperations.get_PoS_prepped_ds(link_index, num_hops, A, ratio_per_hop,
-                                                                       max_nodes_per_hop, directed, A_csc, x, y,
-                                                                       sign_kwargs, rw_kwargs)
-            if sign_k == 1:
-                return sup_data_list
-            print("Prepping SoP data")
-            sop_data_list = OptimizedSignOperations.get_SoP_prepped_ds(powers_of_A, link_index, A, x, y)
-            return _hybrid_combine(sup_data_list, sop_data_list, sign_k)
-        elif powers_of_A and sign_kwargs['optimize_sign']:
-            return OptimizedSignOperations.get_SoP_prepped_ds(powers_of_A, link_index, A, x, y)
-        elif not powers_of_A and sign_kwargs['optimize_sign'] and not sign_kwargs['k_heuristic']:
-            return OptimizedSignOperations.get_PoS_prepped_ds(link_index, num_hops, A, ratio_per_hop,
-                                                              max_nodes_per_hop, directed, A_csc, x, y,
-                                                              sign_kwargs, rw_kwargs)
-        elif not powers_of_A and sign_kwargs['optimize_sign'] and sign_kwargs['k_heuristic']:
-            return OptimizedSignOperations.get_PoS_Plus_prepped_ds(link_index, num_hops, A, ratio_per_hop,
-                                                                   max_nodes_per_hop, directed, A_csc, x, y,
-                                                                   sign_kwargs, rw_kwargs)
-        elif not sign_kwargs['optimize_sign']:
-            raise NotImplementedError("optimize_sign=False (per-link SIGN + SEAL graphs, reference "
-                                      "utils.py:497-550) is not part of the MI355X engine")
-        else:
-            raise NotImplementedError("No matching configuration for model data prep found. Please check code.")
-    raise NotImplementedError("the SEAL flow without sign_kwargs (labelled subgraphs for the MPNN "
-                              "baselines, reference utils.py:556-573) is not part of the MI355X engine")
+    flow = select_flow(sign_kwargs, powers_of_A)
+    ops = OptimizedSignOperations
+
+    def subgraph_flow(operator):          # the PoS-shaped operators share one argument list
+        return operator(link_index, num_hops, A, ratio_per_hop, max_nodes_per_hop, directed, A_csc, x, y,
+                        sign_kwargs, rw_kwargs)
+
+    if flow == "pos":
+        return subgraph_flow(ops.get_PoS_prepped_ds)
+    if flow == "pos_plus":
+        return subgraph_flow(ops.get_PoS_Plus_prepped_ds)
+    if flow == "sop":
+        return ops.get_SoP_prepped_ds(powers_of_A, link_index, A, x, y)
+    # hybrid: plain PoS (never PoS Plus) + SoP; a single operator has nothing to append
+    pos_part = subgraph_flow(ops.get_PoS_prepped_ds)
+    if sign_kwargs['sign_k'] == 1:
+        return pos_part
+    return _hybrid_combine(pos_part, ops.get_SoP_prepped_ds(powers_of_A, link_index, A, x, y),
+                           sign_kwargs['sign_k'])
 
 
 def train_graph(edge_index, num_nodes, edge_weight=None):
@@ -97,25 +115,24 @@ def train_graph(edge_index, num_nodes, edge_weight=None):
     return ssp.csr_matrix((w, (ei[0], ei[1])), shape=(int(num_nodes), int(num_nodes)))
 
 
+def _shuffled_share(edges, percent):
+    """A random `percent` of the columns of `edges` [2, n], in random order, drawn from numpy's
+    GLOBAL generator — one `np.random.permutation(n)` per list, like the reference, so a seeded run
+    sees the same links in the same order."""
+    n = edges.size(1)
+    keep = np.random.permutation(n)[:int(percent / 100 * n)]
+    return edges[:, keep]
+
+
 def pos_neg_edges(split, split_edge, percent=100):
     """utils.py:637-659 for splits that carry pre-sampled negatives (`do_edge_split` always writes
-    'edge_neg'): [2, P] positives, [2, Q] negatives, permuted — and cut to `percent` — with numpy's
-    global generator exactly like the reference (`np.random.permutation`, pos first, then neg; the
-    shuffle happens at percent = 100 too)."""
-    pos_edge = torch.as_tensor(split_edge[split]['edge']).t()
+    'edge_neg'): [2, P] positives, [2, Q] negatives; positives are drawn first, then negatives, and
+    the shuffle happens at percent = 100 too."""
     if 'edge_neg' not in split_edge['train']:
         raise NotImplementedError("on-the-fly negative sampling (PyG negative_sampling) is the "
                                   "producer's job: pass split_edge with 'edge_neg'")
-    neg_edge = torch.as_tensor(split_edge[split]['edge_neg']).t()
-    num_pos = pos_edge.size(1)
-    perm = np.random.permutation(num_pos)
-    perm = perm[:int(percent / 100 * num_pos)]
-    pos_edge = pos_edge[:, perm]
-    num_neg = neg_edge.size(1)
-    perm = np.random.permutation(num_neg)
-    perm = perm[:int(percent / 100 * num_neg)]
-    neg_edge = neg_edge[:, perm]
-    return pos_edge, neg_edge
+    lists = [torch.as_tensor(split_edge[split][key]).t() for key in ('edge', 'edge_neg')]
+    return tuple(_shuffled_share(e, percent) for e in lists)
 
 
 def make_sign_kwargs(*, sign_k, sign_type, optimize_sign=True, k_heuristic=0,

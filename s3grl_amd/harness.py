@@ -44,15 +44,31 @@ class SIGNNetTwin(nn.Module):
         return self.link_pred_mlp(z).view(-1)
 
 
-def batch_slices(row_ptr, link_ids):
-    """Device-side gather of the rows of a set of links: (row index [ΣR_b], local row_ptr [B+1])."""
+def batch_slices(row_ptr, link_ids, total=None):
+    """Device-side gather of the rows of a set of links: (row index [ΣR_b], local row_ptr [B+1]).
+    `total` = ΣR_b when the caller knows it on the host (`RowCounts`): then nothing here waits for
+    the device; without it the size is read back (one sync)."""
     start, end = row_ptr[link_ids], row_ptr[link_ids + 1]
     cnt = end - start
     local = torch.zeros(link_ids.numel() + 1, dtype=torch.int64, device=row_ptr.device)
     local[1:] = torch.cumsum(cnt, 0)
-    idx = torch.repeat_interleave(start - local[:-1], cnt) + torch.arange(
-        int(local[-1]), device=row_ptr.device)
+    if total is None:
+        total = int(local[-1])
+    idx = torch.repeat_interleave(start - local[:-1], cnt, output_size=total) + torch.arange(
+        total, device=row_ptr.device)
     return idx, local
+
+
+class RowCounts:
+    """Rows per link on the HOST, fetched once per dataset: the loader draws its mini-batches on the
+    host (like the reference's DataLoader) and knows every batch's row total without asking the
+    device — no host sync per mini-batch (the reference has one per batch, models.py:341)."""
+
+    def __init__(self, row_ptr):
+        self.counts = (row_ptr[1:] - row_ptr[:-1]).cpu()
+
+    def total(self, link_ids_host):
+        return int(self.counts[link_ids_host].sum())
 
 
 def auc_score(scores, labels):
@@ -81,14 +97,16 @@ def train_and_evaluate(train, test, *, k_heuristic=0, k_pool_strategy="", hidden
     opt = torch.optim.Adam(model.parameters(), lr=lr)
     L = y.numel()
     yf = y.float()
+    counts = RowCounts(row_ptr)
     for _ in range(epochs):
         model.train()
-        perm = torch.randperm(L, device=dev)
+        perm = torch.randperm(L)
         for b in range(0, L - 1, batch_size):
-            ids = perm[b:b + batch_size]
-            if ids.numel() < 2:
+            ids_h = perm[b:b + batch_size]
+            if ids_h.numel() < 2:
                 continue
-            idx, local = batch_slices(row_ptr, ids)
+            ids = ids_h.to(dev, non_blocking=True)
+            idx, local = batch_slices(row_ptr, ids, counts.total(ids_h))
             loss = nn.functional.binary_cross_entropy_with_logits(model(rows[idx], local), yf[ids])
             opt.zero_grad()
             loss.backward()
@@ -96,9 +114,11 @@ def train_and_evaluate(train, test, *, k_heuristic=0, k_pool_strategy="", hidden
     model.eval()
     rows_t, ptr_t, y_t = test
     out = []
+    counts_t = RowCounts(ptr_t)
     with torch.no_grad():
         for b in range(0, y_t.numel(), 1024):
-            ids = torch.arange(b, min(b + 1024, y_t.numel()), device=dev)
-            idx, local = batch_slices(ptr_t, ids)
+            ids_h = torch.arange(b, min(b + 1024, y_t.numel()))
+            ids = ids_h.to(dev, non_blocking=True)
+            idx, local = batch_slices(ptr_t, ids, counts_t.total(ids_h))
             out.append(model(rows_t[idx], local))
     return auc_score(torch.cat(out), y_t), model

@@ -94,7 +94,7 @@ def _all_gather(out, inp, group, async_op=False):
 
 def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, group=None, gather=True,
                        rows_per_link=None, chunks=1, row_shape=None, dtype=torch.float32,
-                       device=None, timers=None, collective_at_world1=False):
+                       device=None, timers=None, collective_at_world1=False, reuse_buffers=False):
     """Shard `link_index` ([2, L]) over the ranks and (when `gather`) reassemble the whole result
     on every rank.
 
@@ -107,6 +107,11 @@ def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, grou
     shard.  `timers` (dict, optional) receives host-side timestamps for the benchmark.
     `collective_at_world1`: run the pieces / in-place all-gather / compaction path even on a
     one-rank group (a test hook: it is how the collective code meets real RCCL on a one-GPU box).
+    `reuse_buffers` (fixed flavour): the returned `rows` live in a process-wide buffer that the NEXT
+    call with the same shape overwrites — for a benchmark loop that must not allocate GBs per step.
+    By default the caller owns what it gets back (the reference calls pos then neg per split with
+    equal counts, sgrl_link_pred.py:195-204: both results must stay valid); only the padded
+    all-gather slots are ever shared between calls.
     """
     li = torch.as_tensor(link_index)
     L = int(li.shape[1])
@@ -114,7 +119,8 @@ def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, grou
     lo, hi = b[rank], b[rank + 1]
     if rows_per_link is not None:
         return _fixed(compute, li, b, rank, world_size, cost, group, gather, int(rows_per_link),
-                      max(int(chunks), 1), tuple(row_shape), dtype, device, timers, collective_at_world1)
+                      max(int(chunks), 1), tuple(row_shape), dtype, device, timers, collective_at_world1,
+                      bool(reuse_buffers))
     rows, row_ptr = compute(li[:, lo:hi])
     if not gather or world_size == 1:
         return rows, row_ptr, (lo, hi)
@@ -143,8 +149,8 @@ def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, grou
 
 
 class _Buffers:
-    """Reused across calls (a benchmark step must not allocate GBs): final rows + the padded
-    all-gather slots, two of them so that piece c+1 is computed while piece c is in flight."""
+    """Reused across calls: the padded all-gather slots (two, so that piece c+1 is computed while
+    piece c is in flight) and — only with `reuse_buffers=True` — the rows handed back."""
     cache = {}
 
     @classmethod
@@ -160,18 +166,25 @@ class _Buffers:
         cls.cache.clear()
 
 
+def _result(key, shape, dtype, device, reuse):
+    """Memory of a returned tensor: the caller's own unless it asked for the shared buffer."""
+    if reuse:
+        return _Buffers.get(key, shape, dtype, device)
+    return torch.empty(shape, dtype=dtype, device=device)
+
+
 def _fixed(compute, li, b, rank, world, cost, group, gather, rpl, chunks, row_shape, dtype, device,
-           timers, collective_at_world1=False):
+           timers, collective_at_world1=False, reuse=False):
     L = int(li.shape[1])
     lo, hi = b[rank], b[rank + 1]
     row_ptr = torch.arange(0, rpl * L + 1, rpl, dtype=torch.int64, device=device)
     if not gather or (world == 1 and not collective_at_world1):
-        rows = _Buffers.get(("local", rank), (rpl * (hi - lo),) + row_shape, dtype, device)
+        rows = _result(("local", rank), (rpl * (hi - lo),) + row_shape, dtype, device, reuse)
         compute(li[:, lo:hi], rows)
         return rows, row_ptr[lo:hi + 1] - rpl * lo, (lo, hi)
     # piece c of rank r = links [pb[r][c], pb[r][c+1]); every rank derives every rank's bounds
     pb = [chunk_bounds(b[r], b[r + 1], chunks, cost) for r in range(world)]
-    final = _Buffers.get(("final", rank), (rpl * L,) + row_shape, dtype, device)
+    final = _result(("final", rank), (rpl * L,) + row_shape, dtype, device, reuse)
     works = [None] * chunks
     slots = [None] * chunks
     pmaxes = [rpl * max(pb[r][c + 1] - pb[r][c] for r in range(world)) for c in range(chunks)]

@@ -159,7 +159,20 @@ def clear_cache(trim=True):
 # the copy, and a pageable copy runs at a fifth of the DMA rate.  So page-locked blocks are pooled
 # and handed out through an ALIAS tensor with a storage object of its own: the block is reused only
 # once that storage has died, i.e. when the list and every view ever cut from it are gone.
+# The tensors handed back ARE page-locked (the whole dataset stays locked while the caller keeps it):
+# the pool never holds more than `_pinned_cap()` bytes — S3GRL_PINNED_CAP_BYTES, default a quarter of
+# the host's RAM — and results beyond that are copied into ordinary pageable memory instead.
 _pool = []     # [base pinned tensor, StorageWeakRef of the alias handed out last (or None)]
+
+
+def _pinned_cap():
+    env = os.environ.get("S3GRL_PINNED_CAP_BYTES")
+    if env:
+        return int(env)
+    try:
+        return os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") // 4
+    except (ValueError, OSError):
+        return 16 << 30
 
 
 def _alloc_pinned(n):
@@ -176,8 +189,16 @@ def _staging(n):
             if best is None or ent[0].numel() < best[0].numel():
                 best = ent
     if best is None:
-        cap = max(int(n), 1)
-        cap = 1 << (cap - 1).bit_length() if cap < (1 << 28) else -(-cap // (1 << 26)) * (1 << 26)
+        cap = -(-max(int(n), 1) // (1 << 22)) * (1 << 22)     # 16 MiB steps: at most that much over-locked
+        held = sum(ent[0].numel() for ent in _pool) * 4
+        if held + cap * 4 > _pinned_cap():        # make room from blocks nobody refers to any more
+            for ent in [e for e in _pool if e[1] is None or e[1].expired()]:
+                _pool.remove(ent)
+                held -= ent[0].numel() * 4
+                if held + cap * 4 <= _pinned_cap():
+                    break
+        if held + cap * 4 > _pinned_cap():
+            return None                           # the caller falls back to pageable memory
         try:
             base = _alloc_pinned(cap)
         except RuntimeError:                      # page-locking refused
@@ -196,7 +217,8 @@ def _staging(n):
 
 def _to_host(rows):
     """D2H into pooled page-locked memory (2.6 GB of PubMed rows: 0.05 s; a pageable `.cpu()`
-    0.27 s), handed over without a second copy."""
+    0.27 s), handed over without a second copy — the result is a PINNED tensor.  Beyond the cap of
+    `_pinned_cap()` bytes (or when page-locking is refused) it is an ordinary pageable copy."""
     stage = _staging(rows.numel())
     if stage is None:
         return rows.cpu()

@@ -134,6 +134,23 @@ def test_staging_pool_recycles_only_dead_blocks(monkeypatch):
     ts._pool.clear()
 
 
+def test_staging_pool_is_capped(monkeypatch):
+    """Results beyond S3GRL_PINNED_CAP_BYTES are not page-locked (the caller gets a pageable copy);
+    dead blocks make room first."""
+    monkeypatch.setattr(ts, "_alloc_pinned", lambda n: torch.empty(n, dtype=torch.float32))
+    monkeypatch.setenv("S3GRL_PINNED_CAP_BYTES", str(40 << 20))      # two 16 MiB blocks fit, three do not
+    ts._pool.clear()
+    a = ts._staging(10)
+    b = ts._staging(10)
+    assert a is not None and b is not None and len(ts._pool) == 2
+    assert ts._staging(10) is None                     # both alive, a third block would pass the cap
+    del a, b
+    c = ts._staging(10 + (4 << 20))                    # a 32 MiB block: both dead blocks are dropped for it
+    assert c is not None and len(ts._pool) == 1 and ts._pool[0][0].numel() * 4 == 32 << 20
+    del c
+    ts._pool.clear()
+
+
 def test_upload_cache_detects_new_and_mutated_inputs(monkeypatch):
     import scipy.sparse as ssp
 

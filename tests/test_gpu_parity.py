@@ -1239,6 +1239,33 @@ def test_degree_order_is_invisible(eng, monkeypatch, name, hops, mode):
     G.close()
 
 
+@pytest.mark.parametrize("name,hops", [("rand300", 2), ("cora", 3), ("usair", 1)])
+def test_export_segmented_sort_flavour(eng, monkeypatch, name, hops):
+    """s3grl_plan_export_subgraphs restores "ascending id inside a hop" through an N-bit LDS bitmap
+    on small graphs and through a segmented radix sort (independent of num_nodes) on graphs whose
+    bitmap passes 64 KiB; S3GRL_FORCE_SEGSORT runs the second flavour here: same lists."""
+    import torch
+
+    g = load_extract(name)
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    G = eng.graph(A)
+    L = eng.links(g["links"].T)
+    plan = eng.plan(G, L, mode="pos", num_hops=hops, sign_k=2, full_stats=True)
+    monkeypatch.delenv("S3GRL_FORCE_SEGSORT", raising=False)
+    a = [t.clone() for t in plan.export_subgraphs()]
+    monkeypatch.setenv("S3GRL_FORCE_SEGSORT", "1")
+    b = [t.clone() for t in plan.export_subgraphs()]
+    monkeypatch.delenv("S3GRL_FORCE_SEGSORT", raising=False)
+    plan.close()
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    ptr, nodes = a[0].cpu().numpy(), a[1].cpu().numpy()
+    for li in range(len(g["links"])):
+        mine = nodes[ptr[li]:ptr[li + 1]]
+        np.testing.assert_array_equal(mine, _ragged(g, f"h{hops}_nodes", li))
+    G.close()
+
+
 @pytest.mark.parametrize("name,hops", [("rand300", 2), ("cora", 3), ("star_iso", 2)])
 def test_leaf_tail_walk_changes_no_bit(eng, monkeypatch, name, hops):
     """The last hop's rows of at most two neighbours are walked with one lane per row instead of

@@ -86,6 +86,20 @@ def _worker_fixed(rank, world, port, chunks, q):
         ok = ok and np.array_equal(rows.numpy(), full) and \
             np.array_equal(ptr.numpy(), np.arange(0, 2 * links.shape[1] + 1, 2))
     ok = ok and sum(calls) == 2 * (hi - lo)
+    # the caller owns what it gets back: a second call of the same shape (pos, then neg of a split,
+    # reference sgrl_link_pred.py:195-204) must not overwrite the first result ...
+    flipped = np.ascontiguousarray(links[::-1])
+    kwargs = dict(rank=rank, world_size=world, rows_per_link=2, chunks=chunks, row_shape=(3, 7),
+                  dtype=torch.float64, device="cpu")
+    first, _, _ = parallel.sharded_precompute(compute, links, **kwargs)
+    second, _, _ = parallel.sharded_precompute(compute, flipped, **kwargs)
+    ok = ok and first.data_ptr() != second.data_ptr() and np.array_equal(first.numpy(), rows_of(links)) \
+        and np.array_equal(second.numpy(), rows_of(flipped))
+    # ... unless the caller asked for the shared buffer (a benchmark loop)
+    r1, _, _ = parallel.sharded_precompute(compute, links, reuse_buffers=True, **kwargs)
+    r2, _, _ = parallel.sharded_precompute(compute, flipped, reuse_buffers=True, **kwargs)
+    ok = ok and r1.data_ptr() == r2.data_ptr()
+    calls.clear()
     # gather=False hands back the local shard only
     rows_l, ptr_l, _ = parallel.sharded_precompute(
         compute, links, rank=rank, world_size=world, cost=parallel.link_cost(A, links),

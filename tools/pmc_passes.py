@@ -14,6 +14,11 @@ ap.add_argument("groups", nargs="+")
 ap.add_argument("--workload", default="pubmed_pos_k3")
 ap.add_argument("--out", default=str(REPO / "gpurun_out" / "pmc_passes.json"))
 a = ap.parse_args()
+# build before any profiler starts (a compiler child of a profiled process would exec with the GPU
+# initialised by the tool's preload)
+sys.path.insert(0, str(REPO))
+import __graft_entry__ as _ge
+_ge.build()
 merged, disp = {}, {}
 base = Path(tempfile.mkdtemp(prefix="s3grl_pmc_", dir="/tmp"))
 for i, grp in enumerate(a.groups):

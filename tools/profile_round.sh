@@ -12,6 +12,9 @@ TAG=${1:-round}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 rm -rf "$O"; mkdir -p "$O"
+# build BEFORE any profiler: under rocprofv3 a compiler child would inherit the tool's preload, i.e.
+# be a GPU-initialised process that execs (bench.py / build() refuse to compile there)
+(cd $R && python3 -c 'import __graft_entry__ as g; g.build()') > $O/build.log 2>&1 || { echo "build failed"; tail -20 $O/build.log; exit 1; }
 cd /tmp && export TMPDIR=/tmp
 rc=0
 for wl in pubmed_pos_k3 pubmed_pos_k3_dense pubmed_sop_k3 pubmed_pos_k5 collab_pos_k3; do
