@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define S3GRL_ABI_VERSION 3
+#define S3GRL_ABI_VERSION 4
 
 typedef enum s3grl_status {
   S3GRL_OK = 0,
@@ -84,8 +84,9 @@ typedef struct s3grl_cfg {
   int32_t directed;  /* must be 0 (A_csc == None in every non-ogbl-citation2 run) */
   uint32_t flags;    /* S3GRL_FLAG_* */
   int32_t rw_m;      /* ScaLed subgraphs (reference utils.py:86-150, rw_kwargs): rw_M random walks */
-  int32_t rw_M;      /*   of length rw_m per node replace the BFS (num_hops is then ignored, like
-                          in the reference); 0 = k-hop BFS */
+  int32_t rw_M;      /*   of length rw_m per node, drawn by the engine, replace the BFS (num_hops is
+                          then ignored, like in the reference); 0 = k-hop BFS.  Walk node sets cached
+                          by the caller: s3grl_plan_create_sets */
   uint32_t seed;     /* seed of the engine's own counter-based generator (walks, hop sampling) */
   int32_t max_nodes_per_hop; /* utils.py:68-70: keep at most this many nodes of every hop;
                                 0 = no cap (None) */
@@ -149,6 +150,42 @@ s3grl_status s3grl_graph_destroy(s3grl_graph* g);
  * reference iterates link_index.t().tolist(), tuned_SIGN.py:147). */
 s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links,
                                int64_t num_links, const s3grl_cfg* cfg, s3grl_plan** out);
+
+/* ScaLed subgraphs from node sets the CALLER cached (reference utils.py:94-108: with rw_kwargs the
+ * subgraph of (src,dst) is torch.unique(cat(cache[src], cache[dst])) of rw_kwargs['cached_pos_rws'] /
+ * ['cached_neg_rws'] — dict node -> unique nodes of its walks, built by utils.create_rw_cache,
+ * utils.py:425-443, sgrl_link_pred.py:123-128 — or rw_kwargs['unique_nodes'][(src,dst)]; src and dst
+ * first, utils.py:134-135).  A CSR of sets on the device:
+ *   per_link == 0: num_sets == the graph's num_nodes, set i belongs to NODE i (empty for nodes the
+ *                  cache does not hold); subgraph of (s,d) = {s,d} ∪ set[s] ∪ set[d];
+ *   per_link == 1: num_sets == num_links, set l belongs to LINK l; subgraph = {s,d} ∪ set[l].
+ * Nodes beyond {src,dst} form "hop 1" (dists 0,0,1,1,..., utils.py:145-146); num_hops, rw_m, rw_M and
+ * the per-hop sampling fields of the cfg play no part (rw_m / rw_M must be 0).  The arrays are read
+ * while the plan is created, not afterwards.  S3GRL_ERR_INVALID_ARGUMENT for a malformed set_ptr
+ * or an id outside [0, num_nodes). */
+typedef struct s3grl_node_sets {
+  const int64_t* set_ptr;   /* device int64 [num_sets + 1], monotone from 0 to num_set_nodes */
+  const int32_t* set_nodes; /* device int32 [num_set_nodes] (duplicates and src / dst themselves allowed) */
+  int64_t num_sets;
+  int64_t num_set_nodes;
+  int32_t per_link;         /* 0 or 1 */
+  int32_t reserved;         /* must be 0 */
+} s3grl_node_sets;
+s3grl_status s3grl_plan_create_sets(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links,
+                                    int64_t num_links, const s3grl_cfg* cfg, const s3grl_node_sets* sets,
+                                    s3grl_plan** out);
+/* The producer of such a cache, in place of reference utils.create_rw_cache (utils.py:425-443:
+ * torch_cluster random_walk from every start node repeated rw_M times, walk length rw_m, unique per
+ * start): for start i the ascending unique nodes of its rw_M uniform walks of length rw_m, the start
+ * itself included, in set_nodes[set_ptr[i] .. set_ptr[i+1]).  starts: device int64 [num_starts];
+ * set_ptr: device int64 [num_starts + 1] out; set_nodes: device int32 out with room for
+ * num_starts * (rw_m * rw_M + 1) entries.  The walks are those a plan with the same cfg.rw_m / rw_M /
+ * seed draws by itself (counter-based generator keyed by seed, node, walk, step): same distribution
+ * as torch_cluster's, other random numbers.  rw_m * rw_M + 1 <= 8192. */
+s3grl_status s3grl_walk_sets(s3grl_context* ctx, const s3grl_graph* g, const int64_t* starts,
+                             int64_t num_starts, int32_t rw_m, int32_t rw_M, uint32_t seed,
+                             int64_t* set_ptr, int32_t* set_nodes);
+
 s3grl_status s3grl_plan_destroy(s3grl_plan* p);
 /* host struct out */
 s3grl_status s3grl_plan_get_stats(const s3grl_plan* p, s3grl_plan_stats* out);

@@ -31,7 +31,7 @@ SYMBOLS = [
     "s3grl_context_create", "s3grl_context_destroy", "s3grl_context_timings",
     "s3grl_context_set_profiling", "s3grl_context_trim", "s3grl_plan_gather_traffic",
     "s3grl_graph_create", "s3grl_graph_destroy",
-    "s3grl_plan_create", "s3grl_plan_destroy", "s3grl_plan_get_stats", "s3grl_plan_row_ptr",
+    "s3grl_plan_create", "s3grl_plan_create_sets", "s3grl_walk_sets", "s3grl_plan_destroy", "s3grl_plan_get_stats", "s3grl_plan_row_ptr",
     "s3grl_plan_row_nodes", "s3grl_plan_export_subgraphs", "s3grl_plan_link_cost", "s3grl_run",
     "s3grl_sop_create", "s3grl_sop_destroy", "s3grl_sop_run", "s3grl_sop_features",
     "s3grl_features_create", "s3grl_features_destroy", "s3grl_features_info", "s3grl_run_features",
@@ -47,7 +47,12 @@ class Cfg(C.Structure):
                 ("reserved", C.c_int32 * 4)]
 
 
-ABI_VERSION = 3
+class NodeSets(C.Structure):
+    _fields_ = [("set_ptr", C.c_void_p), ("set_nodes", C.c_void_p), ("num_sets", C.c_int64),
+                ("num_set_nodes", C.c_int64), ("per_link", C.c_int32), ("reserved", C.c_int32)]
+
+
+ABI_VERSION = 4
 FLAG_FULL_STATS, FLAG_NO_FOLD, FLAG_COUNT_ONLY = 1, 2, 4
 
 
@@ -101,6 +106,8 @@ def lib():
         "s3grl_graph_create": [vp, i64, vp, vp, i64, C.POINTER(vp)],
         "s3grl_graph_destroy": [vp],
         "s3grl_plan_create": [vp, vp, vp, i64, C.POINTER(Cfg), C.POINTER(vp)],
+        "s3grl_plan_create_sets": [vp, vp, vp, i64, C.POINTER(Cfg), C.POINTER(NodeSets), C.POINTER(vp)],
+        "s3grl_walk_sets": [vp, vp, vp, i64, i32, i32, C.c_uint32, vp, vp],
         "s3grl_plan_destroy": [vp],
         "s3grl_plan_get_stats": [vp, C.POINTER(PlanStats)],
         "s3grl_plan_row_ptr": [vp, vp],

@@ -346,8 +346,42 @@ s3grl_status s3grl_plan_destroy(s3grl_plan* p) {
   return S3GRL_OK;
 }
 
+static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links,
+                                     int64_t L, const s3grl_cfg* cfg, const s3grl_node_sets* sets,
+                                     s3grl_plan** out);
+
 s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links,
                                int64_t L, const s3grl_cfg* cfg, s3grl_plan** out) {
+  return plan_create_impl(ctx, g, links, L, cfg, nullptr, out);
+}
+
+s3grl_status s3grl_plan_create_sets(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links,
+                                    int64_t L, const s3grl_cfg* cfg, const s3grl_node_sets* sets,
+                                    s3grl_plan** out) {
+  if (!sets || !sets->set_ptr || sets->num_sets < 0 || sets->reserved != 0 ||
+      (sets->per_link != 0 && sets->per_link != 1)) {
+    set_last_error("s3grl_node_sets: set_ptr is required, per_link is 0 or 1, reserved 0");
+    return S3GRL_ERR_INVALID_ARGUMENT;
+  }
+  return plan_create_impl(ctx, g, links, L, cfg, sets, out);
+}
+
+s3grl_status s3grl_walk_sets(s3grl_context* ctx, const s3grl_graph* g, const int64_t* starts,
+                             int64_t num_starts, int32_t rw_m, int32_t rw_M, uint32_t seed,
+                             int64_t* set_ptr, int32_t* set_nodes) {
+  if (!ctx || !g || num_starts < 0 || (num_starts > 0 && (!starts || !set_nodes)) || !set_ptr)
+    return S3GRL_ERR_INVALID_ARGUMENT;
+  if (rw_m < 1 || rw_M < 1 || rw_m > 65535 || rw_M > 65535) {
+    set_last_error("rw_m and rw_M must be in 1..65535");
+    return S3GRL_ERR_INVALID_ARGUMENT;
+  }
+  S3GRL_HIP_TRY(hipSetDevice(ctx->device));
+  return launch_walk_sets(ctx, g, starts, num_starts, rw_m, rw_M, seed, set_ptr, set_nodes);
+}
+
+static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links,
+                                     int64_t L, const s3grl_cfg* cfg, const s3grl_node_sets* sets,
+                                     s3grl_plan** out) {
   if (!ctx || !g || !cfg || !out || L < 0 || (L > 0 && !links)) return S3GRL_ERR_INVALID_ARGUMENT;
   if (cfg->sign_k < 1 || cfg->sign_k > kMaxSignK || cfg->num_hops < 0 ||
       cfg->num_hops > kMaxLevels - 2) {
@@ -382,6 +416,17 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
       set_last_error("s3grl_cfg.reserved must be zero");
       return S3GRL_ERR_INVALID_ARGUMENT;
     }
+  if (sets) {
+    if (cfg->rw_m > 0) {
+      set_last_error("node sets replace the engine's own walks: rw_m / rw_M must be 0 with s3grl_plan_create_sets");
+      return S3GRL_ERR_INVALID_ARGUMENT;
+    }
+    if (sets->num_sets != (sets->per_link ? L : g->num_nodes)) {
+      set_last_error("s3grl_node_sets.num_sets must be num_links (per_link) or the graph's num_nodes");
+      return S3GRL_ERR_INVALID_ARGUMENT;
+    }
+    if (sets->num_set_nodes < 0 || (sets->num_set_nodes > 0 && !sets->set_nodes)) return S3GRL_ERR_INVALID_ARGUMENT;
+  }
   S3GRL_HIP_TRY(hipSetDevice(ctx->device));
   const int K = cfg->sign_k;
 
@@ -422,7 +467,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   S3GRL_TRY(arena_alloc(ctx, (size_t)scan_workspace_elems(L), &scan_ws, tr));
 
   // d_scalars (int64 x 64): [0] err flag, [1] max n, [2] Σ edges, [3] Σ support, [4] Σ vol,
-  // [5] max R, [6] Σ n counting folded links twice, [7] folded links, [16..23] debug stamps,
+  // [5] max R, [6] Σ n counting folded links twice, [7] folded links, [8] node-set flags, [16..23] debug stamps,
   // [32..47] class counts (int32 each, see classify_kernel)
   int64_t* ds = ctx->d_scalars;
   int64_t* hs = ctx->h_scalars;
@@ -436,21 +481,44 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
     for (int k = 0; k < kStatShards; ++k) t += ctx->h_stats[row * kStatRow + (size_t)k * kStatStride];
     return t;
   };
-  // ScaLed: per-node random walks replace the BFS
+  // ScaLed: the walk nodes of src and dst replace the BFS — the engine's own per-node walks, or the
+  // node sets the caller cached (reference utils.py:94-104)
   const int rw_m = cfg->rw_m, rw_M = cfg->rw_M;
-  int32_t* rw_raw = nullptr;
-  const int rw_len = rw_m * rw_M;
-  if (rw_len > 0) {
-    S3GRL_TRY(arena_alloc(ctx, (size_t)g->num_nodes * rw_len, &rw_raw, tr));
+  WalkSets ws{};
+  ws.num_nodes = (int)g->num_nodes;
+  if (rw_m * rw_M > 0) {
+    int32_t* rw_raw = nullptr;
+    S3GRL_TRY(arena_alloc(ctx, (size_t)g->num_nodes * rw_m * rw_M, &rw_raw, tr));
     S3GRL_TRY(launch_random_walks(ctx, g, rw_m, rw_M, cfg->seed, rw_raw));
+    ws.raw = rw_raw;
+    ws.len = rw_m * rw_M;
+  } else if (sets) {
+    // checked BEFORE any kernel walks them (the kernels index LDS bitmaps with these ids and the
+    // set bounds come from device memory): one extra round trip for set plans
+    S3GRL_TRY(launch_validate_sets(ctx, sets->set_ptr, sets->set_nodes, sets->num_sets, sets->num_set_nodes,
+                                   g->num_nodes, ds + 8));
+    S3GRL_HIP_TRY(hipMemcpyAsync(hs + 8, ds + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
+    S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (hs[8]) {
+      set_last_error(std::string("malformed node sets:") +
+                     ((hs[8] & 1) ? " set_ptr is not monotone from 0 to num_set_nodes;" : "") +
+                     ((hs[8] & 2) ? " a node id is outside [0, num_nodes);" : ""));
+      return S3GRL_ERR_INVALID_ARGUMENT;
+    }
+    ws.ptr = sets->set_ptr;
+    ws.nodes = sets->set_nodes;
+    ws.per_link = sets->per_link;
   }
+  const bool walks = walks_on(ws);
+  plan->walk_plan = walks;
   // reversed duplicates (both directions of a train edge) are folded into one extraction
   int32_t *partner = nullptr, *mirror_of = nullptr;
+  // (a set per LINK need not be the set of the reversed link)
   const bool fold = !(cfg->flags & (S3GRL_FLAG_FULL_STATS | S3GRL_FLAG_NO_FOLD | S3GRL_FLAG_COUNT_ONLY)) &&
-                    !getenv("S3GRL_NO_MIRROR");
+                    !(sets && sets->per_link) && !getenv("S3GRL_NO_MIRROR");
   // per-hop sampling (utils.py:66-70; the reference's rw branch ignores it).  Its BFS keeps a
   // fourth bitmap, so the plan stays on the bitmap flavour of the visited set.
-  HopSampling smp{rw_len > 0 ? 1.0 : cfg->ratio_per_hop, rw_len > 0 ? 0 : cfg->max_nodes_per_hop, cfg->seed};
+  HopSampling smp{walks ? 1.0 : cfg->ratio_per_hop, walks ? 0 : cfg->max_nodes_per_hop, cfg->seed};
   const bool sampling = hop_sampling_on(smp);
   if (fold) {
     uint64_t* keys;
@@ -469,7 +537,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   S3GRL_TRY(arena_alloc(ctx, (size_t)L * kMaxLevels, &plan->lvl, own));
   // one-hop plans on big graphs: sizes by intersecting the two sorted rows (no bitmaps, no limit on
   // num_nodes, no node-list hand-over: link_full_kernel merges the rows again)
-  const bool onehop = cfg->num_hops == 1 && rw_len == 0 && !sampling && onehop_mode_for(g) && g->fwd_indptr;
+  const bool onehop = cfg->num_hops == 1 && !walks && !sampling && onehop_mode_for(g) && g->fwd_indptr;
   int32_t* stash = nullptr;
   int slot = 4096;
   if (const char* e = getenv("S3GRL_STASH_SLOT")) slot = std::max(0, atoi(e));   // test hook; 0 = off
@@ -479,7 +547,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   // Plain plans walk the graph in its degree order (s3grl_relabel.hip): links translated on the way
   // in, everything the plan hands out translated back by the link kernels.  Sampled and random-walk
   // plans draw by the caller's ids and stay on the original order.
-  const bool relabel = rw_len == 0 && !sampling && g->r_indptr && (!onehop || g->r_fwd_indptr) &&
+  const bool relabel = !walks && !sampling && g->r_indptr && (!onehop || g->r_fwd_indptr) &&
                        !getenv("S3GRL_NO_RELABEL");
   s3grl_graph g_walk = *g;   // what count_kernel / link_kernel see
   const int64_t* links_walk = plan->links;
@@ -507,7 +575,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
                      std::to_string(kMaxNodesLds) + " of multi-hop / sampled / random-walk plans");
       return S3GRL_ERR_GRAPH_TOO_LARGE;
     }
-    S3GRL_TRY(launch_count(ctx, &g_walk, links_walk, L, cfg->num_hops, plus ? 1 : 0, K, rw_raw, rw_len,
+    S3GRL_TRY(launch_count(ctx, &g_walk, links_walk, L, cfg->num_hops, plus ? 1 : 0, K, ws,
                            partner, mirror_of,
                            plan->n_nodes, p_nodes, n_rows, n_jobs, lvl_max,
                            reinterpret_cast<int32_t*>(ds), st + 3 * kStatRow, smp, stash, slot, plan->lvl));
@@ -617,7 +685,7 @@ s3grl_status s3grl_plan_create(s3grl_context* ctx, const s3grl_graph* g, const i
   S3GRL_TRY(record(ctx, 1));
   S3GRL_TRY(launch_links(ctx, &g_walk, links_walk, L, class_list,
                          class_count_host, cfg->num_hops,
-                         plus ? 1 : 0, cn_cap, (cfg->flags & S3GRL_FLAG_FULL_STATS) ? 1 : 0, K, rw_raw, rw_len, p_nodes,
+                         plus ? 1 : 0, cn_cap, (cfg->flags & S3GRL_FLAG_FULL_STATS) ? 1 : 0, K, ws, p_nodes,
                          plan->node_off,
                          plan->row_ptr, plan->job_off, coef_off, mirror_of, plan->c_ids,
                          plan->c_coef, plan->jobs, plan->job_z, plan->job_lim, plan->row_nodes, plan->lvl, st,

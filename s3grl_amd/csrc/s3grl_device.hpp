@@ -250,6 +250,27 @@ __device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
 }
 
 // ---------------------------------------------------------------------------------------
+// ScaLed: f(u) for every node the walks of src and dst visited (WalkSets, s3grl_internal.hpp) —
+// the engine's own walks, or the caller's cached node sets (reference utils.py:94-104: the cache of
+// src and of dst by node, or one set per link).  Called by all T threads of the workgroup.
+template <typename F>
+__device__ __forceinline__ void for_each_walk_node(const WalkSets& w, int src, int dst, int link, int tid,
+                                                   int T, F f) {
+  if (w.raw) {
+    for (int i = tid; i < 2 * w.len; i += T)
+      f(w.raw[(int64_t)(i < w.len ? src : dst) * w.len + (i < w.len ? i : i - w.len)]);
+  } else {
+    const int64_t ka = w.per_link ? link : src;
+    const int64_t a0 = w.ptr[ka], na = w.ptr[ka + 1] - a0;
+    const int64_t b0 = w.per_link ? 0 : w.ptr[dst], nb = w.per_link ? 0 : w.ptr[dst + 1] - b0;
+    for (int64_t i = tid; i < na + nb; i += T) {
+      const int u = w.nodes[i < na ? a0 + i : b0 + (i - na)];
+      if ((unsigned)u < (unsigned)w.num_nodes) f(u);   // (validated at plan creation; never index LDS out of range)
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Per-hop sampling (reference utils.py:66-70): of the m nodes a hop discovers, keep
 // k = min(int(ratio * m), max_nodes_per_hop) drawn uniformly without replacement; the others stay
 // "visited" (they are never rediscovered) but are not part of the subgraph.  The reference draws
@@ -351,8 +372,9 @@ __device__ __forceinline__ int bfs_list(const int32_t* __restrict__ indptr,
                                         const int32_t* __restrict__ indices, int W, int src,
                                         int dst, int hops, uint32_t* vis, uint32_t* nxt,
                                         int32_t* list, int cap, int* lvl_end, int* sh, int* hub,
-                                        int& nlev_out, const int32_t* __restrict__ rw_raw = nullptr,
-                                        int rw_len = 0, HopSampling smp = HopSampling{1.0, 0, 0}) {
+                                        int& nlev_out, const WalkSets ws = WalkSets{}, int link = 0,
+                                        HopSampling smp = HopSampling{1.0, 0, 0}) {
+  const bool walks = walks_on(ws);
   const int tid = threadIdx.x;
   for (int t = tid; t < W; t += T) {
     vis[t] = 0;
@@ -369,16 +391,15 @@ __device__ __forceinline__ int bfs_list(const int32_t* __restrict__ indptr,
   }
   __syncthreads();
   int n = 2, nlev = 1;  // levels 0..nlev-1 are complete
-  if (rw_raw) hops = 1;  // ScaLed: "level 1" = what the cached random walks of src and dst visited
+  if (walks) hops = 1;  // ScaLed: "level 1" = what the cached random walks of src and dst visited
   for (int d = 1; d <= hops; ++d) {
     const int f0 = d >= 2 ? lvl_end[d - 2] : 0, f1 = n;
-    if (rw_raw) {
-      for (int i = tid; i < 2 * rw_len; i += T) {
-        const int u = rw_raw[(int64_t)(i < rw_len ? src : dst) * rw_len + (i < rw_len ? i : i - rw_len)];
+    if (walks) {
+      for_each_walk_node(ws, src, dst, link, tid, T, [&](int u) {
         const uint32_t m = 1u << (u & 31);
         const uint32_t old = atomicOr(&vis[u >> 5], m);
         if (!(old & m)) atomicOr(&nxt[u >> 5], m);
-      }
+      });
     } else {
       walk_rows<T, G, 2>(
           f0, f1, list, indptr, indices, hub,
@@ -400,7 +421,7 @@ __device__ __forceinline__ int bfs_list(const int32_t* __restrict__ indptr,
     for (int t = w0; t < w1; ++t) mine += __popc(nxt[t]);
     int added;
     int pos = n + block_excl_scan<T>(mine, sh, added);
-    if (!rw_raw && added > 0 && sampling_on(smp)) {   // utils.py:66-70 (uniform: block-wide values)
+    if (!walks && added > 0 && sampling_on(smp)) {   // utils.py:66-70 (uniform: block-wide values)
       const int keep = hop_keep(smp, added);
       if (keep < added) {
         if (keep > 0) {
@@ -431,7 +452,7 @@ __device__ __forceinline__ int bfs_list(const int32_t* __restrict__ indptr,
     __syncthreads();
   }
   __syncthreads();
-  if (!rw_raw && sampling_on(smp)) {
+  if (!walks && sampling_on(smp)) {
     // vis also holds the discovered-but-dropped nodes: rebuild it as the membership bitmap of S
     for (int t = tid; t < W; t += T) vis[t] = 0;
     __syncthreads();
@@ -483,9 +504,9 @@ __device__ __forceinline__ int bfs_hash(const int32_t* __restrict__ indptr,
                                         const int32_t* __restrict__ indices, int src, int dst,
                                         int hops, int32_t* keys, int32_t* vals, uint32_t mask,
                                         int32_t* list, int cap, int* lvl_end, int* cnt, int* hub,
-                                        int& nlev_out, const int32_t* __restrict__ rw_raw = nullptr,
-                                        int rw_len = 0) {
+                                        int& nlev_out, const WalkSets ws = WalkSets{}, int link = 0) {
   const int tid = threadIdx.x;
+  const bool walks = walks_on(ws);
   for (uint32_t t = tid; t <= mask; t += T) keys[t] = -1;
   __syncthreads();
   if (tid == 0) {
@@ -502,17 +523,16 @@ __device__ __forceinline__ int bfs_hash(const int32_t* __restrict__ indptr,
   }
   __syncthreads();
   int n = 2, nlev = 1;
-  if (rw_raw) hops = 1;
+  if (walks) hops = 1;
   for (int d = 1; d <= hops; ++d) {
     const int f0 = d >= 2 ? lvl_end[d - 2] : 0, f1 = n;
-    if (rw_raw) {
-      for (int i = tid; i < 2 * rw_len; i += T) {
-        const int u = rw_raw[(int64_t)(i < rw_len ? src : dst) * rw_len + (i < rw_len ? i : i - rw_len)];
+    if (walks) {
+      for_each_walk_node(ws, src, dst, link, tid, T, [&](int u) {
         if (hs_insert(keys, mask, u)) {
           const int pos = atomicAdd(cnt, 1);
           if (pos < cap) list[pos] = u;
         }
-      }
+      });
     } else {
       walk_rows<T, G, 2>(
           f0, f1, list, indptr, indices, hub,

@@ -54,6 +54,19 @@ static inline bool hop_sampling_on(const HopSampling& s) {
   return (s.ratio > 0.0 && s.ratio < 1.0) || s.max_nodes > 0;
 }
 
+// ScaLed subgraphs (reference utils.py:86-150): where the "walk nodes" of a link come from.
+// raw: the engine's own walks, [N, len] per NODE (s3grl_cfg.rw_m / rw_M);  ptr / nodes: node sets
+// handed in by the caller as a CSR (s3grl_plan_create_sets), one set per node or one per link.
+struct WalkSets {
+  const int32_t* raw = nullptr;
+  int len = 0;
+  const int64_t* ptr = nullptr;
+  const int32_t* nodes = nullptr;
+  int per_link = 0;
+  int num_nodes = 0;
+};
+__host__ __device__ static inline bool walks_on(const WalkSets& w) { return w.raw != nullptr || w.ptr != nullptr; }
+
 // One gather job = one pair of output rows of one link (rows 2p, 2p+1 of that link).
 struct Job {
   int64_t coef_off;   // first float2 of this job's coefficients, laid out [K][support]
@@ -147,6 +160,7 @@ struct s3grl_plan {
   int32_t* lvl = nullptr;        // [L, kMaxLevels] cumulative node count per BFS level
   int32_t* e_cap = nullptr;      // [L] bound of the induced entries (one-hop plans on big graphs), else null
   bool relabelled = false;       // the kernels walked the graph's degree order (s3grl_relabel.hip)
+  bool walk_plan = false;        // ScaLed: subgraph = walk nodes of src and dst (one "hop", whatever num_hops)
   int32_t* c_ids = nullptr;      // [Σn] subgraph nodes, hop-major (ascending id inside a hop unless relabelled)
   // per job (row pair)
   s3grl::Job* jobs = nullptr;    // [njobs]
@@ -215,7 +229,7 @@ s3grl_status launch_sort_hops(s3grl_context* ctx, const s3grl_plan* p, int32_t* 
 
 // structure.hip
 s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
-                          int hops, int plus, int K, const int32_t* rw_raw, int rw_len,
+                          int hops, int plus, int K, WalkSets ws,
                           const int32_t* partner, const int32_t* mirror_of, int32_t* n_nodes, int32_t* p_nodes,
                           int32_t* n_rows, int32_t* n_jobs, int32_t* lvl_max, int32_t* err_flag,
                           int64_t* tot_nodes_alg, HopSampling smp = HopSampling{1.0, 0, 0},
@@ -223,6 +237,14 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
 int num_class_lists();
 s3grl_status launch_random_walks(s3grl_context* ctx, const s3grl_graph* g, int m, int M,
                                  uint32_t seed, int32_t* raw);
+// structure check of a caller's node sets: bit 0 set_ptr not monotone from 0, bit 1 an id outside [0,N)
+s3grl_status launch_validate_sets(s3grl_context* ctx, const int64_t* set_ptr, const int32_t* set_nodes,
+                                  int64_t num_sets, int64_t total, int64_t num_nodes,
+                                  int64_t* flags /* device, zeroed */);
+// per start node the sorted unique nodes of its M walks of length m, the start included (the cache
+// reference utils.create_rw_cache builds, utils.py:425-443)
+s3grl_status launch_walk_sets(s3grl_context* ctx, const s3grl_graph* g, const int64_t* starts, int64_t num_starts,
+                              int m, int M, uint32_t seed, int64_t* set_ptr, int32_t* set_nodes);
 // folds a reversed duplicate (dst,src) of a link (src,dst) into it: partner[l] = primary of a
 // folded link (else -1), mirror_of[l] = the link folded into l (else -1)
 int64_t mirror_table_slots(int64_t L);
@@ -252,8 +274,7 @@ s3grl_status launch_count1(s3grl_context* ctx, const s3grl_graph* g, const int64
                            int32_t* lvl_max, int32_t* e_cap, int32_t* err_flag, int64_t* tot_nodes_alg);
 s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                           const int32_t* class_list, const int32_t* class_count_host, int hops,
-                          int plus, int cn_cap, int full_stats, int K, const int32_t* rw_raw,
-                          int rw_len, const int32_t* p_nodes,
+                          int plus, int cn_cap, int full_stats, int K, WalkSets ws, const int32_t* p_nodes,
                           const int64_t* node_off, const int64_t* row_ptr, const int64_t* job_off,
                           const int64_t* coef_off, const int32_t* mirror_of, int32_t* c_ids,
                           float* c_coef, Job* jobs, float* job_z, int32_t* job_lim, int64_t* row_nodes,

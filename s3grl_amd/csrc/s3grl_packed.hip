@@ -558,7 +558,7 @@ s3grl_status launch_packed_k(s3grl_context* ctx, const s3grl_plan* p, const s3gr
   static const size_t lds_cap = getenv("S3GRL_GATHER_LDS") ? (size_t)atoi(getenv("S3GRL_GATHER_LDS")) : 0;
   // every job's last two operators reach its whole list when sign_k - 1 >= the BFS depth (one hop for
   // random-walk subgraphs)
-  const int depth = p->cfg.rw_m > 0 ? 1 : p->cfg.num_hops;
+  const int depth = p->walk_plan ? 1 : p->cfg.num_hops;
   if (K >= 2 && K - 1 >= depth && masked) {
     hipLaunchKernelGGL((gather_packed_kernel<K, true, (K >= 2 ? 2 : 1)>), dim3(gx, (unsigned)f->tiles),
                        dim3(kWavesPerBlock * 64), lds_cap, ctx->stream, p->jobs, (int)p->njobs, p->c_ids, p->c_coef,

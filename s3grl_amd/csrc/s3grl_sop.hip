@@ -523,7 +523,7 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
                        g->indptr, g->num_nodes, links, L, RB, n_nodes, reinterpret_cast<int32_t*>(ds));
     S3GRL_HIP_TRY(hipGetLastError());
   } else {
-    S3GRL_TRY(launch_count(ctx, g, links, L, RB, 0, 1, nullptr, 0, nullptr, nullptr, n_nodes, p_nodes, n_rows,
+    S3GRL_TRY(launch_count(ctx, g, links, L, RB, 0, 1, WalkSets{}, nullptr, nullptr, n_nodes, p_nodes, n_rows,
                            n_jobs, lvl_max, reinterpret_cast<int32_t*>(ds), ctx->d_stats));
   }
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_nodes, L, node_off, scan_ws));

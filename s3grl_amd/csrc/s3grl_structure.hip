@@ -75,16 +75,17 @@ template <int G, int kCountBlock>
 __global__ __launch_bounds__(kCountBlock) void count_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int N, int W,
     const int64_t* __restrict__ links, int hops, int plus, int K, int hubs,
-    const int32_t* __restrict__ rw_raw, int rw_len, const int32_t* __restrict__ partner, const int32_t* __restrict__ mirror_of,
+    const WalkSets ws, const int32_t* __restrict__ partner, const int32_t* __restrict__ mirror_of,
     int32_t* __restrict__ n_nodes, int32_t* __restrict__ p_nodes, int32_t* __restrict__ n_rows,
     int32_t* __restrict__ n_jobs, int32_t* __restrict__ lvl_max, int32_t* __restrict__ err_flag,
     unsigned long long* __restrict__ tot_nodes_alg, HopSampling smp, int32_t* __restrict__ stash,
     int slot, int32_t* __restrict__ lvl_stash) {
   extern __shared__ uint32_t smem[];
+  const bool walks = walks_on(ws);
   // `cur` (the frontier as a bitmap, for levels too big for the frontier list) is only needed when
   // a level below `hops` is expanded again: with one hop (and for ScaLed walks) the launcher
   // leaves it out — a third of the LDS of a big graph
-  const bool one_hop = hops <= 1 || rw_raw != nullptr;
+  const bool one_hop = hops <= 1 || walks;
   const int nbm = one_hop ? 2 : 3;
   uint32_t* vis = smem;
   uint32_t* cur = one_hop ? nullptr : smem + W;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(kCountBlock) void count_kernel(
   int* sh = reinterpret_cast<int*>(smem + nbm * W);
   // per-hop sampling: `vis` also holds discovered-but-dropped nodes, so the members of S get a
   // bitmap of their own (the launcher adds W words behind the list when sampling is on)
-  const bool sampling = !rw_raw && sampling_on(smp);
+  const bool sampling = !walks && sampling_on(smp);
   uint32_t* mem = sampling ? smem + nbm * W + 8 + kHubWords + kCountList : nullptr;
   const int tid = threadIdx.x;
   const int l = blockIdx.x;
@@ -151,15 +152,14 @@ __global__ __launch_bounds__(kCountBlock) void count_kernel(
   // per word.  cum_a / cum_b: nodes within K-1 / K hops (P for a row at hop 0 / hop 1).
   int n = 2, cum_a = 2, cum_b = 2, f0 = 0, f1 = 2, biggest = 2, nlev_seen = 1;
   bool use_list = true;
-  if (rw_raw) hops = 1;  // ScaLed: the "hop" is what the cached random walks of src and dst visited
+  if (walks) hops = 1;  // ScaLed: the "hop" is what the cached random walks of src and dst visited
   for (int d = 1; d <= hops; ++d) {
-    if (rw_raw) {
-      for (int i = tid; i < 2 * rw_len; i += kCountBlock) {
-        const int u = rw_raw[(int64_t)(i < rw_len ? src : dst) * rw_len + (i < rw_len ? i : i - rw_len)];
+    if (walks) {
+      for_each_walk_node(ws, src, dst, l, tid, kCountBlock, [&](int u) {
         const uint32_t m = 1u << (u & 31);
         const uint32_t old = atomicOr(&vis[u >> 5], m);
         if (!(old & m)) atomicOr(&nxt[u >> 5], m);
-      }
+      });
     } else if (use_list) {
       walk_rows<kCountBlock, G, 2>(
           f0, f1, list, indptr, indices, hub,
@@ -296,6 +296,98 @@ __global__ void random_walks_kernel(const int32_t* __restrict__ indptr,
     raw[(v * M + w) * m + s] = cur;   // an isolated node stays where it is
   }
 }
+
+#ifndef S3GRL_LINKS_PART
+// The cache reference utils.create_rw_cache builds (utils.py:425-443): for every start node the
+// sorted unique nodes of its M walks of length m, the start itself included (torch_cluster's walk
+// tensor begins with the start; torch.unique sorts).  Same walks as random_walks_kernel for the
+// same (seed, node): a plan built on these sets equals the plan that draws the walks itself.
+// One workgroup per start node: walks into LDS, bitonic sort, unique -> padded scratch + count.
+constexpr int kWalkSetBlock = 256;
+constexpr int kWalkSetMax = 8192;   // M * m + 1 rounded up to a power of two: 32 KiB of LDS
+
+__global__ __launch_bounds__(kWalkSetBlock) void walk_sets_kernel(
+    const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int64_t N,
+    const int64_t* __restrict__ starts, int m, int M, uint32_t seed, int P, int cap,
+    int32_t* __restrict__ scratch /* [num_starts, cap] */, int32_t* __restrict__ count,
+    int32_t* __restrict__ err_flag) {
+  extern __shared__ uint32_t smem[];
+  int32_t* e = reinterpret_cast<int32_t*>(smem);   // [P]
+  __shared__ int sh[kWalkSetBlock / 64];
+  const int tid = threadIdx.x;
+  const int64_t i = blockIdx.x;
+  const int64_t v64 = starts[i];
+  if (v64 < 0 || v64 >= N) {
+    if (tid == 0) {
+      atomicMax(err_flag, 1);
+      count[i] = 0;
+    }
+    return;
+  }
+  const int v = (int)v64;
+  for (int t = tid; t < P; t += kWalkSetBlock) e[t] = t == 0 ? v : 0x7fffffff;
+  __syncthreads();
+  for (int w = tid; w < M; w += kWalkSetBlock) {
+    int cur = v;
+    for (int st = 0; st < m; ++st) {
+      const int b = indptr[cur], deg = indptr[cur + 1] - b;
+      if (deg > 0) cur = indices[b + rw_random(seed, (uint32_t)v, (uint32_t)w, (uint32_t)st) % deg];
+      e[1 + w * m + st] = cur;
+    }
+  }
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < P; t += kWalkSetBlock) {
+        const int u = t ^ j;
+        if (u > t) {
+          const int a = e[t], b = e[u];
+          if ((a > b) == ((t & k) == 0)) {
+            e[t] = b;
+            e[u] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  // unique: thread-contiguous runs, one block scan
+  const int C = (P + kWalkSetBlock - 1) / kWalkSetBlock;
+  const int t0 = min(tid * C, P), t1 = min(t0 + C, P);
+  int mine = 0;
+  for (int t = t0; t < t1; ++t) mine += (e[t] != 0x7fffffff && (t == 0 || e[t] != e[t - 1])) ? 1 : 0;
+  int total;
+  int pos = block_excl_scan<kWalkSetBlock>(mine, sh, total);
+  for (int t = t0; t < t1; ++t)
+    if (e[t] != 0x7fffffff && (t == 0 || e[t] != e[t - 1])) scratch[i * cap + pos++] = e[t];
+  if (tid == 0) count[i] = total;
+}
+
+__global__ void walk_sets_compact_kernel(const int32_t* __restrict__ scratch, int cap,
+                                         const int64_t* __restrict__ set_ptr, int32_t* __restrict__ set_nodes) {
+  const int64_t i = blockIdx.x;
+  const int64_t o = set_ptr[i];
+  const int n = (int)(set_ptr[i + 1] - o);
+  for (int t = threadIdx.x; t < n; t += blockDim.x) set_nodes[o + t] = scratch[i * cap + t];
+}
+
+__global__ void validate_sets_kernel(const int64_t* __restrict__ set_ptr, const int32_t* __restrict__ set_nodes,
+                                     int64_t num_sets, int64_t total, int64_t N, int64_t* __restrict__ flags) {
+  int bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < num_sets;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = set_ptr[i], e = set_ptr[i + 1];
+    if (b > e || b < 0 || e > total || (i == 0 && b != 0) || (i == num_sets - 1 && e != total)) {
+      bad |= 1;
+      continue;
+    }
+    for (int64_t c = b; c < e; ++c) {
+      const int u = set_nodes[c];
+      if (u < 0 || u >= N) bad |= 2;
+    }
+  }
+  if (bad) atomicOr(reinterpret_cast<unsigned long long*>(flags), (unsigned long long)bad);
+}
+#endif  // !S3GRL_LINKS_PART
 
 // ---------------------------------------------------------------------------------------
 // Reversed duplicates.  The reference's train split holds BOTH directions of every train edge
@@ -556,7 +648,7 @@ template <int T, int K, int G, bool GS, bool HS, bool DM = false>
 __global__ __launch_bounds__(T) void link_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int W,
     const int64_t* __restrict__ links, const int32_t* __restrict__ class_list, int hops, int plus,
-    int cn_cap, int full_stats, int hubs, const int32_t* __restrict__ rw_raw, int rw_len,
+    int cn_cap, int full_stats, int hubs, const WalkSets ws,
     const int32_t* __restrict__ p_nodes,
     const int64_t* __restrict__ node_off, const int64_t* __restrict__ row_ptr,
     const int64_t* __restrict__ job_off, const int64_t* __restrict__ coef_off,
@@ -671,10 +763,10 @@ __global__ __launch_bounds__(T) void link_kernel(
     n = n_alloc;
   } else if constexpr (HS) {
     n = bfs_hash<T, G>(indptr, indices, src, dst, hops, hkeys, hvals, hmask, list, n_alloc, lvl_end, sh + 31,
-                       hub, nlev, rw_raw, rw_len);
+                       hub, nlev, ws, l);
   } else {
     n = bfs_list<T, G>(indptr, indices, W, src, dst, hops, vis, inP, list, n_alloc, lvl_end, sh, hub, nlev,
-                       rw_raw, rw_len, smp);
+                       ws, l, smp);
   }
   // set queries of the passes below: membership in S; index into the P-state arrays (+ is it in P);
   // the P-state index of list entry t (= node v)
@@ -751,7 +843,7 @@ __global__ __launch_bounds__(T) void link_kernel(
   int edges_local = 0;
   int edges_exact = -1;   // set when a pass of pair 0 walked every row of S
   int dinv_rows = lvl_end[min(max_row_hop, nlev - 1)];
-  if (!rw_raw && !sampling_on(smp) && hops > max_row_hop) {
+  if (!walks_on(ws) && !sampling_on(smp) && hops > max_row_hop) {
     // A plain BFS to `hops` holds every neighbour of a node that sits below hop `hops`: the
     // subgraph degree of such a row is its global degree, minus the masked target link at src and
     // dst (utils.py:79-80).  No walk.
@@ -822,7 +914,7 @@ __global__ __launch_bounds__(T) void link_kernel(
   // neighbours in the lane's two slots, no tail loop) instead of G; two terms add up to the same
   // bits either way.
   int lo_begin = n;
-  if (lo_id >= 0 && nlev >= 2 && !rw_raw) {
+  if (lo_id >= 0 && nlev >= 2 && !walks_on(ws)) {
     int lo = lvl_end[nlev - 2], hi = n;   // ascending ids inside the hop
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
@@ -1142,6 +1234,57 @@ s3grl_status launch_random_walks(s3grl_context* ctx, const s3grl_graph* g, int m
   return S3GRL_OK;
 }
 
+s3grl_status launch_validate_sets(s3grl_context* ctx, const int64_t* set_ptr, const int32_t* set_nodes,
+                                  int64_t num_sets, int64_t total, int64_t num_nodes, int64_t* flags) {
+  if (num_sets == 0) return S3GRL_OK;
+  hipLaunchKernelGGL(validate_sets_kernel, dim3(512), dim3(256), 0, ctx->stream, set_ptr, set_nodes, num_sets,
+                     total, num_nodes, flags);
+  S3GRL_HIP_TRY(hipGetLastError());
+  return S3GRL_OK;
+}
+
+s3grl_status launch_walk_sets(s3grl_context* ctx, const s3grl_graph* g, const int64_t* starts, int64_t num_starts,
+                              int m, int M, uint32_t seed, int64_t* set_ptr, int32_t* set_nodes) {
+  if (num_starts == 0) {
+    S3GRL_HIP_TRY(hipMemsetAsync(set_ptr, 0, 8, ctx->stream));
+    return S3GRL_OK;
+  }
+  const int64_t cap64 = (int64_t)m * M + 1;
+  int P = 2;
+  while (P < cap64 && P < kWalkSetMax) P <<= 1;
+  if (cap64 > P) {
+    set_last_error("rw_m * rw_M + 1 = " + std::to_string(cap64) + " entries per node exceed " +
+                   std::to_string(kWalkSetMax));
+    return S3GRL_ERR_GRAPH_TOO_LARGE;
+  }
+  const int cap = (int)cap64;
+  Transient tmp{ctx, {}};
+  void *scratch = nullptr, *cnt = nullptr, *ws = nullptr;
+  S3GRL_TRY(ctx->arena.alloc((size_t)num_starts * cap * 4, &scratch));
+  tmp.ptrs.push_back(scratch);
+  S3GRL_TRY(ctx->arena.alloc((size_t)num_starts * 4, &cnt));
+  tmp.ptrs.push_back(cnt);
+  S3GRL_TRY(ctx->arena.alloc((size_t)scan_workspace_elems(num_starts) * 8, &ws));
+  tmp.ptrs.push_back(ws);
+  S3GRL_HIP_TRY(hipMemsetAsync(ctx->d_scalars, 0, 8, ctx->stream));
+  hipLaunchKernelGGL(walk_sets_kernel, dim3((unsigned)num_starts), dim3(kWalkSetBlock), (size_t)P * 4, ctx->stream,
+                     g->indptr, g->indices, g->num_nodes, starts, m, M, seed, P, cap, static_cast<int32_t*>(scratch),
+                     static_cast<int32_t*>(cnt), reinterpret_cast<int32_t*>(ctx->d_scalars));
+  S3GRL_HIP_TRY(hipGetLastError());
+  S3GRL_TRY(launch_scan_i32_to_i64(ctx, static_cast<int32_t*>(cnt), num_starts, set_ptr,
+                                   static_cast<int64_t*>(ws)));
+  hipLaunchKernelGGL(walk_sets_compact_kernel, dim3((unsigned)num_starts), dim3(64), 0, ctx->stream,
+                     static_cast<int32_t*>(scratch), cap, set_ptr, set_nodes);
+  S3GRL_HIP_TRY(hipGetLastError());
+  S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));   // tmp is released on return
+  if (ctx->h_scalars[0] & 0xffffffff) {
+    set_last_error("a start node is outside [0, num_nodes)");
+    return S3GRL_ERR_INVALID_ARGUMENT;
+  }
+  return S3GRL_OK;
+}
+
 s3grl_status launch_mirror_rows(s3grl_context* ctx, const int32_t* partner, int64_t L,
                                 int32_t* n_rows) {
   if (L == 0) return S3GRL_OK;
@@ -1152,14 +1295,14 @@ s3grl_status launch_mirror_rows(s3grl_context* ctx, const int32_t* partner, int6
 }
 
 s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
-                          int hops, int plus, int K, const int32_t* rw_raw, int rw_len,
+                          int hops, int plus, int K, WalkSets ws,
                           const int32_t* partner, const int32_t* mirror_of, int32_t* n_nodes, int32_t* p_nodes,
                           int32_t* n_rows, int32_t* n_jobs, int32_t* lvl_max, int32_t* err_flag,
                           int64_t* tot_nodes_alg, HopSampling smp, int32_t* stash, int slot,
                           int32_t* lvl_stash) {
   if (L == 0) return S3GRL_OK;
   const int W = words_for(g->num_nodes);
-  const int nbm = (hops <= 1 || rw_raw) ? 2 : 3;   // see count_kernel: no frontier bitmap for one hop
+  const int nbm = (hops <= 1 || walks_on(ws)) ? 2 : 3;   // see count_kernel: no frontier bitmap for one hop
   const size_t lds = (size_t)(nbm * W + 8 + kHubWords + kCountList + (hop_sampling_on(smp) ? W : 0)) * 4;
   if (lds > 163840) {
     set_last_error("num_nodes " + std::to_string(g->num_nodes) + ": the LDS bitmaps exceed 160 KiB");
@@ -1173,7 +1316,7 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)L), dim3(small ? 128 : 256), lds, ctx->stream, g->indptr,
                      g->indices, (int)g->num_nodes, W, links, hops, plus, K,
-                     g->max_degree > kHubArmDegree ? 1 : 0, rw_raw, rw_len, partner, mirror_of, n_nodes,
+                     g->max_degree > kHubArmDegree ? 1 : 0, ws, partner, mirror_of, n_nodes,
                      p_nodes, n_rows, n_jobs, lvl_max, err_flag,
                      reinterpret_cast<unsigned long long*>(tot_nodes_alg), smp, stash, slot, lvl_stash);
   S3GRL_HIP_TRY(hipGetLastError());
@@ -1507,8 +1650,7 @@ struct LinkArgs {
   const int64_t* links;
   const int32_t* class_list;
   int hops, plus, cn_cap, full_stats;
-  const int32_t* rw_raw;
-  int rw_len;
+  WalkSets ws;
   const int32_t* p_nodes;
   const int64_t *node_off, *row_ptr, *job_off, *coef_off;
   const int32_t* mirror_of;
@@ -1579,8 +1721,8 @@ s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(T), lds, stream, a.g->indptr,
                      a.g->indices, W, a.links, a.class_list + (int64_t)cls * L, a.hops, a.plus,
-                     a.cn_cap, a.full_stats, a.g->max_degree > kHubArmDegree ? 1 : 0, a.rw_raw,
-                     a.rw_len, a.p_nodes, a.node_off, a.row_ptr, a.job_off, a.coef_off,
+                     a.cn_cap, a.full_stats, a.g->max_degree > kHubArmDegree ? 1 : 0, a.ws,
+                     a.p_nodes, a.node_off, a.row_ptr, a.job_off, a.coef_off,
                      a.mirror_of, a.c_ids, a.c_coef, a.jobs, a.job_z, a.job_lim, a.row_nodes, a.lvl,
                      reinterpret_cast<unsigned long long*>(a.tot_edges),
                      reinterpret_cast<unsigned long long*>(a.tot_support),
@@ -1741,8 +1883,7 @@ namespace s3grl {
 
 s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                           const int32_t* class_list, const int32_t* class_count_host, int hops,
-                          int plus, int cn_cap, int full_stats, int K, const int32_t* rw_raw,
-                          int rw_len, const int32_t* p_nodes,
+                          int plus, int cn_cap, int full_stats, int K, WalkSets ws, const int32_t* p_nodes,
                           const int64_t* node_off, const int64_t* row_ptr, const int64_t* job_off,
                           const int64_t* coef_off, const int32_t* mirror_of, int32_t* c_ids,
                           float* c_coef, Job* jobs, float* job_z, int32_t* job_lim, int64_t* row_nodes,
@@ -1762,7 +1903,7 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
     scratch_owner.ptrs.push_back(q);
     scratch = static_cast<char*>(q);
   }
-  LinkArgs a{g, links, class_list, hops, plus, cn_cap, full_stats, rw_raw, rw_len, p_nodes, node_off,
+  LinkArgs a{g, links, class_list, hops, plus, cn_cap, full_stats, ws, p_nodes, node_off,
              row_ptr,
              job_off, coef_off, mirror_of, c_ids, c_coef, jobs, job_z, job_lim, row_nodes, lvl, tot_edges,
              tot_support, tot_vol, scratch, scratch_stride,

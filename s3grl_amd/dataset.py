@@ -107,6 +107,16 @@ def extract_enclosing_subgraphs(link_index, A, x, y, num_hops, node_label='drnl'
                            sign_kwargs['sign_k'])
 
 
+def create_rw_cache(A, edges, device, rw_m, rw_M, seed=0):
+    """`utils.create_rw_cache` for `process_split` (reference sgrl_link_pred.py:123-128) on the engine:
+    walks on the device copy of A the operators will use anyway (uploaded once, tuned_SIGN's cache)."""
+    from . import scaled
+    from .tuned_SIGN import _device_graph
+
+    eng, g_dev = _device_graph(A)
+    return scaled.create_rw_cache(g_dev, edges, device, rw_m, rw_M, seed=seed, engine=eng)
+
+
 def train_graph(edge_index, num_nodes, edge_weight=None):
     """sgrl_link_pred.py:107-114: `ssp.csr_matrix((edge_weight, (row, col)), shape=(N, N))`, int
     ones when the data has no weights; duplicate entries are summed by scipy."""
@@ -168,8 +178,17 @@ def process_split(split, split_edge, edge_index, num_nodes, x, num_hops, *, sign
         sign_kwargs = make_sign_kwargs(sign_k=sign_k, sign_type=sign_type, optimize_sign=optimize_sign,
                                        k_heuristic=k_heuristic, k_node_set_strategy=k_node_set_strategy,
                                        use_feature=use_feature)
-        # sgrl_link_pred.py:156-159: rw_kwargs is None unless ScaLed sampling is on
-        rw_kwargs = {"rw_m": m, "rw_M": M, "sign": True, "seed": rw_seed} if m else None
+        # sgrl_link_pred.py:123-140,156-159: rw_kwargs is None unless ScaLed sampling is on; for the
+        # optimised PoS flows the walks are cached per node and per (pos / neg) list first, and the
+        # operators extract exactly the cached sets
+        rw_kwargs = None
+        if m:
+            cached_pos = cached_neg = None
+            if optimize_sign and sign_type == "PoS":
+                cached_pos = create_rw_cache(A, pos_edge, device, m, M, seed=rw_seed)
+                cached_neg = create_rw_cache(A, neg_edge, device, m, M, seed=rw_seed)
+            rw_kwargs = {"rw_m": m, "rw_M": M, "sign": True, "seed": rw_seed,
+                         "cached_pos_rws": cached_pos, "cached_neg_rws": cached_neg}
         powers_of_A = GlobalOperators(sign_k) if sign_type in ("SoP", "hybrid") else []
         print("Setting up Positive Subgraphs")
         pos_list = extract_enclosing_subgraphs(pos_edge, A, x, 1, num_hops, node_label, ratio_per_hop,

@@ -104,12 +104,22 @@ class Features:
 
 
 class Plan:
-    def __init__(self, engine, graph, links, cfg):
+    def __init__(self, engine, graph, links, cfg, node_sets=None):
         self.engine, self.graph, self.cfg = engine, graph, cfg
         self.num_links = int(links.shape[0])
         h = C.c_void_p()
-        N.check(N.lib().s3grl_plan_create(engine._ctx, graph._h, _ptr(links), self.num_links,
-                                          C.byref(cfg), C.byref(h)), "s3grl_plan_create")
+        if node_sets is None:
+            N.check(N.lib().s3grl_plan_create(engine._ctx, graph._h, _ptr(links), self.num_links,
+                                              C.byref(cfg), C.byref(h)), "s3grl_plan_create")
+        else:
+            set_ptr, set_nodes, per_link = node_sets
+            assert set_ptr.is_cuda and set_ptr.dtype == torch.int64 and set_ptr.is_contiguous()
+            assert set_nodes.is_cuda and set_nodes.dtype == torch.int32 and set_nodes.is_contiguous()
+            ns = N.NodeSets(set_ptr.data_ptr(), set_nodes.data_ptr() if set_nodes.numel() else None,
+                            set_ptr.numel() - 1, set_nodes.numel(), int(bool(per_link)), 0)
+            N.check(N.lib().s3grl_plan_create_sets(engine._ctx, graph._h, _ptr(links), self.num_links,
+                                                   C.byref(cfg), C.byref(ns), C.byref(h)),
+                    "s3grl_plan_create_sets")
         self._h = h
         engine._children.add(self)
         st = N.PlanStats()
@@ -310,9 +320,30 @@ class Engine:
         finally:
             p.close()
 
+    def walk_sets(self, graph, starts, m, M, seed=0):
+        """(set_ptr int64 [S+1], set_nodes int32) on the device: for every start node the ascending
+        unique nodes of its M uniform random walks of length m, itself included — the cache of
+        reference utils.create_rw_cache (utils.py:425-443); see `s3grl_amd.scaled`."""
+        starts = torch.as_tensor(starts).to(device=self.device, dtype=torch.int64).contiguous()
+        S = int(starts.numel())
+        set_ptr = torch.empty(S + 1, dtype=torch.int64, device=self.device)
+        room = torch.empty(max(S * (int(m) * int(M) + 1), 1), dtype=torch.int32, device=self.device)
+        N.check(N.lib().s3grl_walk_sets(self._ctx, graph._h, _ptr(starts), S, int(m), int(M),
+                                        int(seed) & 0xffffffff, _ptr(set_ptr), _ptr(room)), "s3grl_walk_sets")
+        return set_ptr, room[:int(set_ptr[-1])].clone()
+
+    def node_sets(self, set_ptr, set_nodes, per_link=False):
+        """Upload caller-side node sets (CSR: numpy / torch) for `plan(..., node_sets=...)`."""
+        p = torch.as_tensor(np.asarray(set_ptr, dtype=np.int64) if not torch.is_tensor(set_ptr) else set_ptr)
+        n = torch.as_tensor(np.asarray(set_nodes) if not torch.is_tensor(set_nodes) else set_nodes)
+        if n.numel() and (int(n.min()) < -2**31 or int(n.max()) >= 2**31):
+            raise ValueError("node ids in the sets do not fit int32")
+        return (p.to(device=self.device, dtype=torch.int64).contiguous(),
+                n.to(device=self.device, dtype=torch.int32).contiguous(), bool(per_link))
+
     def plan(self, graph, links, *, mode="pos", num_hops=1, sign_k=3, strategy="intersection",
              directed=False, full_stats=False, fold_reversed=True, rw=None, ratio_per_hop=1.0,
-             max_nodes_per_hop=None, seed=0, count_only=False):
+             max_nodes_per_hop=None, seed=0, count_only=False, node_sets=None):
         cfg = N.Cfg()
         cfg.mode = {"pos": N.MODE_POS, "pos_plus": N.MODE_POS_PLUS}[mode]
         cfg.num_hops = int(num_hops)
@@ -325,6 +356,13 @@ class Engine:
             (N.FLAG_COUNT_ONLY if count_only else 0)
         cfg.seed = int(seed) & 0xffffffff
         cfg.ratio_per_hop = 1.0
+        if node_sets is not None:
+            # ScaLed subgraphs from node sets the caller cached (reference utils.py:94-108):
+            # (set_ptr, set_nodes, per_link) device tensors, see `node_sets()`; num_hops, rw and the
+            # per-hop sampling play no part
+            if rw is not None:
+                raise ValueError("node_sets and rw are alternatives")
+            return Plan(self, graph, links, cfg, node_sets)
         if rw is not None:
             # ScaLed subgraphs (reference rw_kwargs): rw = (m, M[, seed]) — M walks of length m per
             # node instead of the k-hop BFS
@@ -348,7 +386,7 @@ class Engine:
 
     def precompute(self, graph, x, links, *, mode="pos", num_hops=1, sign_k=3,
                    strategy="intersection", directed=False, out=None, rw=None, ratio_per_hop=1.0,
-                   max_nodes_per_hop=None, seed=0):
+                   max_nodes_per_hop=None, seed=0, node_sets=None):
         """links: int64 [L,2] device tensor (see `links()`); x: fp32 [N,F] device tensor."""
         if x is None:
             N.check(N.ERR_NO_FEATURES, "precompute")
@@ -356,7 +394,7 @@ class Engine:
             # reference utils.py:454-480: PoS keys kept, SoP x2..xK appended as x{K+1}..x{2K-1}
             pos = self.precompute(graph, x, links, mode="pos", num_hops=num_hops, sign_k=sign_k, rw=rw,
                                   ratio_per_hop=ratio_per_hop, max_nodes_per_hop=max_nodes_per_hop,
-                                  seed=seed)
+                                  seed=seed, node_sets=node_sets)
             if sign_k == 1:
                 return pos
             sop = self.precompute(graph, x, links, mode="sop", sign_k=sign_k)
@@ -374,7 +412,7 @@ class Engine:
                                                                           "total_rows": 2 * L})
         plan = self.plan(graph, links, mode=mode, num_hops=num_hops, sign_k=sign_k,
                          strategy=strategy, directed=directed, rw=rw, ratio_per_hop=ratio_per_hop,
-                         max_nodes_per_hop=max_nodes_per_hop, seed=seed)
+                         max_nodes_per_hop=max_nodes_per_hop, seed=seed, node_sets=node_sets)
         try:
             rows = plan.run(x, out)
             res = Precomputed(rows, plan.row_ptr(), plan.row_nodes(), dict(plan.stats))

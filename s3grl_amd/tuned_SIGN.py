@@ -8,11 +8,13 @@ returns a `list` of per-link `Data`-like objects that are views into one collate
 
 What is NOT mirrored (raises NotImplementedError, the reference's own convention for unsupported
 flows): directed graphs (`A_csc`), and `k_node_set_strategy='union'`, which the reference itself
-cannot execute (tuned_SIGN.py:243 builds a ragged tensor).  The two randomised options are
-supported with the engine's own counter-based generator — same distribution, different random
-numbers than the reference's: ScaLed random-walk subgraphs (`rw_kwargs`; torch_cluster's walks
-there) and per-hop sampling (`ratio_per_hop < 1`, `max_nodes_per_hop`; Python's `random.sample`
-there, utils.py:66-70), the latter seeded by `SAMPLING_SEED`.
+cannot execute (tuned_SIGN.py:243 builds a ragged tensor).  ScaLed subgraphs (`rw_kwargs`): the
+walk caches the caller hands in (`cached_pos_rws` / `cached_neg_rws`, `unique_nodes`; reference
+utils.py:94-108) are honoured as they are — the extracted node sets are the caller's, bit for
+bit; `s3grl_amd.scaled.create_rw_cache` builds such a cache on the engine.  Without a cache the
+engine draws the walks itself, and per-hop sampling (`ratio_per_hop < 1`, `max_nodes_per_hop`;
+Python's `random.sample` in the reference, utils.py:66-70) draws from the engine's counter-based
+generator seeded by `SAMPLING_SEED`: same distributions, other random numbers.
 """
 from __future__ import annotations
 
@@ -118,7 +120,7 @@ def _fingerprint_x(x):
     return ("n", a.shape, a.dtype.str, _hash_bytes(a))
 
 
-def _device_inputs(A, x):
+def _device_graph(A):
     eng = _engine.default_engine()
     ent = _cache.get("A")
     fp = _fingerprint_A(A)
@@ -127,7 +129,11 @@ def _device_inputs(A, x):
             ent[2].close()
         ent = (A, fp, eng.graph(A))
         _cache["A"] = ent
-    g = ent[2]
+    return eng, ent[2]
+
+
+def _device_inputs(A, x):
+    eng, g = _device_graph(A)
     ent = _cache.get("x")
     fp = _fingerprint_x(x)
     if ent is None or ent[0] is not x or ent[1] != fp:
@@ -364,13 +370,20 @@ def _as_data_list(res, K, y, fixed_rows=None):
     return LinkDataList([(rows, ptr, y)], K)
 
 
-def _rw_of(rw_kwargs):
-    """ScaLed settings of the reference's rw_kwargs (sgrl_link_pred.py:130-159): M walks of length
-    m per node.  The reference's cached walks (`cached_pos_rws`, torch_cluster RNG) cannot be
-    reproduced; the engine draws its own per-node walks from `rw_kwargs.get('seed', 0)`."""
-    if not rw_kwargs or not rw_kwargs.get('rw_m'):
-        return None
-    return (int(rw_kwargs['rw_m']), int(rw_kwargs['rw_M']), int(rw_kwargs.get('seed', 0)))
+def _rw_of(eng, rw_kwargs, y, link_index, num_nodes):
+    """ScaLed settings of the reference's rw_kwargs (sgrl_link_pred.py:130-159, utils.py:86-108) as
+    engine keywords: the node sets the caller cached (`cached_pos_rws` / `cached_neg_rws` by y, or
+    `unique_nodes`) are used as they are — the engine extracts exactly those sets —, and only when
+    none was handed in does the engine draw M walks of length m per node itself (seed =
+    `rw_kwargs.get('seed', 0)`; the reference calls torch_cluster per link there)."""
+    from . import scaled
+
+    what = scaled.resolve(rw_kwargs, y, link_index, num_nodes)
+    if what is None:
+        return {}
+    if what[0] == "walks":
+        return {"rw": what[1:]}
+    return {"node_sets": eng.node_sets(what[1], what[2], what[3])}
 
 
 # seed of the per-hop sampling draw (the reference seeds Python's global `random` from --seed,
@@ -412,7 +425,8 @@ class OptimizedSignOperations:
         assert x is not None                                  # tuned_SIGN.py:166
         eng, g, xd = _device_inputs(A, x)
         res = eng.precompute(g, xd, eng.links(link_index), mode="pos", num_hops=num_hops, sign_k=K,
-                             rw=_rw_of(rw_kwargs), **_sampling_of(ratio_per_hop, max_nodes_per_hop))
+                             **_rw_of(eng, rw_kwargs, y, link_index, g.num_nodes),
+                             **_sampling_of(ratio_per_hop, max_nodes_per_hop))
         return _as_data_list(res, K, y, fixed_rows=2)
 
     @staticmethod
@@ -431,7 +445,7 @@ class OptimizedSignOperations:
         assert x is not None                                  # tuned_SIGN.py:221
         eng, g, xd = _device_inputs(A, x)
         res = eng.precompute(g, xd, eng.links(link_index), mode="pos_plus", num_hops=num_hops,
-                             sign_k=K, strategy=strat, rw=_rw_of(rw_kwargs),
+                             sign_k=K, strategy=strat, **_rw_of(eng, rw_kwargs, y, link_index, g.num_nodes),
                              **_sampling_of(ratio_per_hop, max_nodes_per_hop))
         return _as_data_list(res, K, y)
 

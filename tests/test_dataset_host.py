@@ -120,18 +120,28 @@ def test_unsupported_flows_raise(fake_ops):
     assert fake_ops.calls == []
 
 
-def test_process_split_order_cache_and_kwargs(fake_ops, tmp_path):
+def test_process_split_order_cache_and_kwargs(fake_ops, tmp_path, monkeypatch):
     n, e = workloads.load_topology("usair")
     sp = workloads.edge_split(n, e, seed=0)
     x = torch.from_numpy(np.random.default_rng(2).random((n, 4)).astype(np.float32))
     se = sp.split_edge()
     P, Q = len(se["test"]["edge"]), len(se["test"]["edge_neg"])
     np.random.seed(3)
+    made = []
+
+    def fake_cache(A, edges, device, rw_m, rw_M, seed=0):      # stands in for the engine's walks
+        made.append((int(torch.as_tensor(edges).shape[1]), rw_m, rw_M, seed))
+        return {"cache": len(made)}
+
+    monkeypatch.setattr(ds, "create_rw_cache", fake_cache)
     rows, ptr, y, meta = ds.process_split("test", se, sp.edge_index(), n, x, 1, sign_k=2, sign_type="PoS",
                                           m=3, M=20, rw_seed=9, dataset_root=tmp_path / "USAir", seed=5)
-    # positives (y = 1) first, then negatives (y = 0); the ScaLed settings travel as rw_kwargs
+    # positives (y = 1) first, then negatives (y = 0); the ScaLed settings travel as rw_kwargs, with
+    # one walk cache per list like sgrl_link_pred.py:123-140 builds them (positives first)
     assert [(c[0], c[1], c[3]) for c in fake_ops.calls] == [("pos", P, 1), ("pos", Q, 0)]
-    assert fake_ops.calls[0][4] == {"rw_m": 3, "rw_M": 20, "sign": True, "seed": 9}
+    assert made == [(P, 3, 20, 9), (Q, 3, 20, 9)]
+    assert fake_ops.calls[0][4] == {"rw_m": 3, "rw_M": 20, "sign": True, "seed": 9,
+                                    "cached_pos_rws": {"cache": 1}, "cached_neg_rws": {"cache": 2}}
     assert np.asarray(y).tolist() == [1] * P + [0] * Q and meta["num_pos"] == P
     # the train graph handed to the operators is built from edge_index only: int ones, duplicates summed
     A = ds.train_graph(np.array([[0, 0, 1], [1, 1, 0]]), 3)
