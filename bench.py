@@ -78,12 +78,15 @@ def committed_pmc(workload, L):
     return None, None
 
 
-def collect_pmc(args, kernel_family):
-    """Counter passes of this very command as child processes (one rocprofv3 pass per counter
-    group, no trace: MI355X_MICROARCH.md, HBM section), the program itself after `--`."""
+_PMC_PASSES = []     # [(merged, disp)] of this run's counter passes: one set serves every kernel family
+
+
+def _run_pmc_passes(args):
     import shutil
     import tempfile
 
+    if _PMC_PASSES:
+        return _PMC_PASSES[0]
     sys.path.insert(0, str(REPO / "tools"))
     import pmc_collect
 
@@ -112,17 +115,85 @@ def collect_pmc(args, kernel_family):
             merged.setdefault(fam, {}).update(cs)
         disp.update(dd)
     shutil.rmtree(base, ignore_errors=True)
+    _PMC_PASSES.append((merged, disp))
+    return _PMC_PASSES[0]
+
+
+def collect_pmc(args, kernel_family, per_step=False):
+    """Counter passes of this very command as child processes (one rocprofv3 pass per counter
+    group, no trace: MI355X_MICROARCH.md, HBM section), the program itself after `--`.
+    per_step: the family runs as several launches per step (the link kernels: one per LDS class) —
+    report the sum over the launches of the one step the child runs instead of a per-launch mean."""
+    passes = _run_pmc_passes(args)
+    if passes is None:
+        return None
+    merged, disp = passes
     g = merged.get(kernel_family)
     if not g or "FETCH_SIZE" not in g or "WRITE_SIZE" not in g:
         return None
-    n = max(disp.get(kernel_family, 1), 1)
-    rec = {"kernel": kernel_family, "dispatches": n,
+    launches = max(disp.get(kernel_family, 1), 1)
+    n = 1 if per_step else launches
+    rec = {"kernel": kernel_family, "dispatches": launches, "per": "step (sum over its launches)" if per_step else "launch",
            "FETCH_SIZE_KB": g["FETCH_SIZE"] / n, "WRITE_SIZE_KB": g["WRITE_SIZE"] / n,
            "hbm_bytes_per_launch": (2.0 * g["FETCH_SIZE"] + g["WRITE_SIZE"]) * 1024.0 / n,
            "counters": merged}
     if "TCC_HIT_sum" in g:
         rec["l2_hit_rate"] = g["TCC_HIT_sum"] / max(g["TCC_HIT_sum"] + g.get("TCC_MISS_sum", 0.0), 1.0)
     return rec
+
+
+def link_kernel_roofline(args, w, link_index, stats, phase_ms, K, F, collect):
+    """Roofline block of the link-kernel phase (extraction + operator coefficients): bound = HBM in
+    the sense of SURVEY §8(d) (the CSR terms 8n + 4 vol(S) of B_link), achieved = those bytes over the
+    phase's duration between HIP events.  One-hop plans on big graphs (link_full_kernel) never touch
+    vol(S): the bytes they physically request are counted exactly from the plan."""
+    ms = phase_ms["propagate"]
+    onehop = stats.get("oriented_entries", 0) > 0
+    kname = "link_full_kernel" if onehop else "link_kernel"
+    n_ext, vol, sup, pairs = stats["extracted_nodes"], stats["total_volume"], stats["total_support"], stats["num_row_pairs"]
+    folded = stats.get("folded_links", 0)
+    L = link_index.shape[1]
+    alg = 8 * n_ext + 4 * vol
+    deg = np.diff(w.A.indptr)
+    ends = int(deg[link_index[0]].sum() + deg[link_index[1]].sum())
+    # support counts a folded link twice (algorithmic); the kernels write one list per extracted pair
+    sup_ext = sup * (L - folded) / max(L, 1)
+    if onehop:
+        reads = {"endpoint_rows": 4 * ends * (L - folded) / max(L, 1),        # the two CSR rows, staged in LDS
+                 "oriented_rows": 4 * stats["oriented_entries"],             # probes of the masked adjacency
+                 "row_bounds": 16 * n_ext}                                   # indptr + fwd_indptr pairs per node
+    else:
+        reads = {"csr_rows": 4 * vol * (1 + max(K - 1, 1)), "row_bounds": 8 * n_ext * K,
+                 "node_lists": 4 * n_ext}
+    writes = {"node_ids": 4 * n_ext, "coefficients": 8 * K * sup_ext, "jobs_and_limits": (64 + 12 * K) * pairs,
+              "levels_and_row_nodes": (128 + 16) * (L - folded)}
+    physical = sum(reads.values()) + sum(writes.values())
+    traffic, traffic_source, l2_hit, pmc = None, None, None, None
+    if collect:
+        rec = collect_pmc(args, kname, per_step=True)
+        if rec:
+            traffic, l2_hit = rec["hbm_bytes_per_launch"], rec.get("l2_hit_rate")
+            traffic_source = "collected by this run: child rocprofv3 --pmc passes of the same command, summed over the step's launches"
+            pmc = {k: rec[k] for k in rec if k != "counters"}
+    sec = ms * 1e-3
+    return {
+        "kernel": kname, "kernel_ms": ms,
+        "kernel_ms_what": "the link-kernel phase between HIP events on the context's stream: one launch per LDS "
+                          "class on forked streams, running concurrently",
+        "bound": "hbm", "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": alg / sec / 1e9 / HBM_PEAK_GBS,
+        "algorithmic_bytes": alg,
+        "algorithmic_what": "SURVEY §8(d) CSR terms of B_link over the extracted links: 8n + 4 vol(S)",
+        "physical_bytes": physical, "physical_GBps": physical / sec / 1e9,
+        "physical_reads": reads, "physical_writes": writes,
+        "traffic": traffic, "traffic_source": traffic_source, "l2_hit_rate": l2_hit, "pmc": pmc,
+        "limiter": ("dependent-load latency: ~25 steps per link (rows -> rank merge -> hash -> oriented-row "
+                    "probes -> CSR of local ids -> K pulls), each a barrier-separated round trip to L2 or LDS; "
+                    "neither HBM (this fraction) nor VALU issue is saturated") if onehop else
+                   "VALU issue of the row walk (76-86 % busy at under half of its lanes), DESIGN §2.1",
+        "phase_ms": phase_ms,
+        "folded_links": folded, "mean_subgraph_nodes": stats["total_nodes"] / max(L, 1),
+    }
 
 
 def cpu_baseline(w, link_index, y, budget_s, max_links):
@@ -573,7 +644,16 @@ def main():
                  "bytes that must cross HBM: id/coefficient lists, output"),
             ]
             best, rows = hierarchical_roofline(levels, gather_ms)
-            line["roofline"] = {
+            phase_ms = {"structure": tm["structure_ms"] / max(tm["plans"], 1.0),
+                        "propagate": tm["propagate_ms"] / max(tm["plans"], 1.0), "gather": gather_ms}
+            dominant = max(phase_ms, key=phase_ms.get)
+            line["dominant_phase"] = dominant
+            if dominant == "propagate":
+                # the link kernels dominate (config 5: one-hop plans on a big graph): THEIR block is the
+                # line's roofline; the gather's block moves to roofline_gather
+                line["roofline"] = link_kernel_roofline(args, w, link_index, stats, phase_ms, K, F,
+                                                        collect=args.collect_pmc and world == 1)
+            line["roofline" if dominant != "propagate" else "roofline_gather"] = {
                 "kernel": kname, "kernel_ms": gather_ms,
                 "bound": best["level"], "achieved": best["GBps"], "peak": best["peak_GBps"], "unit": "GB/s",
                 "frac": best["frac"], "levels": rows,
@@ -589,9 +669,7 @@ def main():
                             "4nF + 4R(K+1)(1+F).  It is not traffic: the packed operand stores only the "
                             "non-zero 16-byte chunks and X sits in the Infinity Cache, so this rate can "
                             "exceed the HBM peak; `frac` above is computed from physical bytes"},
-                "phase_ms": {"structure": tm["structure_ms"] / max(tm["plans"], 1.0),
-                             "propagate": tm["propagate_ms"] / max(tm["plans"], 1.0),
-                             "gather": gather_ms},
+                "phase_ms": phase_ms,
                 "link_kernels": {
                     "ms": tm["propagate_ms"] / max(tm["plans"], 1.0),
                     "algorithmic_bytes": 8 * stats["extracted_nodes"] + 4 * stats["total_volume"],

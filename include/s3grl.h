@@ -113,7 +113,9 @@ typedef struct s3grl_plan_stats {
                                (s,d) earlier in the list: same subgraph, rows swapped.  The
                                totals above count them like any other link (algorithmic). */
   int64_t extracted_nodes;  /* Σ n over the links actually extracted */
-  int64_t reserved[1];
+  int64_t oriented_entries; /* one-hop plans on big graphs: Σ over the extracted links of the degree-oriented
+                               row entries of their subgraph's nodes (what link_full_kernel probes: the
+                               physical counterpart of total_volume); 0 for other plans */
 } s3grl_plan_stats;
 
 typedef struct s3grl_context s3grl_context; /* device, stream, workspace arena */

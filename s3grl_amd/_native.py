@@ -60,10 +60,10 @@ class PlanStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "num_links", "total_rows", "total_nodes", "total_volume", "total_sub_edges",
         "total_support", "num_row_pairs", "max_nodes", "workspace_bytes", "folded_links",
-        "extracted_nodes")] + [("reserved", C.c_int64 * 1)]
+        "extracted_nodes", "oriented_entries")]
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
 class S3GRLError(RuntimeError):

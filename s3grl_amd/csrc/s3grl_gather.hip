@@ -32,6 +32,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_kernel(
   if (jid >= njobs) return;
   const int col0 = blockIdx.y * (CH * 256);  // first feature column of this wave's tile
   const Job job = jobs[jid];
+  if (job.split) return;   // gathered piece by piece (s3grl_plan::gjobs)
   const int cnt = __builtin_amdgcn_readfirstlane(job.support);
   const int32_t* __restrict__ ids = c_ids + job.ids_off;
   // coefficients of this pair: [K][cnt] float2 (row a, row b), operator-major
@@ -100,15 +101,15 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_kernel(
 template <int K>
 s3grl_status launch_k(s3grl_context* ctx, const Job* jobs, int64_t njobs, const int32_t* c_ids,
                       const float* c_coef, const float* job_z, const float* X, int64_t ldx,
-                      int64_t F, float* rows) {
+                      int64_t F, float* rows, hipStream_t stream) {
   const unsigned gx = (unsigned)((njobs + kWavesPerBlock - 1) / kWavesPerBlock);
   if (F <= 256) {
-    hipLaunchKernelGGL((gather_kernel<K, 1>), dim3(gx, 1), dim3(kWavesPerBlock * 64), 0, ctx->stream,
+    hipLaunchKernelGGL((gather_kernel<K, 1>), dim3(gx, 1), dim3(kWavesPerBlock * 64), 0, stream,
                        jobs, (int)njobs, c_ids, c_coef, job_z, X, ldx, (int)F, rows);
   } else {
     const unsigned gy = (unsigned)((F + 511) / 512);
     hipLaunchKernelGGL((gather_kernel<K, 2>), dim3(gx, gy), dim3(kWavesPerBlock * 64), 0,
-                       ctx->stream, jobs, (int)njobs, c_ids, c_coef, job_z, X, ldx, (int)F, rows);
+                       stream, jobs, (int)njobs, c_ids, c_coef, job_z, X, ldx, (int)F, rows);
   }
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
@@ -116,19 +117,22 @@ s3grl_status launch_k(s3grl_context* ctx, const Job* jobs, int64_t njobs, const 
 
 }  // namespace
 
-s3grl_status launch_gather(s3grl_context* ctx, const Job* jobs, int64_t njobs, const int32_t* c_ids,
-                           const float* c_coef, const float* job_z, int K, const float* X,
-                           int64_t ldx, int64_t F, float* rows) {
+s3grl_status launch_gather(s3grl_context* ctx, const GatherView& v, const int32_t* c_ids,
+                           const float* c_coef, int K, const float* X, int64_t ldx, int64_t F, float* rows,
+                           hipStream_t stream) {
+  const Job* jobs = v.jobs;
+  const int64_t njobs = v.njobs;
+  const float* job_z = v.job_z;
   if (njobs == 0) return S3GRL_OK;
   switch (K) {
-    case 1: return launch_k<1>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows);
-    case 2: return launch_k<2>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows);
-    case 3: return launch_k<3>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows);
-    case 4: return launch_k<4>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows);
-    case 5: return launch_k<5>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows);
-    case 6: return launch_k<6>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows);
-    case 7: return launch_k<7>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows);
-    case 8: return launch_k<8>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows);
+    case 1: return launch_k<1>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, stream);
+    case 2: return launch_k<2>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, stream);
+    case 3: return launch_k<3>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, stream);
+    case 4: return launch_k<4>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, stream);
+    case 5: return launch_k<5>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, stream);
+    case 6: return launch_k<6>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, stream);
+    case 7: return launch_k<7>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, stream);
+    case 8: return launch_k<8>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, stream);
     default:
       set_last_error("sign_k must be in 1..8");
       return S3GRL_ERR_INVALID_ARGUMENT;

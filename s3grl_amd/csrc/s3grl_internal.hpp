@@ -36,7 +36,7 @@ constexpr int kMaxNodesLds = 327680;   // 4 bitmaps of N bits must fit 160 KiB o
 constexpr int kMaxSignK = 8;
 constexpr int kStatShards = 64;        // see stat_slot() in s3grl_device.hpp
 constexpr int kStatStride = 16;        // int64 per shard: one 128-byte line
-constexpr int kStatRows = 4;           // Σ edges, Σ support, Σ vol, Σ n (algorithmic)
+constexpr int kStatRows = 5;           // Σ edges, Σ support, Σ vol, Σ n (algorithmic), Σ oriented-row entries
 constexpr int kMaxLevels = 32;         // BFS levels tracked per link (num_hops <= 30)
 // link_kernel keeps a whole subgraph on-chip; links are binned by LDS need into classes
 constexpr int kNumClasses = 6;
@@ -81,7 +81,32 @@ struct Job {
   int64_t mirror_row; // first output row of the same pair of the REVERSED link (dst,src) when
                       // that link is in the list too and was folded into this one, else -1
   int32_t mirror_swap;// rows a,b go to mirror_row+1, mirror_row (the src/dst pair), else same order
-  int32_t pad;
+  int32_t split;      // 1: the list is cut into pieces that are gathered on their own (s3grl_plan::gjobs)
+                      // and summed by combine_kernel; the gather launch over the jobs skips this one
+};
+
+// Jobs whose list is longer than a threshold are cut into pieces of 2^kSplitSegShift entries: the
+// longest unit of a gather launch is bounded (a 5 900-node PubMed subgraph is a 1.9 ms wavefront —
+// the tail of a launch once the list is sharded over 8 GPUs), and no fp32 running sum is longer than
+// the threshold (the pieces are added in f64): the accumulation error stops growing with the
+// subgraph.  A piece costs a wavefront's fixed work and 2 partial rows, so the threshold is as high
+// as the plan allows: the longest unit should take about half of what the launch takes anyway —
+// Σn / 8192 entries (4096 resident wavefronts, half) — between kSplitThresholdMin and
+// kSplitThreshold.  Measured on the headline (164 000 links, gather 6.96 ms unsplit): threshold 4096
+// 7.03 ms, 3072 7.16, 2048 7.48; the pieces on the context's own stream in front of the main launch:
+// +0.3 ms even for a hundred split jobs (they run on a side stream).
+// S3GRL_SPLIT_T / S3GRL_SPLIT_SEG_SHIFT override (0 = never split).
+constexpr int kSplitThreshold = 4096;
+constexpr int kSplitThresholdMin = 2048;
+constexpr int kSplitSegShift = 10;
+
+// what a gather launch works on: the jobs of a plan, or the pieces of its split jobs
+struct GatherView {
+  const Job* jobs;
+  int64_t njobs;
+  const float* job_z;
+  const int32_t* job_lim;
+  const int32_t* job_order;
 };
 
 // Grow-only caching device allocator: plans are created and destroyed every benchmark step,
@@ -171,6 +196,15 @@ struct s3grl_plan {
                                  // positions >= job_lim[j, i] (non-decreasing in i)
   float* c_coef = nullptr;       // [Σ_jobs n, K, 2]
   int64_t* row_nodes = nullptr;  // [ΣR]
+  // split jobs (Job::split): their pieces as gather units of their own
+  int split_t = 0, seg_shift = 0;  // threshold and piece size the link kernels laid the coefficients out for
+  int64_t npieces = 0;
+  int64_t* piece_off = nullptr;  // [njobs + 1] first piece of every job (no pieces for an unsplit job)
+  s3grl::Job* gjobs = nullptr;   // [npieces] out_row = 2 * piece index into the partial-row scratch
+  float* g_z = nullptr;          // [npieces, K, 2] zeros (the label column is written by the combine step)
+  int32_t* g_lim = nullptr;      // [npieces, K]
+  int32_t* g_order = nullptr;    // [npieces] identity
+  int32_t* piece_job = nullptr;  // [npieces] the job a piece belongs to
   std::vector<void*> owned;      // everything above, for release
 };
 
@@ -220,6 +254,9 @@ struct Transient {  // released on scope exit (stream-ordered reuse is safe: one
     for (void* p : ptrs) ctx->arena.release(p);
   }
 };
+
+// api.hip: the context's side streams and their fork / join events, created on first use
+s3grl_status ensure_side_streams(s3grl_context* ctx);
 
 // relabel.hip
 s3grl_status build_degree_order(s3grl_context* ctx, s3grl_graph* g);
@@ -271,7 +308,8 @@ s3grl_status build_forward_rows(s3grl_context* ctx, s3grl_graph* g);
 s3grl_status launch_count1(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                            int plus, int K, const int32_t* partner, const int32_t* mirror_of,
                            int32_t* n_nodes, int32_t* p_nodes, int32_t* n_rows, int32_t* n_jobs,
-                           int32_t* lvl_max, int32_t* e_cap, int32_t* err_flag, int64_t* tot_nodes_alg);
+                           int32_t* lvl_max, int32_t* e_cap, int32_t* err_flag, int64_t* tot_nodes_alg,
+                           int64_t* tot_oriented);
 s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                           const int32_t* class_list, const int32_t* class_count_host, int hops,
                           int plus, int cn_cap, int full_stats, int K, WalkSets ws, const int32_t* p_nodes,
@@ -282,21 +320,32 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           int64_t* tot_edges, int64_t* tot_support, int64_t* tot_vol,
                           HopSampling smp = HopSampling{1.0, 0, 0}, const int32_t* stash = nullptr,
                           int slot = 0, const int32_t* e_cap = nullptr, int64_t max_nodes = 0,
-                          const int32_t* old_of_new = nullptr, const int32_t* new_of_old = nullptr);
+                          const int32_t* old_of_new = nullptr, const int32_t* new_of_old = nullptr,
+                          int split_t = 0, int seg_shift = 0);
+// pieces of the split jobs: piece_off [njobs + 1] (device) and *total (device scalar) first, the
+// piece arrays once the host knows the total
+s3grl_status launch_split_count(s3grl_context* ctx, const Job* jobs, int64_t njobs, int seg_shift,
+                                int32_t* cnt, int64_t* piece_off, int64_t* scan_ws);
+s3grl_status launch_split_fill(s3grl_context* ctx, const Job* jobs, const int32_t* job_lim, int64_t njobs,
+                               int K, int seg_shift, const int64_t* piece_off, Job* gjobs, int32_t* g_lim,
+                               int32_t* g_order, int32_t* piece_job);
+// rows of the split jobs = f64 sum of their pieces' partial rows (+ operator 0, label column, mirror)
+s3grl_status launch_combine(s3grl_context* ctx, const s3grl_plan* p, const float* prows, const float* X,
+                            int64_t ldx, int64_t F, float* rows);
 s3grl_status launch_dists(s3grl_context* ctx, const int64_t* node_off, const int32_t* lvl, int64_t L,
                           int8_t* dists);
 // gather.hip
-s3grl_status launch_gather(s3grl_context* ctx, const Job* jobs, int64_t njobs, const int32_t* c_ids,
-                           const float* c_coef, const float* job_z, int K, const float* X,
-                           int64_t ldx, int64_t F, float* rows);
+s3grl_status launch_gather(s3grl_context* ctx, const GatherView& v, const int32_t* c_ids,
+                           const float* c_coef, int K, const float* X, int64_t ldx, int64_t F, float* rows,
+                           hipStream_t stream);
 // features.hip
 s3grl_status build_packed_rows(s3grl_context* ctx, s3grl_features* f, double max_density);
-s3grl_status launch_gather_packed(s3grl_context* ctx, const s3grl_plan* p, const s3grl_features* f,
-                                  float* rows);
+s3grl_status launch_gather_packed(s3grl_context* ctx, const s3grl_plan* p, const GatherView& v,
+                                  const s3grl_features* f, float* rows, hipStream_t stream);
 s3grl_status launch_gather_traffic(s3grl_context* ctx, const s3grl_plan* p, const s3grl_features* f,
                                    unsigned long long* d_out /* [8] device, zeroed */);
-s3grl_status launch_gather_sparse(s3grl_context* ctx, const s3grl_plan* p, const s3grl_features* f,
-                                  float* rows);
+s3grl_status launch_gather_sparse(s3grl_context* ctx, const s3grl_plan* p, const GatherView& v,
+                                  const s3grl_features* f, float* rows, hipStream_t stream);
 s3grl_status launch_copy_pad(s3grl_context* ctx, const float* X, int64_t ldx, int64_t N, int64_t F,
                              float* Y, int64_t ldy);
 

@@ -90,7 +90,8 @@ __global__ __launch_bounds__(64 * kCount1Waves) void count1_kernel(
     int K, const int32_t* __restrict__ partner, const int32_t* __restrict__ mirror_of,
     int32_t* __restrict__ n_nodes, int32_t* __restrict__ p_nodes, int32_t* __restrict__ n_rows,
     int32_t* __restrict__ n_jobs, int32_t* __restrict__ lvl_max, int32_t* __restrict__ e_cap,
-    int32_t* __restrict__ err_flag, unsigned long long* __restrict__ tot_nodes_alg) {
+    int32_t* __restrict__ err_flag, unsigned long long* __restrict__ tot_nodes_alg,
+    unsigned long long* __restrict__ tot_oriented) {
   const int lane = threadIdx.x & 63;
   const int64_t l = (int64_t)blockIdx.x * kCount1Waves + (threadIdx.x >> 6);
   if (l >= L) return;
@@ -166,6 +167,9 @@ __global__ __launch_bounds__(64 * kCount1Waves) void count1_kernel(
     e_cap[l] = (int)min(2ll * fsum, (long long)0x3fffffff);
     const unsigned long long mult = (mirror_of && mirror_of[l] >= 0) ? 2ull : 1ull;
     atomicAdd(stat_slot(tot_nodes_alg), mult * (unsigned long long)n);
+    // oriented-row entries link_full_kernel will probe for this link (measurement: bench.py's
+    // physical-bytes figure of the one-hop path)
+    atomicAdd(stat_slot(tot_oriented), (unsigned long long)fsum);
   }
 }
 
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(T) void link_full_kernel(
     int32_t* __restrict__ lvl_out, unsigned long long* __restrict__ tot_edges,
     unsigned long long* __restrict__ tot_support, unsigned long long* __restrict__ tot_vol,
     uint32_t* __restrict__ bm_scratch, int64_t bm_stride_words, int lds_bytes,
-    unsigned long long* __restrict__ dbg, const int32_t* __restrict__ old_of_new) {
+    unsigned long long* __restrict__ dbg, const int32_t* __restrict__ old_of_new, int split_t, int seg_shift) {
   extern __shared__ uint32_t smem[];
   const int tid = threadIdx.x;
   constexpr int G = 4;
@@ -551,6 +555,14 @@ __global__ __launch_bounds__(T) void link_full_kernel(
       float2* s_in = cur;
       float2* s_out = nxs;
       float2* coef = reinterpret_cast<float2*>(c_coef) + coff * K;   // [K][n] float2
+      // lists longer than split_t: coefficients piece by piece (see link_kernel)
+      const bool split = split_t > 0 && n > split_t;
+      auto cidx = [&](int i, int t) -> int64_t {
+        if (!split) return (int64_t)i * n + t;
+        const int s0 = (t >> seg_shift) << seg_shift;
+        const int len = min(1 << seg_shift, n - s0);
+        return (int64_t)s0 * K + (int64_t)i * len + (t - s0);
+      };
 #pragma unroll 1
       for (int i = 0; i < K; ++i) {
         const int g = tid & (G - 1);
@@ -558,7 +570,7 @@ __global__ __launch_bounds__(T) void link_full_kernel(
           const float dw = fabsf(dinv[t]);
           const float rx = dw * ax, ry = dw * ay;
           s_out[t] = make_float2(dw * rx, dw * ry);
-          coef[(int64_t)i * n + t] = make_float2(rx, ry);
+          coef[cidx(i, t)] = make_float2(rx, ry);
           // label column of operator i+1: r[src] + r[dst]  (tuned_SIGN.py:177-185)
           if (t == pos_src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
           if (t == pos_dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
@@ -623,7 +635,7 @@ __global__ __launch_bounds__(T) void link_full_kernel(
         j.z_b = (node_b == src || node_b == dst) ? 1 : 0;
         j.mirror_row = mirror >= 0 ? mrp + 2 * pr : -1;
         j.mirror_swap = pr == 0 ? 1 : 0;
-        j.pad = 0;
+        j.split = split ? 1 : 0;
         jobs[jid] = j;
         atomicAdd(stat_slot(tot_support), (unsigned long long)n * (mirror >= 0 ? 2ull : 1ull));
       }

@@ -158,6 +158,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
   const int jid = __builtin_amdgcn_readfirstlane(job_order[wid]);   // longest jobs start first
   const int col0 = blockIdx.y * kTile;
   const Job job = jobs[jid];
+  if (job.split) return;   // gathered piece by piece (s3grl_plan::gjobs)
   const int cnt = __builtin_amdgcn_readfirstlane(job.support);
   const uint32_t* __restrict__ uid = reinterpret_cast<const uint32_t*>(c_ids + job.ids_off);
   const float2* __restrict__ cf = reinterpret_cast<const float2*>(c_coef) + job.coef_off;
@@ -490,11 +491,19 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
 __global__ __launch_bounds__(256) void gather_traffic_kernel(
     const Job* __restrict__ jobs, int njobs, const int32_t* __restrict__ c_ids,
     const int32_t* __restrict__ job_lim, int K, int packed, const PackedHdr* __restrict__ hdr,
-    int64_t N, int F, unsigned long long* __restrict__ out) {
+    int64_t N, int F, int pieces, unsigned long long* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   const int jid = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (jid >= njobs) return;
   const Job job = jobs[jid];
+  if (job.split) {   // gathered piece by piece; the combine step writes its rows (and reads X for operator 0)
+    if (lane == 0) {
+      const unsigned long long nr = (job.node_b >= 0 ? 2 : 1) * (job.mirror_row >= 0 ? 2 : 1);
+      atomicAdd(&out[4], 4ull * nr * (K + 1) * (unsigned long long)(F + 1));
+      atomicAdd(&out[5], 16ull * ((F + 3) / 4) * (job.node_b >= 0 ? 2 : 1));
+    }
+    return;
+  }
   const int cnt = job.support;
   const int32_t* __restrict__ ids = c_ids + job.ids_off;
   const int tile_cols = packed ? kTile : (F <= 256 ? 256 : 512);
@@ -543,15 +552,16 @@ __global__ __launch_bounds__(256) void gather_traffic_kernel(
   atomicAdd(&out[2], feat);
   atomicAdd(&out[3], 8ull * coef_entries * tiles);
   atomicAdd(&out[4], 4ull * nrow * ncopy * (K + 1) * (unsigned long long)(F + 1));
-  atomicAdd(&out[5], 16ull * chunks_row * nrow);
+  // a piece's partial rows are read back once by the combine step
+  atomicAdd(&out[5], 16ull * chunks_row * nrow + (pieces ? 4ull * nrow * (K + 1) * (unsigned long long)(F + 1) : 0ull));
   atomicAdd(&out[6], (unsigned long long)tiles * (sizeof(Job) + 4ull * K + 4ull) + 8ull * K);
   atomicAdd(&out[7], (unsigned long long)tiles);
 }
 
 template <int K>
-s3grl_status launch_packed_k(s3grl_context* ctx, const s3grl_plan* p, const s3grl_features* f,
-                             float* rows) {
-  const unsigned gx = (unsigned)((p->njobs + kWavesPerBlock - 1) / kWavesPerBlock);
+s3grl_status launch_packed_k(s3grl_context* ctx, const s3grl_plan* p, const GatherView& v,
+                             const s3grl_features* f, float* rows, hipStream_t stream) {
+  const unsigned gx = (unsigned)((v.njobs + kWavesPerBlock - 1) / kWavesPerBlock);
   static const bool masked = !getenv("S3GRL_GATHER_UNMASKED");   // comparison hook: the unconditional loads
   const uint32_t data_bytes = (uint32_t)((f->pk_chunks + 1) * 16);
   // experiment hook: dynamic LDS per workgroup caps the resident waves (timing only)
@@ -561,21 +571,21 @@ s3grl_status launch_packed_k(s3grl_context* ctx, const s3grl_plan* p, const s3gr
   const int depth = p->walk_plan ? 1 : p->cfg.num_hops;
   if (K >= 2 && K - 1 >= depth && masked) {
     hipLaunchKernelGGL((gather_packed_kernel<K, true, (K >= 2 ? 2 : 1)>), dim3(gx, (unsigned)f->tiles),
-                       dim3(kWavesPerBlock * 64), lds_cap, ctx->stream, p->jobs, (int)p->njobs, p->c_ids, p->c_coef,
-                       p->job_z, p->job_lim, p->job_order, static_cast<const PackedHdr*>(f->pk_hdr),
+                       dim3(kWavesPerBlock * 64), lds_cap, stream, v.jobs, (int)v.njobs, p->c_ids, p->c_coef,
+                       v.job_z, v.job_lim, v.job_order, static_cast<const PackedHdr*>(f->pk_hdr),
                        static_cast<const float4_t*>(f->pk_data), data_bytes, f->N, f->dense, f->ld, (int)f->F, rows);
     S3GRL_HIP_TRY(hipGetLastError());
     return S3GRL_OK;
   }
   if (masked)
     hipLaunchKernelGGL((gather_packed_kernel<K, true, 1>), dim3(gx, (unsigned)f->tiles), dim3(kWavesPerBlock * 64),
-                       lds_cap, ctx->stream, p->jobs, (int)p->njobs, p->c_ids, p->c_coef, p->job_z, p->job_lim,
-                       p->job_order, static_cast<const PackedHdr*>(f->pk_hdr),
+                       lds_cap, stream, v.jobs, (int)v.njobs, p->c_ids, p->c_coef, v.job_z, v.job_lim,
+                       v.job_order, static_cast<const PackedHdr*>(f->pk_hdr),
                        static_cast<const float4_t*>(f->pk_data), data_bytes, f->N, f->dense, f->ld, (int)f->F, rows);
   else
     hipLaunchKernelGGL((gather_packed_kernel<K, false, 1>), dim3(gx, (unsigned)f->tiles), dim3(kWavesPerBlock * 64),
-                       0, ctx->stream, p->jobs, (int)p->njobs, p->c_ids, p->c_coef, p->job_z, p->job_lim,
-                       p->job_order, static_cast<const PackedHdr*>(f->pk_hdr),
+                       0, stream, v.jobs, (int)v.njobs, p->c_ids, p->c_coef, v.job_z, v.job_lim,
+                       v.job_order, static_cast<const PackedHdr*>(f->pk_hdr),
                        static_cast<const float4_t*>(f->pk_data), data_bytes, f->N, f->dense, f->ld, (int)f->F, rows);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
@@ -636,23 +646,27 @@ s3grl_status launch_gather_traffic(s3grl_context* ctx, const s3grl_plan* p, cons
   }
   hipLaunchKernelGGL(gather_traffic_kernel, dim3((unsigned)((p->njobs + 3) / 4)), dim3(256), 0, ctx->stream,
                      p->jobs, (int)p->njobs, p->c_ids, p->job_lim, p->cfg.sign_k, f->packed ? 1 : 0,
-                     static_cast<const PackedHdr*>(f->pk_hdr), f->N, (int)f->F, d_out);
+                     static_cast<const PackedHdr*>(f->pk_hdr), f->N, (int)f->F, 0, d_out);
+  if (p->npieces)
+    hipLaunchKernelGGL(gather_traffic_kernel, dim3((unsigned)((p->npieces + 3) / 4)), dim3(256), 0, ctx->stream,
+                       p->gjobs, (int)p->npieces, p->c_ids, p->g_lim, p->cfg.sign_k, f->packed ? 1 : 0,
+                       static_cast<const PackedHdr*>(f->pk_hdr), f->N, (int)f->F, 1, d_out);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
 
-s3grl_status launch_gather_packed(s3grl_context* ctx, const s3grl_plan* p, const s3grl_features* f,
-                                  float* rows) {
-  if (p->njobs == 0) return S3GRL_OK;
+s3grl_status launch_gather_packed(s3grl_context* ctx, const s3grl_plan* p, const GatherView& v,
+                                  const s3grl_features* f, float* rows, hipStream_t stream) {
+  if (v.njobs == 0) return S3GRL_OK;
   switch (p->cfg.sign_k) {
-    case 1: return launch_packed_k<1>(ctx, p, f, rows);
-    case 2: return launch_packed_k<2>(ctx, p, f, rows);
-    case 3: return launch_packed_k<3>(ctx, p, f, rows);
-    case 4: return launch_packed_k<4>(ctx, p, f, rows);
-    case 5: return launch_packed_k<5>(ctx, p, f, rows);
-    case 6: return launch_packed_k<6>(ctx, p, f, rows);
-    case 7: return launch_packed_k<7>(ctx, p, f, rows);
-    case 8: return launch_packed_k<8>(ctx, p, f, rows);
+    case 1: return launch_packed_k<1>(ctx, p, v, f, rows, stream);
+    case 2: return launch_packed_k<2>(ctx, p, v, f, rows, stream);
+    case 3: return launch_packed_k<3>(ctx, p, v, f, rows, stream);
+    case 4: return launch_packed_k<4>(ctx, p, v, f, rows, stream);
+    case 5: return launch_packed_k<5>(ctx, p, v, f, rows, stream);
+    case 6: return launch_packed_k<6>(ctx, p, v, f, rows, stream);
+    case 7: return launch_packed_k<7>(ctx, p, v, f, rows, stream);
+    case 8: return launch_packed_k<8>(ctx, p, v, f, rows, stream);
     default:
       set_last_error("sign_k must be in 1..8");
       return S3GRL_ERR_INVALID_ARGUMENT;

@@ -387,6 +387,82 @@ __global__ void validate_sets_kernel(const int64_t* __restrict__ set_ptr, const 
   }
   if (bad) atomicOr(reinterpret_cast<unsigned long long*>(flags), (unsigned long long)bad);
 }
+
+// ---- split jobs (Job::split, kSplitThreshold) ---------------------------------------------------
+// pieces per job: ceil(support / 2^seg_shift) for a split job, none otherwise
+__global__ void split_count_kernel(const Job* __restrict__ jobs, int64_t njobs, int seg_shift,
+                                   int32_t* __restrict__ cnt) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= njobs) return;
+  const Job job = jobs[j];
+  cnt[j] = job.split ? (job.support + (1 << seg_shift) - 1) >> seg_shift : 0;
+}
+
+// piece s of job j as a gather unit of its own: list entries [s·SEG, min((s+1)·SEG, support)), its
+// coefficient block (laid out by the link kernel), operator reach clamped to the piece, and two
+// rows of the partial-row scratch as output.  No mirror, no label column: combine_kernel does those.
+__global__ void split_fill_kernel(const Job* __restrict__ jobs, const int32_t* __restrict__ job_lim,
+                                  int64_t njobs, int K, int seg_shift, const int64_t* __restrict__ piece_off,
+                                  Job* __restrict__ gjobs, int32_t* __restrict__ g_lim,
+                                  int32_t* __restrict__ g_order, int32_t* __restrict__ piece_job) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= njobs) return;
+  const int64_t p0 = piece_off[j], p1 = piece_off[j + 1];
+  if (p1 == p0) return;
+  const Job job = jobs[j];
+  for (int64_t q = p0; q < p1; ++q) {
+    const int s0 = (int)(q - p0) << seg_shift;
+    const int len = min(1 << seg_shift, job.support - s0);
+    Job g = job;
+    g.coef_off = job.coef_off + (int64_t)s0 * K;
+    g.ids_off = job.ids_off + s0;
+    g.out_row = 2 * q;
+    g.support = len;
+    g.mirror_row = -1;
+    g.mirror_swap = 0;
+    g.split = 0;
+    gjobs[q] = g;
+    for (int i = 0; i < K; ++i) g_lim[q * K + i] = min(max(job_lim[j * K + i] - s0, 0), len);
+    g_order[q] = (int32_t)q;
+    piece_job[q] = (int32_t)j;
+  }
+}
+
+// Rows of a split job: operator i+1 = Σ over its pieces (ascending, in f64) of the pieces' partial
+// rows; operator 0 = [z | X[node]]; label column from job_z; the folded reversed link gets the same
+// rows swapped.  Launched over the pieces: the workgroup of a job's FIRST piece does the job's row.
+__global__ __launch_bounds__(256) void combine_kernel(
+    const Job* __restrict__ jobs, const int64_t* __restrict__ piece_off, const int32_t* __restrict__ piece_job,
+    const float* __restrict__ job_z, int K, const float* __restrict__ prows, const float* __restrict__ X,
+    int64_t ldx, int F, float* __restrict__ rows) {
+  const int64_t j = piece_job[blockIdx.x];
+  const int r = blockIdx.y;
+  const int64_t p0 = piece_off[j], p1 = piece_off[j + 1];
+  if (p0 != (int64_t)blockIdx.x) return;
+  const Job job = jobs[j];
+  if (r == 1 && job.node_b < 0) return;
+  const int Fp = F + 1;
+  const int64_t rstride = (int64_t)(K + 1) * Fp;
+  const int node = r == 0 ? job.node_a : job.node_b;
+  float* __restrict__ out = rows + (job.out_row + r) * rstride;
+  float* __restrict__ mir = job.mirror_row >= 0
+                                ? rows + (job.mirror_row + (job.mirror_swap ? 1 - r : r)) * rstride : nullptr;
+  for (int e = threadIdx.x; e < (K + 1) * Fp; e += blockDim.x) {
+    const int i = e / Fp, c = e - i * Fp;
+    float v;
+    if (c == 0) {
+      v = i == 0 ? (float)(r == 0 ? job.z_a : job.z_b) : job_z[(j * K + (i - 1)) * 2 + r];
+    } else if (i == 0) {
+      v = X[(int64_t)node * ldx + (c - 1)];
+    } else {
+      double acc = 0.0;
+      for (int64_t q = p0; q < p1; ++q) acc += (double)prows[(2 * q + r) * rstride + e];
+      v = (float)acc;
+    }
+    out[e] = v;
+    if (mir) mir[e] = v;
+  }
+}
 #endif  // !S3GRL_LINKS_PART
 
 // ---------------------------------------------------------------------------------------
@@ -659,7 +735,8 @@ __global__ __launch_bounds__(T) void link_kernel(
     unsigned long long* __restrict__ tot_support, unsigned long long* __restrict__ tot_vol,
     char* __restrict__ scratch, int64_t scratch_stride, unsigned long long* __restrict__ dbg,
     HopSampling smp, const int32_t* __restrict__ stash, int slot,
-    const int32_t* __restrict__ old_of_new, const int32_t* __restrict__ new_of_old, int lo_id) {
+    const int32_t* __restrict__ old_of_new, const int32_t* __restrict__ new_of_old, int lo_id,
+    int split_t, int seg_shift) {
   extern __shared__ uint32_t smem[];
   // the caller's id of an internal id (the graph is walked in its degree order, s3grl_relabel.hip)
   auto ext = [&](int v) -> int { return old_of_new ? old_of_new[v] : v; };
@@ -963,6 +1040,17 @@ __global__ __launch_bounds__(T) void link_kernel(
     float2* s_in = cur;
     float2* s_out = nxs;
     float2* coef = reinterpret_cast<float2*>(c_coef) + coff * K;  // [K][support] float2
+    // A list longer than split_t entries is cut into pieces of 2^seg_shift entries that the gather
+    // treats as jobs of their own (s3grl_internal.hpp, kSplitThreshold): their coefficients are laid
+    // out piece by piece, [K][piece length] each.  All pieces before the last are full, so piece s
+    // starts at s * 2^seg_shift * K.
+    const bool split = split_t > 0 && support > split_t;
+    auto cidx = [&](int i, int t) -> int64_t {
+      if (!split) return (int64_t)i * support + t;
+      const int s0 = (t >> seg_shift) << seg_shift;
+      const int len = min(1 << seg_shift, support - s0);
+      return (int64_t)s0 * K + (int64_t)i * len + (t - s0);
+    };
     // one operator step over ALL rows through the bit matrix: WL lanes per row (one word of the
     // row each, WL = the row's word count rounded up to a power of two, at most 16), the set
     // bits of a word in ascending position, then a fixed xor tree over the WL lanes:
@@ -1004,7 +1092,7 @@ __global__ __launch_bounds__(T) void link_kernel(
           const float dw = dinvP[w];
           const float rx = dw * ax, ry = dw * ay;
           if (!last) s_out[w] = make_float2(dw * rx, dw * ry);
-          coef[(int64_t)i * support + t] = make_float2(rx, ry);
+          coef[cidx(i, t)] = make_float2(rx, ry);
           if (v == src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
           if (v == dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
         }
@@ -1075,12 +1163,12 @@ __global__ __launch_bounds__(T) void link_kernel(
             }
             const float rx = dw * a.x, ry = dw * a.y;
             s_out[w] = make_float2(dw * rx, dw * ry);
-            coef[(int64_t)i * support + t] = make_float2(rx, ry);
+            coef[cidx(i, t)] = make_float2(rx, ry);
             // label column of operator i+1: Σ_w r[w] z_w = r[src] + r[dst]  (tuned_SIGN.py:177-185)
             if (v == src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
             if (v == dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
           });
-      for (int t = limit + tid; t < support; t += T) coef[(int64_t)i * support + t] = make_float2(0.f, 0.f);
+      for (int t = limit + tid; t < support; t += T) coef[cidx(i, t)] = make_float2(0.f, 0.f);
       dinv_rows = max(dinv_rows, limit);
       if (build_bm) bm_ready = true;
       __syncthreads();
@@ -1135,7 +1223,7 @@ __global__ __launch_bounds__(T) void link_kernel(
             if (t < support) {
               const float dw = a.n > 0 ? 1.0f / sqrtf((float)a.n) : 0.0f;
               const float rx = dw * a.x, ry = dw * a.y;
-              coef[(int64_t)i * support + t] = make_float2(rx, ry);
+              coef[cidx(i, t)] = make_float2(rx, ry);
               if (v == src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
               if (v == dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
             }
@@ -1164,7 +1252,7 @@ __global__ __launch_bounds__(T) void link_kernel(
       j.z_b = (node_b == src || node_b == dst) ? 1 : 0;
       j.mirror_row = mirror >= 0 ? mrp + 2 * pr : -1;
       j.mirror_swap = pr == 0 ? 1 : 0;
-      j.pad = 0;
+      j.split = split ? 1 : 0;
       jobs[jid] = j;
       atomicAdd(stat_slot(tot_support), (unsigned long long)support * (mirror >= 0 ? 2ull : 1ull));
     }
@@ -1282,6 +1370,34 @@ s3grl_status launch_walk_sets(s3grl_context* ctx, const s3grl_graph* g, const in
     set_last_error("a start node is outside [0, num_nodes)");
     return S3GRL_ERR_INVALID_ARGUMENT;
   }
+  return S3GRL_OK;
+}
+
+s3grl_status launch_split_count(s3grl_context* ctx, const Job* jobs, int64_t njobs, int seg_shift,
+                                int32_t* cnt, int64_t* piece_off, int64_t* scan_ws) {
+  if (njobs == 0) return S3GRL_OK;
+  hipLaunchKernelGGL(split_count_kernel, dim3((unsigned)((njobs + 255) / 256)), dim3(256), 0, ctx->stream, jobs,
+                     njobs, seg_shift, cnt);
+  S3GRL_HIP_TRY(hipGetLastError());
+  return launch_scan_i32_to_i64(ctx, cnt, njobs, piece_off, scan_ws);
+}
+
+s3grl_status launch_split_fill(s3grl_context* ctx, const Job* jobs, const int32_t* job_lim, int64_t njobs,
+                               int K, int seg_shift, const int64_t* piece_off, Job* gjobs, int32_t* g_lim,
+                               int32_t* g_order, int32_t* piece_job) {
+  if (njobs == 0) return S3GRL_OK;
+  hipLaunchKernelGGL(split_fill_kernel, dim3((unsigned)((njobs + 255) / 256)), dim3(256), 0, ctx->stream, jobs,
+                     job_lim, njobs, K, seg_shift, piece_off, gjobs, g_lim, g_order, piece_job);
+  S3GRL_HIP_TRY(hipGetLastError());
+  return S3GRL_OK;
+}
+
+s3grl_status launch_combine(s3grl_context* ctx, const s3grl_plan* p, const float* prows, const float* X,
+                            int64_t ldx, int64_t F, float* rows) {
+  if (p->njobs == 0 || p->npieces == 0) return S3GRL_OK;
+  hipLaunchKernelGGL(combine_kernel, dim3((unsigned)p->npieces, 2), dim3(256), 0, ctx->stream, p->jobs,
+                     p->piece_off, p->piece_job, p->job_z, p->cfg.sign_k, prows, X, ldx, (int)F, rows);
+  S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
 
@@ -1604,12 +1720,14 @@ s3grl_status build_forward_rows(s3grl_context* ctx, s3grl_graph* g) {
 s3grl_status launch_count1(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                            int plus, int K, const int32_t* partner, const int32_t* mirror_of,
                            int32_t* n_nodes, int32_t* p_nodes, int32_t* n_rows, int32_t* n_jobs,
-                           int32_t* lvl_max, int32_t* e_cap, int32_t* err_flag, int64_t* tot_nodes_alg) {
+                           int32_t* lvl_max, int32_t* e_cap, int32_t* err_flag, int64_t* tot_nodes_alg,
+                           int64_t* tot_oriented) {
   if (L == 0) return S3GRL_OK;
   hipLaunchKernelGGL(count1_kernel, dim3((unsigned)((L + kCount1Waves - 1) / kCount1Waves)),
                      dim3(64 * kCount1Waves), 0, ctx->stream, g->indptr, g->indices, g->fwd_deg,
                      (int)g->num_nodes, links, L, plus, K, partner, mirror_of, n_nodes, p_nodes, n_rows,
-                     n_jobs, lvl_max, e_cap, err_flag, reinterpret_cast<unsigned long long*>(tot_nodes_alg));
+                     n_jobs, lvl_max, e_cap, err_flag, reinterpret_cast<unsigned long long*>(tot_nodes_alg),
+                     reinterpret_cast<unsigned long long*>(tot_oriented));
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -1675,6 +1793,7 @@ struct LinkArgs {
   int big_need;   // LDS need of the biggest link of the class whose matrix / columns sit in HBM
   const int32_t *old_of_new, *new_of_old;   // non-null: the graph is walked in its degree order
   int lo_id;                                // then: ids >= lo_id have at most two stored neighbours (else -1)
+  int split_t, seg_shift;                   // lists longer than split_t are laid out in pieces of 2^seg_shift
 };
 
 // One-hop full-reach classes (link_full_kernel).  Small classes run one wavefront per link (no
@@ -1697,7 +1816,7 @@ s3grl_status launch_full_class(s3grl_context* ctx, const LinkArgs& a, int64_t L,
                      reinterpret_cast<unsigned long long*>(a.tot_support),
                      reinterpret_cast<unsigned long long*>(a.tot_vol), bm_scratch, bm_stride_words,
                      getenv("S3GRL_BIG_COLS_HBM") ? 0 : (int)lds,   // test hook: big class, columns in HBM
-                     (BMG && a.dbg) ? a.dbg : nullptr, a.old_of_new);
+                     (BMG && a.dbg) ? a.dbg : nullptr, a.old_of_new, a.split_t, a.seg_shift);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -1727,7 +1846,7 @@ s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t 
                      reinterpret_cast<unsigned long long*>(a.tot_edges),
                      reinterpret_cast<unsigned long long*>(a.tot_support),
                      reinterpret_cast<unsigned long long*>(a.tot_vol), a.scratch, a.scratch_stride,
-                     a.dbg, a.smp, a.stash, a.slot, a.old_of_new, a.new_of_old, a.lo_id);
+                     a.dbg, a.smp, a.stash, a.slot, a.old_of_new, a.new_of_old, a.lo_id, a.split_t, a.seg_shift);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -1758,13 +1877,7 @@ s3grl_status launch_link_class(s3grl_context* ctx, const LinkArgs& a, int64_t L,
 // The launches of the LDS classes do not depend on each other: they go round-robin onto the
 // context's stream and its side streams (forked and joined with events), so that the tail of one
 // class overlaps the start of the next instead of draining the chip five times per plan.
-static s3grl_status side_streams(s3grl_context* ctx) {
-  for (int i = 0; i < s3grl_context::kSide; ++i)
-    if (!ctx->side[i]) S3GRL_HIP_TRY(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
-  for (int i = 0; i <= s3grl_context::kSide; ++i)
-    if (!ctx->side_ev[i]) S3GRL_HIP_TRY(hipEventCreateWithFlags(&ctx->side_ev[i], hipEventDisableTiming));
-  return S3GRL_OK;
-}
+static s3grl_status side_streams(s3grl_context* ctx) { return ensure_side_streams(ctx); }
 
 template <int K>
 s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
@@ -1890,7 +2003,8 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           int32_t* lvl,
                           int64_t* tot_edges, int64_t* tot_support, int64_t* tot_vol,
                           HopSampling smp, const int32_t* stash, int slot, const int32_t* e_cap,
-                          int64_t max_nodes, const int32_t* old_of_new, const int32_t* new_of_old) {
+                          int64_t max_nodes, const int32_t* old_of_new, const int32_t* new_of_old,
+                          int split_t, int seg_shift) {
   if (L == 0) return S3GRL_OK;
   // links too large for LDS keep their lists in HBM scratch: one 256-byte aligned slice each
   Transient scratch_owner{ctx, {}};
@@ -1909,7 +2023,7 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
              tot_support, tot_vol, scratch, scratch_stride,
              getenv("S3GRL_DEBUG_STAMPS") ? reinterpret_cast<unsigned long long*>(ctx->d_scalars + 16) : nullptr,
              smp, stash, slot, e_cap, nullptr, 0, 0, 0, old_of_new, new_of_old,
-             (old_of_new && !getenv("S3GRL_NO_LEAF_WALK")) ? g->deg_le2_from : -1};
+             (old_of_new && !getenv("S3GRL_NO_LEAF_WALK")) ? g->deg_le2_from : -1, split_t, seg_shift};
   // the class whose bit matrix does not fit LDS: one slice per resident workgroup of a persistent grid
   if (class_count_host[kFullBig] > 0) {
     // slice = list of found edges (uint32, at most ecap / 2) + CSR columns (uint16 x ecap) of the

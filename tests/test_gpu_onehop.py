@@ -61,6 +61,7 @@ def test_onehop_path_equals_bitmap_flavour(eng, monkeypatch, name, K, bm_hbm):
             assert torch.equal(a, b)                      # node lists, canonical order, hop distances
         s0, s1 = dict(p0.stats), dict(p1.stats)
         s0.pop("workspace_bytes"), s1.pop("workspace_bytes")
+        assert s0.pop("oriented_entries") == 0 and s1.pop("oriented_entries") > 0   # a one-hop-path figure
         assert s0 == s1                                   # n, vol(S), induced edges, support: exact
         # two summation orders of the same fp32 sums (the multi-hop path walks the degree order)
         assert rel_err(r1.cpu().numpy(), r0.cpu().numpy()) < 3e-6
@@ -89,6 +90,7 @@ def test_onehop_path_degree_order_is_invisible(eng, monkeypatch, name, bm_hbm):
         (G0, p0), (G1, p1) = _plans(eng, monkeypatch, A, links, "pos_plus", 3, bm_hbm)
         st = dict(p1.stats)
         st.pop("workspace_bytes")
+        st.pop("oriented_entries")        # ties of the (degree, id) orientation follow the id order walked
         outs.append((p1.run(f).clone(), p1.row_ptr().clone(), p1.row_nodes().clone(),
                      [t.clone() for t in p1.export_subgraphs()], st))
         p0.close(), p1.close(), G0.close(), G1.close()
