@@ -370,6 +370,8 @@ def main():
     ap.add_argument("--max-links", type=int, default=0, help="truncate the link list (debug)")
     ap.add_argument("--chunks", type=int, default=2,
                     help="N > 1: pieces per rank (all-gather of piece c overlaps the compute of c+1)")
+    ap.add_argument("--contiguous-shards", action="store_true",
+                    help="N > 1: contiguous ranges of the list instead of pair-aware shards (comparison)")
     ap.add_argument("--no-allgather", action="store_true",
                     help="N > 1: every rank keeps its shard (data-parallel consumer); no collective")
     ap.add_argument("--verify", action="store_true",
@@ -449,7 +451,7 @@ def main():
             return res.stats
         plan = eng.plan(g, links, mode=w.mode, num_hops=w.num_hops, sign_k=K)
         if out is None:
-            out = torch.empty((plan.stats["total_rows"], K + 1, F + 1), dtype=torch.float32,
+            out = torch.empty((plan.total_rows, K + 1, F + 1), dtype=torch.float32,
                               device=eng.device)
         plan.run(x, out)
         st = dict(plan.stats)
@@ -461,28 +463,34 @@ def main():
     if world > 1:
         # shard weights, once at set-up (like the uploads): exact subgraph sizes from the engine's
         # sizing pass; SoP extracts no subgraph, its cost is one gather per link + the scalar ball
-        cost = parallel.measured_cost(eng, g, link_index, w.num_hops) if w.mode != "sop" \
+        # a reversed duplicate is priced at what it costs once it is folded into its primary, and the
+        # assignment keeps the two directions of a pair on one rank (parallel.shard_assignment)
+        cost = parallel.measured_cost(eng, g, link_index, w.num_hops, mode=w.mode) if w.mode != "sop" \
             else parallel.link_cost(w.A, link_index) + 64.0
         li_dev = torch.as_tensor(link_index).to(eng.device)
+        shards = parallel.ShardPlan(li_dev, world, cost, pair_aware=not args.contiguous_shards, device=eng.device)
         gather = not args.no_allgather
         timers = {}
+        fold_stats = {}
         if fixed_rows:
-            compute = parallel.engine_compute(eng, g, x, mode=w.mode, num_hops=w.num_hops, sign_k=K)
+            compute = parallel.engine_compute(eng, g, x, mode=w.mode, num_hops=w.num_hops, sign_k=K, stats=fold_stats)
 
             def step_sharded():
                 return parallel.sharded_precompute(
-                    compute, li_dev, rank=rank, world_size=world, cost=cost, gather=gather,
+                    compute, li_dev, rank=rank, world_size=world, gather=gather,
                     rows_per_link=2, chunks=args.chunks if gather else 1, row_shape=(K + 1, F + 1),
-                    device=eng.device, timers=timers, reuse_buffers=True)
+                    device=eng.device, timers=timers, reuse_buffers=True, shards=shards)
         else:
             def compute_ragged(shard):
                 res = eng.precompute(g, x, eng.links(shard), mode=w.mode, num_hops=w.num_hops, sign_k=K)
+                fold_stats["links"] = fold_stats.get("links", 0) + res.stats["num_links"]
+                fold_stats["folded_links"] = fold_stats.get("folded_links", 0) + res.stats["folded_links"]
                 return res.rows, res.row_ptr
 
             def step_sharded():
                 return parallel.sharded_precompute(compute_ragged, li_dev, rank=rank, world_size=world,
-                                                   cost=cost, gather=gather)
-        b = parallel.shard_bounds(L, world, cost)
+                                                   gather=gather, shards=shards)
+        b = shards.bounds
         shard_info = {"bounds": b, "links_per_rank": [b[r + 1] - b[r] for r in range(world)]}
 
     def step():
@@ -500,6 +508,8 @@ def main():
         stats = step()
     barrier()
     eng.set_profiling(True)
+    if world > 1:
+        fold_stats.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         stats = step()
@@ -522,7 +532,9 @@ def main():
                 "structure_ms": tm["structure_ms"] / args.steps, "propagate_ms": tm["propagate_ms"] / args.steps,
                 "gather_ms": tm["gather_ms"] / args.steps,
                 "sop_ms": (tm["sop_setup_ms"] + tm["sop_run_ms"]) / args.steps,
-                "plans_per_step": tm["plans"] / args.steps}
+                "plans_per_step": tm["plans"] / args.steps,
+                "links": fold_stats.get("links", 0) // max(args.steps, 1),
+                "folded_links": fold_stats.get("folded_links", 0) // max(args.steps, 1)}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
 
@@ -535,8 +547,9 @@ def main():
         else:
             ref = eng.precompute(g, x, links, mode=w.mode, num_hops=w.num_hops, sign_k=K).rows
         if args.no_allgather:
-            lo, hi = shard_info["bounds"][rank], shard_info["bounds"][rank + 1]
-            ok = fixed_rows and torch.equal(rows_sh, ref[2 * lo:2 * hi])
+            mine_ix = shards.order_dev[shard_info["bounds"][rank]:shard_info["bounds"][rank + 1]]
+            ok = fixed_rows and torch.equal(rows_sh.view((-1, 2) + tuple(ref.shape[1:])),
+                                            ref.view((L, 2) + tuple(ref.shape[1:]))[mine_ix])
         else:
             ok = rows_sh.shape == ref.shape and torch.equal(rows_sh, ref)
         flag = torch.tensor([1 if ok else 0], dtype=torch.int64,
@@ -583,12 +596,16 @@ def main():
         if world > 1:
             comp = [r["structure_ms"] + r["propagate_ms"] + r["gather_ms"] + r["sop_ms"] for r in per_rank]
             line["multi_gpu"] = {
-                "sharding": "contiguous link ranges balanced by the engine's per-link cost model on exact "
-                            "subgraph sizes (the sizing pass over the whole list, once at set-up: "
-                            "parallel.measured_cost / s3grl_plan_link_cost); graph + X replicated",
+                "sharding": ("contiguous link ranges" if args.contiguous_shards else
+                             "pair-aware shards (both directions of a pair on one rank, so the fold of reversed "
+                             "duplicates survives; pairs in order of first appearance)") +
+                            " balanced by the engine's per-link cost model on exact subgraph sizes (the sizing "
+                            "pass over the whole list, once at set-up: parallel.measured_cost / "
+                            "s3grl_plan_link_cost, a folded duplicate priced at its output rows); graph + X replicated",
+                "folded_links_total": sum(r["folded_links"] for r in per_rank),
                 "collective": None if args.no_allgather else
-                              ("%d padded all_gather_into_tensor per step (pieces of a range are gathered on "
-                               "RCCL's stream while the next piece is computed) + compaction" % args.chunks
+                              ("%d padded all_gather_into_tensor per step (pieces of a shard are gathered on "
+                               "RCCL's stream while the next piece is computed) + scatter into list order" % args.chunks
                                if fixed_rows else "sizes + one padded all_gather_into_tensor + compaction"),
                 "backend": backend, "links_per_rank": shard_info["links_per_rank"],
                 "per_rank": per_rank,

@@ -73,7 +73,9 @@ typedef enum s3grl_strategy {
 #define S3GRL_FLAG_COUNT_ONLY 4u /* sizing pass only: the plan holds the subgraph sizes (node_ptr of
                                     s3grl_plan_export_subgraphs, total_nodes / max_nodes / total_rows
                                     of the stats) and nothing else; it cannot be run.  Used to
-                                    balance the shards of a multi-GPU job by exact subgraph size */
+                                    balance the shards of a multi-GPU job by exact subgraph size.
+                                    Reversed duplicates are folded like in a full plan (size 0 for
+                                    the folded link) unless S3GRL_FLAG_NO_FOLD is set too */
 
 /* sign_kwargs / call arguments of the reference operators (tuned_SIGN.py:137-138,145,200,229) */
 typedef struct s3grl_cfg {
@@ -189,8 +191,12 @@ s3grl_status s3grl_walk_sets(s3grl_context* ctx, const s3grl_graph* g, const int
                              int64_t* set_ptr, int32_t* set_nodes);
 
 s3grl_status s3grl_plan_destroy(s3grl_plan* p);
-/* host struct out */
+/* host struct out.  Plan creation does not wait for its last kernels (the gather of s3grl_run* is
+ * queued right behind them): total_sub_edges / total_support / total_volume are read back here, i.e.
+ * this call waits for the context's stream when it is the first to ask. */
 s3grl_status s3grl_plan_get_stats(const s3grl_plan* p, s3grl_plan_stats* out);
+/* ΣR alone (host int64 out): what the caller sizes `rows` by; never waits */
+s3grl_status s3grl_plan_total_rows(const s3grl_plan* p, int64_t* total_rows);
 /* device int64 [L+1] out */
 s3grl_status s3grl_plan_row_ptr(const s3grl_plan* p, int64_t* row_ptr);
 /* device int64 [total_rows] out: global node id of every output row */
@@ -204,11 +210,15 @@ s3grl_status s3grl_plan_export_subgraphs(const s3grl_plan* p, int64_t* node_ptr,
 
 /* Relative cost of every link (device fp32 [L] out), in arbitrary units, from the sizes the plan
  * measured — what a multi-GPU caller balances its shards by (a count-only plan is enough).  The
- * model follows the kernels and was fitted on MI355X: multi-hop plans  n + 800  (gather and row
- * walks grow with the subgraph, ~800 nodes' worth of fixed work per link: PubMed 8 shards within
- * 4 % of each other); one-hop plans on big graphs  e_bound + 150  with e_bound the bound of the
- * induced entries the sizing pass derives from the degree-oriented rows (a hub-rich positive costs
- * several times a random negative of the collab-scale workload; node counts alone say 1.5x). */
+ * model follows the kernels and was fitted on MI355X: multi-hop plans  pairs * n + 400  (gather and
+ * row walks grow with the subgraph and with the row pairs of PoS Plus, ~400 nodes' worth of fixed
+ * work per link); one-hop plans on big graphs  e_bound + 150 + (pairs - 1) * n  with e_bound the
+ * bound of the induced entries the sizing pass derives from the degree-oriented rows (a hub-rich
+ * positive costs several times a random negative of the collab-scale workload; node counts alone
+ * say 1.5x).  A reversed duplicate (d,s) that the plan folds into its primary (s,d) costs 250: its two
+ * output rows and bookkeeping (least squares over the shards of 2-, 4- and 8-way splits of PubMed:
+ * 410 / 290 at sign_k = 3, 310 / 260 at sign_k = 5) — so the cost of a pair is what ONE rank pays for it when both directions are kept
+ * together (s3grl_amd.parallel.shard_assignment); with S3GRL_FLAG_NO_FOLD every link is priced in full. */
 s3grl_status s3grl_plan_link_cost(const s3grl_plan* p, float* cost);
 
 /* PoS / PoS Plus, feature half: rows[r, i, :] = [z | Σ_w Â^i[row r, w] X[w, :]].

@@ -13,8 +13,10 @@ import numpy as np
 HERE = Path(__file__).resolve().parent
 SRC = HERE / "s3grl_oracle_c.c"
 LIB = HERE / "_build" / "libs3grl_oracle_c.so"
+LIB_F32 = HERE / "_build" / "libs3grl_oracle_c_f32.so"
 
 _lib = None
+_lib_f32 = None
 
 
 def build(force=False):
@@ -39,6 +41,15 @@ def lib():
     return _lib
 
 
+def lib_f32():
+    """The same source built with float arithmetic (`make f32`): the reference's own precision."""
+    global _lib_f32
+    if _lib_f32 is None:
+        build()
+        _lib_f32 = C.CDLL(str(LIB_F32))
+    return _lib_f32
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -49,10 +60,13 @@ def _csr(A):
     return indptr, indices
 
 
-def pos_rows(link_index, num_hops, A, X, sign_k, *, plus=False, threads=0):
+def pos_rows(link_index, num_hops, A, X, sign_k, *, plus=False, threads=0, f32=False):
     """(rows fp64 [sum R, K+1, 1+F], row_ptr int64 [L+1], row_nodes int64 [sum R],
     node_count int32 [L]) for `link_index` [2, L] — the collated output of the reference's
-    get_PoS_prepped_ds / get_PoS_Plus_prepped_ds ('intersection')."""
+    get_PoS_prepped_ds / get_PoS_Plus_prepped_ds ('intersection').  `f32`: the diffusion half in
+    float arithmetic (the reference's precision) instead of double; the result is still returned as
+    fp64 values."""
+    compute = lib_f32() if f32 else lib()
     links = np.ascontiguousarray(np.asarray(link_index, dtype=np.int64).T)
     L = links.shape[0]
     indptr, indices = _csr(A)
@@ -68,7 +82,7 @@ def pos_rows(link_index, num_hops, A, X, sign_k, *, plus=False, threads=0):
     rows = np.empty((int(row_ptr[-1]), sign_k + 1, 1 + F), dtype=np.float64)
     row_nodes = np.empty(int(row_ptr[-1]), dtype=np.int64)
     node_count = np.empty(L, dtype=np.int32)
-    rc = lib().s3grl_oracle_c_pos(C.c_int64(N), _p(indptr), _p(indices), _p(X), C.c_int64(F),
+    rc = compute.s3grl_oracle_c_pos(C.c_int64(N), _p(indptr), _p(indices), _p(X), C.c_int64(F),
                                   C.c_int64(F), _p(links), C.c_int64(L), int(num_hops), int(sign_k),
                                   int(plus), int(threads), _p(row_ptr), _p(rows), _p(row_nodes),
                                   _p(node_count))

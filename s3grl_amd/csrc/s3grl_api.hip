@@ -119,10 +119,21 @@ __global__ void max_i32_kernel(const int32_t* __restrict__ in, int64_t n, int64_
 }
 
 __global__ void link_cost_kernel(const int32_t* __restrict__ n_nodes, const int32_t* __restrict__ e_cap,
-                                 int64_t L, float* __restrict__ cost) {
+                                 const int64_t* __restrict__ row_ptr, int64_t L, float* __restrict__ cost) {
   const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= L) return;
-  cost[l] = e_cap ? (float)e_cap[l] + 150.f : (float)n_nodes[l] + 800.f;
+  const int n = n_nodes[l];
+  // a reversed duplicate folded into its primary is not extracted (n == 0): it costs its output rows
+  // and its share of the per-link bookkeeping
+  if (n == 0) {
+    cost[l] = 250.f;
+    return;
+  }
+  // every row pair beyond the first (PoS Plus: the common-neighbour rows) is another K passes over the
+  // subgraph and another gather job over its list
+  const float pairs = (float)((row_ptr[l + 1] - row_ptr[l] + 1) / 2);
+  cost[l] = e_cap ? (float)e_cap[l] + 150.f + (pairs - 1.f) * (float)n
+                  : pairs * (float)n + 400.f;
 }
 
 // job_n[job_off[l] + p] = n_nodes[l]: every row pair of a link gets a list of the link's size
@@ -242,8 +253,36 @@ static s3grl_status resolve_pending_gather(s3grl_context* ctx) {
   return S3GRL_OK;
 }
 
+// Totals the link kernels of the last plan summed (see s3grl_context::stats_owner)
+static s3grl_status resolve_plan_stats(s3grl_context* ctx) {
+  s3grl_plan* p = ctx->stats_owner;
+  if (!p) return S3GRL_OK;
+  ctx->stats_owner = nullptr;
+  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  constexpr size_t kStatRow = (size_t)kStatShards * kStatStride;
+  auto total = [&](int row) {
+    int64_t t = 0;
+    for (int k = 0; k < kStatShards; ++k) t += ctx->h_stats[row * kStatRow + (size_t)k * kStatStride];
+    return t;
+  };
+  p->stats.total_sub_edges = total(0);
+  p->stats.total_support = total(1);
+  p->stats.total_volume = total(2);
+  p->stats_pending = false;
+  if (ctx->profiling) {
+    float ms = 0;
+    S3GRL_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->timings[0] += ms;
+    S3GRL_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
+    ctx->timings[1] += ms;
+    ctx->timings[6] += 1.0;
+  }
+  return S3GRL_OK;
+}
+
 s3grl_status s3grl_context_set_profiling(s3grl_context* ctx, int32_t enabled) {
   if (!ctx) return S3GRL_ERR_INVALID_ARGUMENT;
+  S3GRL_TRY(resolve_plan_stats(ctx));
   S3GRL_TRY(resolve_pending_gather(ctx));
   ctx->profiling = enabled != 0;
   for (double& t : ctx->timings) t = 0.0;   // (re)start accumulation
@@ -252,6 +291,7 @@ s3grl_status s3grl_context_set_profiling(s3grl_context* ctx, int32_t enabled) {
 
 s3grl_status s3grl_context_timings(s3grl_context* ctx, double* what) {
   if (!ctx || !what) return S3GRL_ERR_INVALID_ARGUMENT;
+  S3GRL_TRY(resolve_plan_stats(ctx));
   S3GRL_TRY(resolve_pending_gather(ctx));
   std::memcpy(what, ctx->timings, sizeof(ctx->timings));
   return S3GRL_OK;
@@ -353,6 +393,10 @@ s3grl_status s3grl_graph_destroy(s3grl_graph* g) {
 
 s3grl_status s3grl_plan_destroy(s3grl_plan* p) {
   if (!p) return S3GRL_OK;
+  if (p->ctx->stats_owner == p) {   // nobody asked for the totals; the events of a profiled plan still count
+    if (p->ctx->profiling) (void)resolve_plan_stats(p->ctx);
+    p->ctx->stats_owner = nullptr;
+  }
   for (void* q : p->owned) p->ctx->arena.release(q);
   delete p;
   return S3GRL_OK;
@@ -440,6 +484,7 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
     if (sets->num_set_nodes < 0 || (sets->num_set_nodes > 0 && !sets->set_nodes)) return S3GRL_ERR_INVALID_ARGUMENT;
   }
   S3GRL_HIP_TRY(hipSetDevice(ctx->device));
+  S3GRL_TRY(resolve_plan_stats(ctx));   // the statistics buffers are about to be reused
   const int K = cfg->sign_k;
 
   std::unique_ptr<s3grl_plan, s3grl_status (*)(s3grl_plan*)> plan(new s3grl_plan(),
@@ -476,10 +521,11 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   S3GRL_TRY(arena_alloc(ctx, (size_t)L, &lvl_max, tr));
   S3GRL_TRY(arena_alloc(ctx, (size_t)L, &n_jobs, tr));
   S3GRL_TRY(arena_alloc(ctx, (size_t)L * num_class_lists(), &class_list, tr));
-  S3GRL_TRY(arena_alloc(ctx, (size_t)scan_workspace_elems(L), &scan_ws, tr));
+  S3GRL_TRY(arena_alloc(ctx, (size_t)3 * scan_workspace_elems(L), &scan_ws, tr));
 
   // d_scalars (int64 x 64): [0] err flag, [1] max n, [2] Σ edges, [3] Σ support, [4] Σ vol,
-  // [5] max R, [6] Σ n counting folded links twice, [7] folded links, [8] node-set flags, [16..23] debug stamps,
+  // [5] max R, [6] Σ n counting folded links twice, [7] folded links, [8] node-set flags, [9..11] Σ n of the
+  // extracted links, Σ R, row pairs, [16..23] debug stamps,
   // [32..47] class counts (int32 each, see classify_kernel)
   int64_t* ds = ctx->d_scalars;
   int64_t* hs = ctx->h_scalars;
@@ -526,7 +572,7 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   // reversed duplicates (both directions of a train edge) are folded into one extraction
   int32_t *partner = nullptr, *mirror_of = nullptr;
   // (a set per LINK need not be the set of the reversed link)
-  const bool fold = !(cfg->flags & (S3GRL_FLAG_FULL_STATS | S3GRL_FLAG_NO_FOLD | S3GRL_FLAG_COUNT_ONLY)) &&
+  const bool fold = !(cfg->flags & (S3GRL_FLAG_FULL_STATS | S3GRL_FLAG_NO_FOLD)) &&
                     !(sets && sets->per_link) && !getenv("S3GRL_NO_MIRROR");
   // per-hop sampling (utils.py:66-70; the reference's rw branch ignores it).  Its BFS keeps a
   // fourth bitmap, so the plan stays on the bitmap flavour of the visited set.
@@ -594,24 +640,20 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
                            reinterpret_cast<int32_t*>(ds), st + 3 * kStatRow, smp, stash, slot, plan->lvl));
   }
   if (fold) S3GRL_TRY(launch_mirror_rows(ctx, partner, L, n_rows));
-  S3GRL_TRY(launch_scan_i32_to_i64(ctx, plan->n_nodes, L, plan->node_off, scan_ws));
-  S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_rows, L, plan->row_ptr, scan_ws));
-  S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_jobs, L, plan->job_off, scan_ws));
-  hipLaunchKernelGGL(max_i32_kernel, dim3(256), dim3(256), 0, ctx->stream, plan->n_nodes, L, ds + 1);
-  hipLaunchKernelGGL(max_i32_kernel, dim3(256), dim3(256), 0, ctx->stream, n_rows, L, ds + 5);
-  S3GRL_HIP_TRY(hipGetLastError());
+  // offsets of nodes / rows / row pairs, their maxima (ds[1], ds[5]) and totals (ds[9..11]) in one go
+  S3GRL_TRY(launch_scan3(ctx, plan->n_nodes, n_rows, n_jobs, L, plan->node_off, plan->row_ptr, plan->job_off,
+                         scan_ws, ds + 1, ds + 5, ds + 9));
   // PoS has no common-neighbour rows: the LDS classes are known without a round trip
   if (!plus)
     S3GRL_TRY(launch_classify(ctx, g, 1, K, plan->n_nodes, p_nodes, lvl_max, L, class_count, class_list,
                               !sampling, e_cap, stash ? slot : 0));
-  S3GRL_HIP_TRY(hipMemcpyAsync(hs, ds, 8 * 8, hipMemcpyDeviceToHost, ctx->stream));
-  S3GRL_HIP_TRY(hipMemcpyAsync(hs + 32, ds + 32, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipMemcpyAsync(hs, ds, 48 * 8, hipMemcpyDeviceToHost, ctx->stream));   // scalars + class counts
   S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_stats + 3 * kStatRow, st + 3 * kStatRow, 2 * kStatRow * sizeof(int64_t),
                                hipMemcpyDeviceToHost, ctx->stream));
-  S3GRL_HIP_TRY(hipMemcpyAsync(hs + 16, plan->node_off + L, 8, hipMemcpyDeviceToHost, ctx->stream));
-  S3GRL_HIP_TRY(hipMemcpyAsync(hs + 17, plan->row_ptr + L, 8, hipMemcpyDeviceToHost, ctx->stream));
-  S3GRL_HIP_TRY(hipMemcpyAsync(hs + 18, plan->job_off + L, 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  hs[16] = hs[9];    // Σ n over the extracted links, Σ R, row pairs
+  hs[17] = hs[10];
+  hs[18] = hs[11];
   const int err = (int)(hs[0] & 0xffffffff);
   if (err == 2) {
     set_last_error("a link has src == dst");
@@ -699,8 +741,7 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   // lists longer than split_t entries are gathered in pieces of 2^seg_shift (kSplitThreshold)
   int seg_shift = kSplitSegShift;
   if (const char* e = getenv("S3GRL_SPLIT_SEG_SHIFT")) seg_shift = std::min(20, std::max(4, atoi(e)));
-  int split_t = (int)std::min<int64_t>(kSplitThreshold, std::max<int64_t>(kSplitThresholdMin, tot_n / 8192));
-  split_t = (split_t >> seg_shift) << seg_shift;
+  int split_t = kSplitThreshold;
   if (const char* e = getenv("S3GRL_SPLIT_T")) split_t = std::max(0, atoi(e));
   if (split_t > 0) split_t = std::max(split_t, 1 << seg_shift);   // a split job has at least two pieces
   if (max_n <= split_t) split_t = 0;                               // nothing to split in this plan
@@ -726,41 +767,37 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   S3GRL_TRY(record(ctx, 2));
   S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_stats, st, 3 * kStatRow * sizeof(int64_t), hipMemcpyDeviceToHost,
                                ctx->stream));
-  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
-  if (split_t > 0 && hs[21] > 0) {
-    const int64_t np = hs[21];
-    plan->npieces = np;
-    S3GRL_TRY(arena_alloc(ctx, (size_t)np, &plan->gjobs, own));
-    S3GRL_TRY(arena_alloc(ctx, (size_t)np * K * 2, &plan->g_z, own));
-    S3GRL_TRY(arena_alloc(ctx, (size_t)np * K, &plan->g_lim, own));
-    S3GRL_TRY(arena_alloc(ctx, (size_t)np, &plan->g_order, own));
-    S3GRL_TRY(arena_alloc(ctx, (size_t)np, &plan->piece_job, own));
-    S3GRL_HIP_TRY(hipMemsetAsync(plan->g_z, 0, (size_t)np * K * 2 * sizeof(float), ctx->stream));
-    S3GRL_TRY(launch_split_fill(ctx, plan->jobs, plan->job_lim, njobs, K, seg_shift, plan->piece_off, plan->gjobs,
-                                plan->g_lim, plan->g_order, plan->piece_job));
-  }
-  plan->stats.total_sub_edges = stat_total(0);
-  plan->stats.total_support = stat_total(1);
-  plan->stats.total_volume = stat_total(2);
-  if (getenv("S3GRL_DEBUG_STAMPS")) {   // diagnostic build aid: cycles per link_kernel phase
-    S3GRL_HIP_TRY(hipMemcpy(hs + 16, ds + 16, 8 * 8, hipMemcpyDeviceToHost));
-    fprintf(stderr, "[s3grl] link_kernel phase cycles (sum over workgroups): bfs %lld  P/rank %lld  "
-                    "deg %lld  ops<K %lld  last op %lld  tail %lld\n",
-            (long long)hs[16], (long long)hs[17], (long long)hs[18], (long long)hs[19],
-            (long long)hs[20], (long long)hs[21]);
-    S3GRL_HIP_TRY(hipMemcpy(hs + 24, ds + 24, 8 * 8, hipMemcpyDeviceToHost));
-    fprintf(stderr, "[s3grl] link_full_kernel, big class: merge %lld  hash+ids %lld  probes %lld  "
-                    "csr+sort %lld  passes %lld\n",
-            (long long)hs[24], (long long)hs[25], (long long)hs[26], (long long)hs[27], (long long)hs[28]);
-  }
   plan->stats.workspace_bytes = (int64_t)ctx->arena.bytes_held();
-  if (ctx->profiling) {
-    float ms = 0;
-    S3GRL_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
-    ctx->timings[0] += ms;
-    S3GRL_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
-    ctx->timings[1] += ms;
-    ctx->timings[6] += 1.0;
+  // The totals (Σ edges / support / vol) are read back when somebody asks for them: no wait for the
+  // link kernels here, so the gather can be queued right behind them.  Plans with split jobs need
+  // the piece count on the host now.
+  plan->stats_pending = true;
+  ctx->stats_owner = plan.get();
+  if (split_t > 0 || getenv("S3GRL_DEBUG_STAMPS")) {
+    S3GRL_TRY(resolve_plan_stats(ctx));
+    if (split_t > 0 && hs[21] > 0) {
+      const int64_t np = hs[21];
+      plan->npieces = np;
+      S3GRL_TRY(arena_alloc(ctx, (size_t)np, &plan->gjobs, own));
+      S3GRL_TRY(arena_alloc(ctx, (size_t)np * K * 2, &plan->g_z, own));
+      S3GRL_TRY(arena_alloc(ctx, (size_t)np * K, &plan->g_lim, own));
+      S3GRL_TRY(arena_alloc(ctx, (size_t)np, &plan->g_order, own));
+      S3GRL_TRY(arena_alloc(ctx, (size_t)np, &plan->piece_job, own));
+      S3GRL_HIP_TRY(hipMemsetAsync(plan->g_z, 0, (size_t)np * K * 2 * sizeof(float), ctx->stream));
+      S3GRL_TRY(launch_split_fill(ctx, plan->jobs, plan->job_lim, njobs, K, seg_shift, plan->piece_off, plan->gjobs,
+                                  plan->g_lim, plan->g_order, plan->piece_job));
+    }
+    if (getenv("S3GRL_DEBUG_STAMPS")) {   // diagnostic build aid: cycles per link_kernel phase
+      S3GRL_HIP_TRY(hipMemcpy(hs + 16, ds + 16, 8 * 8, hipMemcpyDeviceToHost));
+      fprintf(stderr, "[s3grl] link_kernel phase cycles (sum over workgroups): bfs %lld  P/rank %lld  "
+                      "deg %lld  ops<K %lld  last op %lld  tail %lld\n",
+              (long long)hs[16], (long long)hs[17], (long long)hs[18], (long long)hs[19],
+              (long long)hs[20], (long long)hs[21]);
+      S3GRL_HIP_TRY(hipMemcpy(hs + 24, ds + 24, 8 * 8, hipMemcpyDeviceToHost));
+      fprintf(stderr, "[s3grl] link_full_kernel, big class: merge %lld  hash+ids %lld  probes %lld  "
+                      "csr+sort %lld  passes %lld\n",
+              (long long)hs[24], (long long)hs[25], (long long)hs[26], (long long)hs[27], (long long)hs[28]);
+    }
   }
   *out = plan.release();
   return S3GRL_OK;
@@ -795,7 +832,14 @@ s3grl_status s3grl_plan_gather_traffic(s3grl_context* ctx, const s3grl_plan* p,
 
 s3grl_status s3grl_plan_get_stats(const s3grl_plan* p, s3grl_plan_stats* out) {
   if (!p || !out) return S3GRL_ERR_INVALID_ARGUMENT;
+  if (p->stats_pending && p->ctx->stats_owner == p) S3GRL_TRY(resolve_plan_stats(p->ctx));
   *out = p->stats;
+  return S3GRL_OK;
+}
+
+s3grl_status s3grl_plan_total_rows(const s3grl_plan* p, int64_t* total_rows) {
+  if (!p || !total_rows) return S3GRL_ERR_INVALID_ARGUMENT;
+  *total_rows = p->stats.total_rows;
   return S3GRL_OK;
 }
 
@@ -803,7 +847,7 @@ s3grl_status s3grl_plan_link_cost(const s3grl_plan* p, float* cost) {
   if (!p || (!cost && p->L)) return S3GRL_ERR_INVALID_ARGUMENT;
   if (p->L == 0) return S3GRL_OK;
   hipLaunchKernelGGL(link_cost_kernel, dim3((unsigned)((p->L + 255) / 256)), dim3(256), 0, p->ctx->stream,
-                     p->n_nodes, p->e_cap, p->L, cost);
+                     p->n_nodes, p->e_cap, p->row_ptr, p->L, cost);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }

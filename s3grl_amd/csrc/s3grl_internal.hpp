@@ -85,19 +85,17 @@ struct Job {
                       // and summed by combine_kernel; the gather launch over the jobs skips this one
 };
 
-// Jobs whose list is longer than a threshold are cut into pieces of 2^kSplitSegShift entries: the
-// longest unit of a gather launch is bounded (a 5 900-node PubMed subgraph is a 1.9 ms wavefront —
-// the tail of a launch once the list is sharded over 8 GPUs), and no fp32 running sum is longer than
-// the threshold (the pieces are added in f64): the accumulation error stops growing with the
-// subgraph.  A piece costs a wavefront's fixed work and 2 partial rows, so the threshold is as high
-// as the plan allows: the longest unit should take about half of what the launch takes anyway —
-// Σn / 8192 entries (4096 resident wavefronts, half) — between kSplitThresholdMin and
-// kSplitThreshold.  Measured on the headline (164 000 links, gather 6.96 ms unsplit): threshold 4096
-// 7.03 ms, 3072 7.16, 2048 7.48; the pieces on the context's own stream in front of the main launch:
-// +0.3 ms even for a hundred split jobs (they run on a side stream).
-// S3GRL_SPLIT_T / S3GRL_SPLIT_SEG_SHIFT override (0 = never split).
+// Jobs whose list is longer than kSplitThreshold entries are cut into pieces of 2^kSplitSegShift
+// entries: the longest unit of a gather launch is bounded (a 5 900-node PubMed subgraph is a 1.9 ms
+// wavefront — the tail of a launch once the list is sharded over 8 GPUs), and no fp32 running sum is
+// longer than the threshold (the pieces are added in f64): the accumulation error stops growing
+// with the subgraph.  A piece costs a wavefront's fixed work and 2 partial rows.  Measured on the
+// headline (164 000 links, gather 6.96 ms unsplit): threshold 4096 7.03 ms, 3072 7.16, 2048 7.48; the
+// pieces on the context's own stream in front of the main launch: +0.3 ms even for a hundred split
+// jobs (they run on a side stream).  The threshold is a constant, NOT a function of the plan: whether
+// a job is split decides its summation order, and a link must come out bit for bit the same in a
+// sharded and in an unsharded run.  S3GRL_SPLIT_T / S3GRL_SPLIT_SEG_SHIFT override (0 = never split).
 constexpr int kSplitThreshold = 4096;
-constexpr int kSplitThresholdMin = 2048;
 constexpr int kSplitSegShift = 10;
 
 // what a gather launch works on: the jobs of a plan, or the pieces of its split jobs
@@ -144,6 +142,10 @@ struct s3grl_context {
   int64_t* h_scalars = nullptr;  // pinned host mirror
   int64_t* d_stats = nullptr;    // [kStatRows][kStatShards * kStatStride] sharded totals of a plan
   int64_t* h_stats = nullptr;    // pinned host mirror
+  // the plan whose link-kernel totals (Σ edges / support / vol) are still on their way into h_stats:
+  // plan creation does not wait for its link kernels — the gather is queued right behind them — and
+  // the totals are read when somebody asks (s3grl_plan_get_stats), or before the buffers are reused
+  s3grl_plan* stats_owner = nullptr;
 };
 
 struct s3grl_graph {
@@ -185,6 +187,7 @@ struct s3grl_plan {
   int32_t* lvl = nullptr;        // [L, kMaxLevels] cumulative node count per BFS level
   int32_t* e_cap = nullptr;      // [L] bound of the induced entries (one-hop plans on big graphs), else null
   bool relabelled = false;       // the kernels walked the graph's degree order (s3grl_relabel.hip)
+  bool stats_pending = false;    // total_sub_edges / total_support / total_volume not read back yet
   bool walk_plan = false;        // ScaLed: subgraph = walk nodes of src and dst (one "hop", whatever num_hops)
   int32_t* c_ids = nullptr;      // [Σn] subgraph nodes, hop-major (ascending id inside a hop unless relabelled)
   // per job (row pair)
@@ -295,6 +298,12 @@ s3grl_status launch_job_order(s3grl_context* ctx, const int32_t* n_nodes, const 
 int64_t scan_workspace_elems(int64_t n);
 s3grl_status launch_scan_i32_to_i64(s3grl_context* ctx, const int32_t* in, int64_t n, int64_t* out,
                                     int64_t* workspace);
+// exclusive scans of three int32 [n] arrays -> int64 [n+1] in one set of launches (n > 0);
+// workspace3: 3 x scan_workspace_elems(n); max0 / max1 (device int64, zeroed; may be null): maxima of
+// in0 / in1; totals (device int64 [3]; may be null): the three totals
+s3grl_status launch_scan3(s3grl_context* ctx, const int32_t* in0, const int32_t* in1, const int32_t* in2,
+                          int64_t n, int64_t* out0, int64_t* out1, int64_t* out2, int64_t* workspace3,
+                          int64_t* max0, int64_t* max1, int64_t* totals);
 s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_cap, int K,
                              const int32_t* n_nodes, const int32_t* p_nodes,
                              const int32_t* lvl_max, int64_t L, int32_t* class_count,

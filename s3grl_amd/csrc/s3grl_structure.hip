@@ -595,6 +595,89 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restri
   }
 }
 
+// The three offset arrays of a plan (nodes, rows, row pairs per link) in ONE set of launches
+// (blockIdx.y picks the array) instead of three, with their maxima and totals written next to the
+// plan's other scalars: a plan is a few dozen small launches, and on a sharded list their fixed cost
+// is paid once per piece (0.5 ms per plan before this).
+struct Scan3 {
+  const int32_t* in[3];
+  int64_t* out[3];
+  int64_t* part[3];
+  long long* max_out[3];   // may be null
+  int64_t* total_out[3];   // may be null
+};
+
+__global__ __launch_bounds__(256) void scan3_partials_kernel(Scan3 a, int64_t n) {
+  __shared__ int sh[4];
+  const int y = blockIdx.y;
+  const int32_t* __restrict__ in = a.in[y];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile;
+  int s = 0, m = 0;
+  for (int k = threadIdx.x; k < kScanTile; k += 256)
+    if (base + k < n) {
+      const int v = in[base + k];
+      s += v;
+      m = max(m, v);
+    }
+  s = block_sum<256>(s, sh);
+  if (threadIdx.x == 0) a.part[y][blockIdx.x] = s;
+  if (a.max_out[y]) {
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(a.max_out[y], (long long)m);
+  }
+}
+
+__global__ __launch_bounds__(1024) void scan3_top_kernel(Scan3 a, int64_t nb, int64_t n) {
+  __shared__ int64_t sh[1024];
+  const int y = blockIdx.x;
+  int64_t* __restrict__ part = a.part[y];
+  const int tid = threadIdx.x;
+  const int64_t chunk = (nb + 1023) / 1024;
+  const int64_t b = tid * chunk, e = min(nb, b + chunk);
+  int64_t s = 0;
+  for (int64_t i = b; i < e; ++i) s += part[i];
+  sh[tid] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int64_t t = tid >= o ? sh[tid - o] : 0;
+    __syncthreads();
+    sh[tid] += t;
+    __syncthreads();
+  }
+  int64_t run = tid ? sh[tid - 1] : 0;
+  for (int64_t i = b; i < e; ++i) {
+    const int64_t v = part[i];
+    part[i] = run;
+    run += v;
+  }
+  if (tid == 1023) {
+    a.out[y][n] = sh[1023];
+    if (a.total_out[y]) *a.total_out[y] = sh[1023];
+  }
+}
+
+__global__ __launch_bounds__(256) void scan3_apply_kernel(Scan3 a, int64_t n) {
+  __shared__ int sh[4];
+  const int y = blockIdx.y;
+  const int32_t* __restrict__ in = a.in[y];
+  int64_t* __restrict__ out = a.out[y];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile;
+  const int64_t i0 = base + threadIdx.x * 4;
+  int v[4], s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[k] = i0 + k < n ? in[i0 + k] : 0;
+    s += v[k];
+  }
+  int total;
+  int64_t run = a.part[y][blockIdx.x] + block_excl_scan<256>(s, sh, total);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (i0 + k < n) out[i0 + k] = run;
+    run += v[k];
+  }
+}
+
 #include "s3grl_onehop.inl"
 
 // ---------------------------------------------------------------------------------------
@@ -1536,6 +1619,28 @@ s3grl_status launch_job_order(s3grl_context* ctx, const int32_t* n_nodes, const 
 }
 
 int64_t scan_workspace_elems(int64_t n) { return (n + kScanTile - 1) / kScanTile + 1; }
+
+s3grl_status launch_scan3(s3grl_context* ctx, const int32_t* in0, const int32_t* in1, const int32_t* in2,
+                          int64_t n, int64_t* out0, int64_t* out1, int64_t* out2, int64_t* workspace3,
+                          int64_t* max0, int64_t* max1, int64_t* totals) {
+  const int64_t nb = (n + kScanTile - 1) / kScanTile;
+  const int64_t wsz = scan_workspace_elems(n);
+  Scan3 a;
+  a.in[0] = in0; a.in[1] = in1; a.in[2] = in2;
+  a.out[0] = out0; a.out[1] = out1; a.out[2] = out2;
+  for (int y = 0; y < 3; ++y) {
+    a.part[y] = workspace3 + y * wsz;
+    a.total_out[y] = totals ? totals + y : nullptr;
+  }
+  a.max_out[0] = reinterpret_cast<long long*>(max0);
+  a.max_out[1] = reinterpret_cast<long long*>(max1);
+  a.max_out[2] = nullptr;
+  hipLaunchKernelGGL(scan3_partials_kernel, dim3((unsigned)nb, 3), dim3(256), 0, ctx->stream, a, n);
+  hipLaunchKernelGGL(scan3_top_kernel, dim3(3), dim3(1024), 0, ctx->stream, a, nb, n);
+  hipLaunchKernelGGL(scan3_apply_kernel, dim3((unsigned)nb, 3), dim3(256), 0, ctx->stream, a, n);
+  S3GRL_HIP_TRY(hipGetLastError());
+  return S3GRL_OK;
+}
 
 s3grl_status launch_scan_i32_to_i64(s3grl_context* ctx, const int32_t* in, int64_t n, int64_t* out,
                                     int64_t* workspace) {

@@ -122,9 +122,20 @@ class Plan:
                     "s3grl_plan_create_sets")
         self._h = h
         engine._children.add(self)
-        st = N.PlanStats()
-        N.check(N.lib().s3grl_plan_get_stats(h, C.byref(st)), "s3grl_plan_get_stats")
-        self.stats = st.as_dict()
+        self._stats = None
+        tr = C.c_int64()
+        N.check(N.lib().s3grl_plan_total_rows(h, C.byref(tr)), "s3grl_plan_total_rows")
+        self.total_rows = int(tr.value)
+
+    @property
+    def stats(self):
+        """Sizes and totals the plan measured (s3grl_plan_stats).  Read lazily: the first access
+        waits for the plan's kernels, so ask after `run()` has queued the gather, not before."""
+        if self._stats is None:
+            st = N.PlanStats()
+            N.check(N.lib().s3grl_plan_get_stats(self._h, C.byref(st)), "s3grl_plan_get_stats")
+            self._stats = st.as_dict()
+        return self._stats
 
     def row_ptr(self):
         out = torch.empty(self.num_links + 1, dtype=torch.int64, device=self.engine.device)
@@ -132,7 +143,7 @@ class Plan:
         return out
 
     def row_nodes(self):
-        out = torch.empty(self.stats["total_rows"], dtype=torch.int64, device=self.engine.device)
+        out = torch.empty(self.total_rows, dtype=torch.int64, device=self.engine.device)
         N.check(N.lib().s3grl_plan_row_nodes(self._h, _ptr(out)), "s3grl_plan_row_nodes")
         return out
 
@@ -155,7 +166,7 @@ class Plan:
             assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
         F = x.shape[1]
         K = self.cfg.sign_k
-        R = self.stats["total_rows"]
+        R = self.total_rows
         if out is None:
             out = torch.empty((R, K + 1, F + 1), dtype=torch.float32, device=eng.device)
         else:
@@ -298,7 +309,7 @@ class Engine:
         """int64 [L] on the device: |S| of every link's enclosing subgraph — the sizing pass alone
         (count kernel + scan, ~1/8 of a plan), e.g. to balance multi-GPU shards by exact size."""
         p = self.plan(graph, links, mode="pos", num_hops=num_hops, sign_k=1, rw=rw, ratio_per_hop=ratio_per_hop,
-                      max_nodes_per_hop=max_nodes_per_hop, seed=seed, count_only=True)
+                      max_nodes_per_hop=max_nodes_per_hop, seed=seed, count_only=True, fold_reversed=False)
         try:
             node_ptr = torch.empty(p.num_links + 1, dtype=torch.int64, device=self.device)
             N.check(N.lib().s3grl_plan_export_subgraphs(p._h, _ptr(node_ptr), C.c_void_p(0), C.c_void_p(0)),
@@ -308,11 +319,14 @@ class Engine:
             p.close()
 
     def link_costs(self, graph, links, *, num_hops=1, rw=None, ratio_per_hop=1.0, max_nodes_per_hop=None,
-                   seed=0):
+                   seed=0, mode="pos", fold_reversed=True):
         """fp32 [L] on the device: the relative cost of every link (s3grl_plan_link_cost), from the
-        sizing pass alone — the weights a multi-GPU job balances its shards by."""
-        p = self.plan(graph, links, mode="pos", num_hops=num_hops, sign_k=2, rw=rw, ratio_per_hop=ratio_per_hop,
-                      max_nodes_per_hop=max_nodes_per_hop, seed=seed, count_only=True)
+        sizing pass alone — the weights a multi-GPU job balances its shards by.  `mode` as in the
+        real run (PoS Plus rows enter the cost); a reversed duplicate that the real run folds into
+        its primary is priced at its two output rows (`fold_reversed=False`: every link in full)."""
+        p = self.plan(graph, links, mode=mode if mode in ("pos", "pos_plus") else "pos", num_hops=num_hops,
+                      sign_k=2, rw=rw, ratio_per_hop=ratio_per_hop, max_nodes_per_hop=max_nodes_per_hop,
+                      seed=seed, count_only=True, fold_reversed=fold_reversed)
         try:
             cost = torch.empty(p.num_links, dtype=torch.float32, device=self.device)
             N.check(N.lib().s3grl_plan_link_cost(p._h, _ptr(cost)), "s3grl_plan_link_cost")
@@ -415,7 +429,8 @@ class Engine:
                          max_nodes_per_hop=max_nodes_per_hop, seed=seed, node_sets=node_sets)
         try:
             rows = plan.run(x, out)
-            res = Precomputed(rows, plan.row_ptr(), plan.row_nodes(), dict(plan.stats))
+            row_ptr, row_nodes = plan.row_ptr(), plan.row_nodes()      # queued behind the gather ...
+            res = Precomputed(rows, row_ptr, row_nodes, dict(plan.stats))   # ... before the totals are waited for
         finally:
             plan.close()
         return res

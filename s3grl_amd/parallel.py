@@ -40,6 +40,56 @@ def shard_bounds(num_links, world_size, cost=None):
     return [int(min(max(x, 0), num_links)) for x in np.maximum.accumulate(b)]
 
 
+def shard_assignment(link_index, world_size, cost=None, pair_aware=True):
+    """Which rank computes which link: (order int64 [L], bounds [world_size + 1]) — rank r owns the
+    links order[bounds[r]:bounds[r+1]].
+
+    pair_aware: both directions of a pair, (s,d) and (d,s), go to the SAME rank, so that the engine
+    still folds the reversed duplicate into its primary there (the reference's train positives hold
+    both directions of every train edge: 23 % of PubMed's list is served for free on one GPU, and
+    contiguous ranges of the permuted list split most of those pairs across ranks).  Pairs are
+    taken in order of first appearance and cut into `world_size` runs of equal total cost, so the
+    assignment follows the list order as far as the pairs allow.  Without pair_aware: contiguous
+    ranges (`shard_bounds`), order = identity."""
+    li = np.asarray(torch.as_tensor(link_index).cpu())
+    L = int(li.shape[1])
+    if not pair_aware or L == 0:
+        return np.arange(L, dtype=np.int64), shard_bounds(L, world_size, cost)
+    lo, hi = np.minimum(li[0], li[1]).astype(np.int64), np.maximum(li[0], li[1]).astype(np.int64)
+    key = lo * (int(hi.max()) + 1) + hi
+    _, first, inv = np.unique(key, return_index=True, return_inverse=True)
+    c = np.ones(L) if cost is None else np.asarray(cost, dtype=np.float64)
+    gcost = np.bincount(inv, weights=c, minlength=len(first))
+    gorder = np.argsort(first, kind="stable")                  # pairs by first appearance
+    gb = shard_bounds(len(gorder), world_size, gcost[gorder])  # runs of pairs of equal total cost
+    rank_of_group = np.empty(len(gorder), dtype=np.int64)
+    for r in range(world_size):
+        rank_of_group[gorder[gb[r]:gb[r + 1]]] = r
+    rank_of_link = rank_of_group[inv]
+    # inside a rank: pair by pair (first appearance), the two directions next to each other — a rank's
+    # list is cut into pieces for the pipelined all-gather, and a cut must not separate partners
+    order = np.lexsort((np.arange(L), first[inv], rank_of_link)).astype(np.int64)
+    counts = np.bincount(rank_of_link, minlength=world_size)
+    bounds = [0] + [int(x) for x in np.cumsum(counts)]
+    return order, bounds
+
+
+class ShardPlan:
+    """An assignment made once (set-up, like the uploads) and reused by every step: the list grouped
+    by rank on the device, where every column belongs in the caller's list, and the bounds."""
+
+    def __init__(self, link_index, world_size, cost=None, pair_aware=True, device=None):
+        li = torch.as_tensor(link_index)
+        self.num_links = int(li.shape[1])
+        order, self.bounds = shard_assignment(li, world_size, cost, pair_aware)
+        self.identity = not pair_aware
+        self.order = torch.from_numpy(order)
+        self.cost = None if cost is None else np.asarray(cost, dtype=np.float64)[order]
+        dev = li.device if device is None else torch.device(device)
+        self.links = li.to(dev)[:, self.order.to(dev)].contiguous()
+        self.order_dev = self.order.to(dev)
+
+
 def link_cost(A, link_index):
     """Cheap proxy of a link's subgraph size: deg(src) + deg(dst) + 1."""
     deg = np.diff(A.indptr)
@@ -61,11 +111,13 @@ def khop_cost(A, link_index, num_hops):
     return tot[li[0]] + tot[li[1]]
 
 
-def measured_cost(engine, graph, link_index, num_hops):
+def measured_cost(engine, graph, link_index, num_hops, mode="pos"):
     """The engine's own per-link cost (`Engine.link_costs`: the sizing pass alone + the cost model
     of s3grl_plan_link_cost) — what SURVEY §8(e) calls balancing by "the plan pass's exact vol(S)".
-    One cheap pass over the whole list at set-up time, identical on every rank."""
-    return engine.link_costs(graph, engine.links(link_index), num_hops=num_hops).cpu().numpy().astype(np.float64)
+    One cheap pass over the whole list at set-up time, identical on every rank.  A reversed
+    duplicate that the engine folds into its primary is priced as what it costs (two more output
+    rows), the primary in full: with pair-aware shards the pair's cost lands on one rank."""
+    return engine.link_costs(graph, engine.links(link_index), num_hops=num_hops, mode=mode).cpu().numpy().astype(np.float64)
 
 
 def chunk_bounds(lo, hi, chunks, cost=None):
@@ -94,7 +146,8 @@ def _all_gather(out, inp, group, async_op=False):
 
 def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, group=None, gather=True,
                        rows_per_link=None, chunks=1, row_shape=None, dtype=torch.float32,
-                       device=None, timers=None, collective_at_world1=False, reuse_buffers=False):
+                       device=None, timers=None, collective_at_world1=False, reuse_buffers=False,
+                       pair_aware=False, shards=None):
     """Shard `link_index` ([2, L]) over the ranks and (when `gather`) reassemble the whole result
     on every rank.
 
@@ -103,8 +156,12 @@ def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, grou
     Fixed flavour (`rows_per_link = 2` for PoS / SoP / hybrid; needs `row_shape`, `device`):
         `compute(link_index_piece, out)` fills `out` ([piece links * rows_per_link, *row_shape]).
 
-    Returns (rows, row_ptr, (lo, hi)): the WHOLE list on every rank when `gather`, else the local
-    shard.  `timers` (dict, optional) receives host-side timestamps for the benchmark.
+    Returns (rows, row_ptr, where): the WHOLE list (in the caller's order) on every rank when
+    `gather`, else the local shard; `where` = (lo, hi) for contiguous shards, or — `pair_aware`, see
+    `shard_assignment` — the int64 tensor of the list positions this rank computed (the rows of a
+    local shard are in that order).  `shards`: a `ShardPlan` made once for this list (a step must not
+    redo the assignment); `cost` / `pair_aware` are then taken from it.  `timers` (dict, optional)
+    receives host-side timestamps.
     `collective_at_world1`: run the pieces / in-place all-gather / compaction path even on a
     one-rank group (a test hook: it is how the collective code meets real RCCL on a one-GPU box).
     `reuse_buffers` (fixed flavour): the returned `rows` live in a process-wide buffer that the NEXT
@@ -115,15 +172,29 @@ def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, grou
     """
     li = torch.as_tensor(link_index)
     L = int(li.shape[1])
-    b = shard_bounds(L, world_size, cost)
+    if shards is None and pair_aware:
+        shards = ShardPlan(li, world_size, cost, True)
+    if shards is not None and not shards.identity:
+        assert shards.num_links == L and len(shards.bounds) == world_size + 1
+        order, order_t, b = shards.order, shards.order_dev, shards.bounds
+        li, cost = shards.links, shards.cost      # the list, grouped by rank; positions map back through `order`
+    elif shards is not None:
+        order, order_t, b, cost = None, None, shards.bounds, shards.cost
+    else:
+        order, order_t = None, None
+        b = shard_bounds(L, world_size, cost)
     lo, hi = b[rank], b[rank + 1]
+    where = (lo, hi) if order is None else order_t[lo:hi]
     if rows_per_link is not None:
-        return _fixed(compute, li, b, rank, world_size, cost, group, gather, int(rows_per_link),
-                      max(int(chunks), 1), tuple(row_shape), dtype, device, timers, collective_at_world1,
-                      bool(reuse_buffers))
+        rows, row_ptr, _ = _fixed(compute, li, b, rank, world_size, cost, group, gather, int(rows_per_link),
+                                  max(int(chunks), 1), tuple(row_shape), dtype, device, timers,
+                                  collective_at_world1, bool(reuse_buffers), order_t)
+        return rows, row_ptr, where
     rows, row_ptr = compute(li[:, lo:hi])
     if not gather or world_size == 1:
-        return rows, row_ptr, (lo, hi)
+        if order is not None and gather:      # one rank, whole list: back into the caller's order
+            rows, row_ptr = _reorder_ragged(rows, row_ptr, order_t.to(rows.device))
+        return rows, row_ptr, where
     dev = rows.device
     # 1) sizes
     mine = torch.tensor([rows.shape[0], hi - lo], dtype=torch.int64, device=dev)
@@ -145,7 +216,28 @@ def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, grou
     counts = torch.cat([allcnt[r * lmax: r * lmax + int(sizes[r, 1])] for r in range(world_size)])
     out_ptr = torch.zeros(L + 1, dtype=torch.int64, device=dev)
     out_ptr[1:] = torch.cumsum(counts, 0)
-    return out_rows, out_ptr, (lo, hi)
+    if order is not None:
+        out_rows, out_ptr = _reorder_ragged(out_rows, out_ptr, order_t.to(dev))
+    return out_rows, out_ptr, where
+
+
+def _reorder_ragged(rows, row_ptr, order):
+    """rows / row_ptr of the links in shard order (position i = list position order[i]) -> the
+    caller's order."""
+    L = order.numel()
+    cnt = row_ptr[1:] - row_ptr[:-1]
+    out_cnt = torch.empty_like(cnt)
+    out_cnt[order] = cnt
+    out_ptr = torch.zeros(L + 1, dtype=torch.int64, device=rows.device)
+    out_ptr[1:] = torch.cumsum(out_cnt, 0)
+    # destination row of every source row: start of its link in the caller's order + offset in the link
+    dst_start = out_ptr[:-1][order]
+    total = int(row_ptr[-1])
+    dst = torch.repeat_interleave(dst_start - row_ptr[:-1], cnt, output_size=total) + \
+        torch.arange(total, device=rows.device)
+    out = torch.empty_like(rows)
+    out[dst] = rows
+    return out, out_ptr
 
 
 class _Buffers:
@@ -174,10 +266,14 @@ def _result(key, shape, dtype, device, reuse):
 
 
 def _fixed(compute, li, b, rank, world, cost, group, gather, rpl, chunks, row_shape, dtype, device,
-           timers, collective_at_world1=False, reuse=False):
+           timers, collective_at_world1=False, reuse=False, order=None):
+    """`li` is the list grouped by rank (rank r owns columns b[r]:b[r+1]); `order` (device-resident
+    positions in the caller's list, or None = identity) says where every column belongs."""
     L = int(li.shape[1])
     lo, hi = b[rank], b[rank + 1]
     row_ptr = torch.arange(0, rpl * L + 1, rpl, dtype=torch.int64, device=device)
+    if order is not None:
+        order = order.to(device)
     if not gather or (world == 1 and not collective_at_world1):
         rows = _result(("local", rank), (rpl * (hi - lo),) + row_shape, dtype, device, reuse)
         compute(li[:, lo:hi], rows)
@@ -190,12 +286,19 @@ def _fixed(compute, li, b, rank, world, cost, group, gather, rpl, chunks, row_sh
     pmaxes = [rpl * max(pb[r][c + 1] - pb[r][c] for r in range(world)) for c in range(chunks)]
     cap = max(max(pmaxes), 1)
 
+    final_links = final.view((L, rpl) + row_shape)
+
     def compact(c):
         slot, pmax = slots[c]
         for r in range(world):
-            n = rpl * (pb[r][c + 1] - pb[r][c])
-            if n:
-                final[rpl * pb[r][c]: rpl * pb[r][c] + n].copy_(slot[r, :n], non_blocking=True)
+            p0, p1 = pb[r][c], pb[r][c + 1]
+            n = rpl * (p1 - p0)
+            if not n:
+                continue
+            if order is None:
+                final[rpl * p0: rpl * p0 + n].copy_(slot[r, :n], non_blocking=True)
+            else:      # scatter by list position: 2 rows x (K+1) x (1+F) floats per link, contiguous
+                final_links.index_copy_(0, order[p0:p1], slot[r, :n].view((p1 - p0, rpl) + row_shape))
 
     t_comm = 0.0
     for c in range(chunks):
@@ -223,9 +326,10 @@ def _fixed(compute, li, b, rank, world, cost, group, gather, rpl, chunks, row_sh
     return final, row_ptr, (lo, hi)
 
 
-def engine_compute(engine, graph, x, *, mode="pos", num_hops=1, sign_k=3, **kw):
+def engine_compute(engine, graph, x, *, mode="pos", num_hops=1, sign_k=3, stats=None, **kw):
     """The fixed-flavour compute callable running the HIP engine on this rank's device:
-    `compute(link_index_piece [2, n] (host or device), out)`."""
+    `compute(link_index_piece [2, n] (host or device), out)`.  `stats` (dict, optional) accumulates
+    the plans' link and folded-link counts."""
 
     def compute(piece, out):
         links = engine.links(piece)
@@ -235,6 +339,9 @@ def engine_compute(engine, graph, x, *, mode="pos", num_hops=1, sign_k=3, **kw):
         plan = engine.plan(graph, links, mode=mode, num_hops=num_hops, sign_k=sign_k, **kw)
         try:
             plan.run(x, out)
+            if stats is not None:
+                stats["links"] = stats.get("links", 0) + plan.stats["num_links"]
+                stats["folded_links"] = stats.get("folded_links", 0) + plan.stats["folded_links"]
         finally:
             plan.close()
 

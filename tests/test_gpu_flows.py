@@ -309,8 +309,24 @@ def test_link_costs_and_sizes_from_the_sizing_pass():
     node_ptr = plan.export_subgraphs()[0].cpu().numpy()
     assert np.array_equal(sizes, np.diff(node_ptr))            # folding off: every link sized
     cost = eng.link_costs(G, links, num_hops=2).cpu().numpy()
-    assert np.allclose(cost, sizes + 800.0)
+    assert np.allclose(cost, sizes + 400.0)                    # (the fixture holds no reversed duplicates)
     plan.close()
+    # a reversed duplicate is folded into its primary in the real run: priced at its output rows;
+    # PoS Plus: every row pair is another pass over the subgraph
+    both = np.concatenate([g["links"][:8], g["links"][:8, ::-1]])
+    lb = eng.links(both.T.copy())
+    cb = eng.link_costs(G, lb, num_hops=2).cpu().numpy()
+    # (the direction with src < dst is the primary, wherever it stands in the list)
+    fwd = g["links"][:8, 0] < g["links"][:8, 1]
+    assert np.allclose(np.where(fwd, cb[:8], cb[8:]), sizes[:8] + 400.0)
+    assert np.allclose(np.where(fwd, cb[8:], cb[:8]), 250.0)
+    full = eng.link_costs(G, lb, num_hops=2, fold_reversed=False).cpu().numpy()
+    assert np.allclose(full[8:], sizes[:8] + 400.0)
+    pp = eng.plan(G, links, mode="pos_plus", num_hops=2, sign_k=2)
+    pairs = (np.diff(pp.row_ptr().cpu().numpy()) + 1) // 2
+    pp.close()
+    cp = eng.link_costs(G, links, num_hops=2, mode="pos_plus").cpu().numpy()
+    assert np.allclose(cp, pairs * sizes + 400.0) and pairs.max() > 1
     # a count-only plan cannot be run
     p = eng.plan(G, links, mode="pos", num_hops=2, sign_k=2, count_only=True)
     with pytest.raises(ValueError, match="count-only"):

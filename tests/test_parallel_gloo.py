@@ -46,6 +46,14 @@ def _worker(rank, world, port, plus, q):
         compute, links, rank=rank, world_size=world, cost=parallel.link_cost(A, links))
     full_rows, full_ptr, _ = oracle.collate_rows(fn(links, 1, A, X, 1, kw, dtype=np.float64), 2)
     ok = np.array_equal(ptr.numpy(), full_ptr) and np.array_equal(rows.numpy(), full_rows)
+    # pair-aware shards (both directions of a pair on one rank): same result in the caller's order
+    both = np.concatenate([links, links[::-1, :7]], axis=1)
+    both = both[:, np.random.default_rng(1).permutation(both.shape[1])]
+    rows2, ptr2, where = parallel.sharded_precompute(
+        compute, both, rank=rank, world_size=world, cost=parallel.link_cost(A, both), pair_aware=True)
+    full2, fptr2, _ = oracle.collate_rows(fn(both, 1, A, X, 1, kw, dtype=np.float64), 2)
+    ok = ok and np.array_equal(ptr2.numpy(), fptr2) and np.array_equal(rows2.numpy(), full2)
+    ok = ok and torch.is_tensor(where) and where.dtype == torch.int64
     q.put((rank, ok, lo, hi))
     dist.barrier()
     dist.destroy_process_group()
@@ -99,6 +107,21 @@ def _worker_fixed(rank, world, port, chunks, q):
     r1, _, _ = parallel.sharded_precompute(compute, links, reuse_buffers=True, **kwargs)
     r2, _, _ = parallel.sharded_precompute(compute, flipped, reuse_buffers=True, **kwargs)
     ok = ok and r1.data_ptr() == r2.data_ptr()
+    calls.clear()
+    # pair-aware shards: a reversed duplicate lands on its partner's rank, the reassembled tensor is
+    # in the caller's order all the same, and a shard plan made once serves every step
+    both = np.concatenate([links, links[::-1, :9]], axis=1)
+    both = np.ascontiguousarray(both[:, np.random.default_rng(2).permutation(both.shape[1])])
+    plan = parallel.ShardPlan(both, world, parallel.link_cost(A, both), pair_aware=True)
+    for _ in range(2):
+        rows_p, ptr_p, where = parallel.sharded_precompute(compute, both, shards=plan, **kwargs)
+        ok = ok and np.array_equal(rows_p.numpy(), rows_of(both)) and int(ptr_p[-1]) == 2 * both.shape[1]
+    mine = set(map(tuple, both[:, where.numpy()].T.tolist()))
+    ok = ok and all(((d, s_) in mine) == ((s_, d) in mine) or (d, s_) not in set(map(tuple, both.T.tolist()))
+                    for s_, d in mine)
+    rows_l, _, where_l = parallel.sharded_precompute(compute, both, shards=plan, gather=False,
+                                                     **{k: v for k, v in kwargs.items() if k != "chunks"})
+    ok = ok and np.array_equal(rows_l.numpy(), rows_of(both[:, where_l.numpy()]))
     calls.clear()
     # gather=False hands back the local shard only
     rows_l, ptr_l, _ = parallel.sharded_precompute(
