@@ -40,8 +40,9 @@ __all__ = [
 # --------------------------------------------------------------------------------------
 # extraction half  (reference utils.py:33-85)
 # --------------------------------------------------------------------------------------
-def neighbors(fringe, A):
-    """Union of the CSR rows of `fringe` — reference utils.py:33-44 (outgoing branch).
+def neighbors(fringe, A, outgoing=True):
+    """Union of the CSR rows of `fringe` — reference utils.py:33-44; `outgoing=False`: union of the
+    CSC columns (`A` is then the CSC form, utils.py:41-42: the nodes with an edge INTO the fringe).
 
     Reads `.indices`, so *structural* entries count even when their stored value is zero
     (SURVEY §8c K4): after the target link is masked, local node 1 is still a "neighbour"
@@ -50,7 +51,9 @@ def neighbors(fringe, A):
     fringe = list(fringe)
     if not fringe:
         return set()
-    return set(int(v) for v in A[fringe].indices)
+    if outgoing:
+        return set(int(v) for v in A[fringe].indices)
+    return set(int(v) for v in A[:, fringe].indices)
 
 
 _M64 = (1 << 64) - 1
@@ -83,9 +86,12 @@ def hash_sampler(seed, src, dst):
 
 
 def k_hop_subgraph(src, dst, num_hops, A, node_features=None, y=1, order="canonical",
-                   rw_nodes=None, sample_ratio=1.0, max_nodes_per_hop=None, sampler=None):
-    """k-hop enclosing subgraph of link (src, dst) — reference utils.py:47-85, non-rw branch,
-    undirected.  Every paper config runs it with sample_ratio=1.0 / max_nodes_per_hop=None; the
+                   rw_nodes=None, sample_ratio=1.0, max_nodes_per_hop=None, sampler=None,
+                   directed=False, A_csc=None):
+    """k-hop enclosing subgraph of link (src, dst) — reference utils.py:47-85, non-rw branch.
+    `directed` (utils.py:58-63): a hop follows the out-edges (rows of A) AND the in-edges (columns,
+    through `A_csc`) of the fringe; the induced matrix A[nodes][:, nodes] keeps the directions.
+    Every paper config runs it with sample_ratio=1.0 / max_nodes_per_hop=None; the
     per-hop sampling of utils.py:66-70 is restated too, with the draw behind `sampler(fringe, k,
     dist)` (default: `random.sample`, what the reference calls).
 
@@ -122,7 +128,11 @@ def k_hop_subgraph(src, dst, num_hops, A, node_features=None, y=1, order="canoni
         def sampler(fr, k, dist):
             return random.sample(sorted(fr), k)
     for dist in range(1, num_hops + 1):
-        fringe = neighbors(fringe, A) - visited
+        if not directed:
+            fringe = neighbors(fringe, A)
+        else:                                              # utils.py:60-63
+            fringe = neighbors(fringe, A) | neighbors(fringe, A_csc, False)
+        fringe = fringe - visited
         visited |= fringe                                  # dropped nodes stay visited (utils.py:65)
         if sample_ratio < 1.0:                             # utils.py:66-67
             fringe = set(sampler(fringe, int(sample_ratio * len(fringe)), dist))
@@ -175,14 +185,15 @@ def _powers(op, K):
 
 def pos_link(src, dst, num_hops, A, x, K, *, plus=False, strategy="intersection",
              dtype=np.float32, order="canonical", rw_nodes=None, sample_ratio=1.0,
-             max_nodes_per_hop=None, sampler=None):
+             max_nodes_per_hop=None, sampler=None, directed=False, A_csc=None):
     """One iteration of the reference's PoS / PoS Plus hot loop — tuned_SIGN.py:147-187 and
     :202-260.  Returns a dict with x, x1..xK ([R, 1+F]), the selected local rows, the global
     ids of those rows, the node list and hop distances."""
     nodes, sub, dists, X_S, _ = k_hop_subgraph(src, dst, num_hops, A, node_features=x,
                                                 order=order, rw_nodes=rw_nodes,
                                                 sample_ratio=sample_ratio,
-                                                max_nodes_per_hop=max_nodes_per_hop, sampler=sampler)
+                                                max_nodes_per_hop=max_nodes_per_hop, sampler=sampler,
+                                                directed=directed, A_csc=A_csc)
     n = sub.shape[0]
     op = normalized_subgraph_operator(sub, dtype)
     powers = _powers(op, K)
@@ -231,15 +242,19 @@ def _sampling_of(src, dst, ratio_per_hop, max_nodes_per_hop, sample_seed):
 
 def get_PoS_prepped_ds(link_index, num_hops, A, x, y, sign_kwargs, *, dtype=np.float32,
                        order="canonical", rw_node_sets=None, ratio_per_hop=1.0,
-                       max_nodes_per_hop=None, sample_seed=None):
+                       max_nodes_per_hop=None, sample_seed=None, directed=False, A_csc=None):
     """Reference tuned_SIGN.py:137-189 (optimised PoS flow), one dict per link.
-    `rw_node_sets[l]` = the random-walk node set of link l (ScaLed branch), else k-hop BFS."""
+    `rw_node_sets[l]` = the random-walk node set of link l (ScaLed branch), else k-hop BFS.
+    `directed` / `A_csc` as the reference passes them through to k_hop_subgraph (:149-150); the
+    operator is D^-1/2 A D^-1/2 of the DIRECTED induced matrix with D = out-degrees (row counts,
+    :158-161), and rows [0, 1] of its powers are taken as they are."""
     assert x is not None
     K = sign_kwargs["sign_k"]
     out = []
     for l, (src, dst) in enumerate(_links(link_index)):
         d = pos_link(src, dst, num_hops, A, x, K, plus=False, dtype=dtype, order=order,
                      rw_nodes=None if rw_node_sets is None else rw_node_sets[l],
+                     directed=directed, A_csc=A_csc,
                      **_sampling_of(src, dst, ratio_per_hop, max_nodes_per_hop, sample_seed))
         d["y"] = y
         out.append(d)
@@ -248,7 +263,7 @@ def get_PoS_prepped_ds(link_index, num_hops, A, x, y, sign_kwargs, *, dtype=np.f
 
 def get_PoS_Plus_prepped_ds(link_index, num_hops, A, x, y, sign_kwargs, *, dtype=np.float32,
                             order="canonical", rw_node_sets=None, ratio_per_hop=1.0,
-                            max_nodes_per_hop=None, sample_seed=None):
+                            max_nodes_per_hop=None, sample_seed=None, directed=False, A_csc=None):
     """Reference tuned_SIGN.py:192-262 (optimised PoS Plus flow), one dict per link."""
     assert x is not None
     K = sign_kwargs["sign_k"]
@@ -257,6 +272,7 @@ def get_PoS_Plus_prepped_ds(link_index, num_hops, A, x, y, sign_kwargs, *, dtype
     for l, (src, dst) in enumerate(_links(link_index)):
         d = pos_link(src, dst, num_hops, A, x, K, plus=True, strategy=strat, dtype=dtype,
                      order=order, rw_nodes=None if rw_node_sets is None else rw_node_sets[l],
+                     directed=directed, A_csc=A_csc,
                      **_sampling_of(src, dst, ratio_per_hop, max_nodes_per_hop, sample_seed))
         d["y"] = y
         out.append(d)

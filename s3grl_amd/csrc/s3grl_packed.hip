@@ -142,8 +142,14 @@ __device__ __forceinline__ uint32_t select_or_oob(uint64_t mask, uint32_t if_set
 // MINNB = 2: a plan whose last two operators reach the whole list in every job (sign_k - 1 >=
 // num_hops): the variant that holds every operator's accumulators at once (NB = 1) is left out, and
 // with it its registers — PubMed sign_k = 5: 128 instead of 166 VGPRs, four waves per SIMD.
+// S3GRL_GATHER_WAVES (build-time experiment hook): ask the compiler for that many waves per SIMD
+#ifdef S3GRL_GATHER_WAVES
+#define S3GRL_GATHER_OCC __attribute__((amdgpu_waves_per_eu(S3GRL_GATHER_WAVES, S3GRL_GATHER_WAVES)))
+#else
+#define S3GRL_GATHER_OCC
+#endif
 template <int K, bool MASKED, int MINNB>
-__global__ __launch_bounds__(kWavesPerBlock * 64) void gather_packed_kernel(
+__global__ __launch_bounds__(kWavesPerBlock * 64) S3GRL_GATHER_OCC void gather_packed_kernel(
     const Job* __restrict__ jobs, int njobs, const int32_t* __restrict__ c_ids,
     const float* __restrict__ c_coef, const float* __restrict__ job_z,
     const int32_t* __restrict__ job_lim, const int32_t* __restrict__ job_order,

@@ -30,6 +30,19 @@ def golden_dir():
     return GOLDEN
 
 
+def csr_from_arcs(n, arcs):
+    """A directed graph as the reference holds it: A[u, v] = 1 for every arc u -> v
+    (sgrl_link_pred.py:107-114 on a directed edge_index)."""
+    import scipy.sparse as ssp
+
+    a = np.asarray(arcs, dtype=np.int64).reshape(-1, 2)
+    return ssp.csr_matrix((np.ones(len(a), dtype=np.int64), (a[:, 0], a[:, 1])), shape=(n, n))
+
+
+def load_extract_directed(name):
+    return np.load(GOLDEN / f"extract_directed_{name}.npz")
+
+
 def load_extract(name):
     return np.load(GOLDEN / f"extract_{name}.npz")
 
@@ -43,5 +56,6 @@ def load_sampled(name):
 
 
 SAMPLED_NAMES = ["rand300", "usair", "cora"]
+DIRECTED_NAMES = ["tiny", "rand300", "usair", "cora"]
 EXTRACT_NAMES = ["probe5", "triangle", "pair", "star_iso", "rand300", "usair", "cora"]
 DIFFUSION_NAMES = ["probe5", "star_iso", "rand300", "usair"]

@@ -4,7 +4,7 @@
 
 Two kinds of fixture:
 
-extract_*.npz  — REFERENCE-PINNED.  Produced by executing the reference's own
+extract_*.npz, extract_directed_*.npz  — REFERENCE-PINNED.  Produced by executing the reference's own
     `utils.k_hop_subgraph` / `utils.neighbors` (reference utils.py:33-85) from /root/reference.
     Those two functions are pure scipy + python sets, but `utils.py` imports torch_geometric /
     torch_sparse / graphistry at module scope (absent from this image), so the import is made
@@ -131,10 +131,10 @@ def fixture_links(name, n, edges, rng):
     return pos + neg + extra
 
 
-def canonical_case(ref_utils, A, src, dst, h):
+def canonical_case(ref_utils, A, src, dst, h, A_csc=None):
     X = np.arange(A.shape[0], dtype=np.float32).reshape(-1, 1)
     nodes, sub, dists, xs, y = ref_utils.k_hop_subgraph(
-        src, dst, h, A, 1.0, None, node_features=X, y=1, directed=False, A_csc=None,
+        src, dst, h, A, 1.0, None, node_features=X, y=1, directed=A_csc is not None, A_csc=A_csc,
         rw_kwargs=None)
     nodes = [int(v) for v in nodes]
     assert nodes[0] == src and nodes[1] == dst
@@ -174,6 +174,57 @@ def make_extract(ref_utils):
                 blob[f"h{h}_{k}_off"] = off
         np.savez_compressed(HERE / f"extract_{name}.npz", **blob)
         print(f"extract_{name}.npz: {len(links)} links x hops {hops}")
+
+
+def directed_fixture_graphs():
+    """Directed versions of three fixture graphs: every undirected edge keeps one direction (chosen
+    at random), a third of them both; plus a hand-made 6-node digraph with a source, a sink, a
+    2-cycle and a self-loop-free chain."""
+    rng = np.random.default_rng(31)
+    g = {"tiny": (6, np.array([[0, 1], [1, 0], [0, 2], [3, 0], [2, 1], [1, 4], [4, 5], [3, 5]]))}
+    und = fixture_graphs()
+    for name in ("rand300", "usair", "cora"):
+        n, e = und[name]
+        e = np.asarray(e, dtype=np.int64)
+        flip = rng.random(len(e)) < 0.5
+        one = np.where(flip[:, None], e[:, ::-1], e)
+        both = e[rng.random(len(e)) < 0.33]
+        arcs = np.unique(np.vstack([one, both, both[:, ::-1]]), axis=0)
+        g[name] = (n, arcs)
+    return g
+
+
+def make_extract_directed(ref_utils):
+    """extract_directed_*.npz — REFERENCE-PINNED like extract_*.npz, for the directed branch of the
+    reference's BFS (utils.py:58-63: out-neighbours through the CSR, in-neighbours through `A_csc`)
+    and its directed induced matrix: `utils.k_hop_subgraph(directed=True, A_csc=A.tocsc())` itself."""
+    rng = np.random.default_rng(17)
+    und = fixture_graphs()
+    for name, (n, arcs) in directed_fixture_graphs().items():
+        A = ssp.csr_matrix((np.ones(len(arcs), dtype=np.int64), (arcs[:, 0], arcs[:, 1])), shape=(n, n))
+        A_csc = A.tocsc()
+        if name == "tiny":
+            links = [(0, 1), (1, 0), (2, 5), (3, 4), (0, 5), (4, 3)]
+        else:
+            links = fixture_links(name, n, und[name][1], rng)
+        hops = {"cora": [3], "usair": [1, 2]}.get(name, [1, 2, 3])
+        blob = {"num_nodes": np.int64(n), "arcs": np.asarray(arcs, dtype=np.int32),
+                "links": np.asarray(links, dtype=np.int64), "hops": np.asarray(hops)}
+        for h in hops:
+            cat = {"nodes": [], "dists": [], "sub": [], "cn": []}
+            for s, d in links:
+                nodes, dists, trip, cn = canonical_case(ref_utils, A, s, d, h, A_csc)
+                cat["nodes"].append(nodes.astype(np.int32))
+                cat["dists"].append(dists.astype(np.int8))
+                cat["sub"].append(trip.astype(np.int32))
+                cat["cn"].append(cn.astype(np.int32))
+            for k, parts in cat.items():
+                off = np.zeros(len(parts) + 1, dtype=np.int64)
+                np.cumsum([len(p) for p in parts], out=off[1:])
+                blob[f"h{h}_{k}"] = np.concatenate(parts, axis=0)
+                blob[f"h{h}_{k}_off"] = off
+        np.savez_compressed(HERE / f"extract_directed_{name}.npz", **blob)
+        print(f"extract_directed_{name}.npz: {len(links)} links x hops {hops}, {len(arcs)} arcs")
 
 
 def make_sampled(ref_utils):
@@ -260,6 +311,12 @@ if __name__ == "__main__":
     if not REFERENCE.exists():
         sys.exit("needs /root/reference (build container only)")
     ref = import_reference_utils()
-    make_extract(ref)
-    make_sampled(ref)
-    make_diffusion()
+    only = sys.argv[1:]          # e.g. `make_golden.py directed`: regenerate one family, leave the rest
+    if not only or "extract" in only:
+        make_extract(ref)
+    if not only or "directed" in only:
+        make_extract_directed(ref)
+    if not only or "sampled" in only:
+        make_sampled(ref)
+    if not only or "diffusion" in only:
+        make_diffusion()

@@ -6,8 +6,8 @@ import pytest
 import scipy.sparse as ssp
 
 import oracle
-from conftest import (DIFFUSION_NAMES, EXTRACT_NAMES, SAMPLED_NAMES, csr_from_undirected, load_diffusion,
-                      load_extract, load_sampled)
+from conftest import (DIFFUSION_NAMES, DIRECTED_NAMES, EXTRACT_NAMES, SAMPLED_NAMES, csr_from_arcs,
+                      csr_from_undirected, load_diffusion, load_extract, load_extract_directed, load_sampled)
 
 
 def _ragged(blob, key, i):
@@ -36,6 +36,31 @@ def test_extraction_matches_reference(name):
             trip = trip[np.lexsort((trip[:, 1], trip[:, 0]))]
             np.testing.assert_array_equal(trip, _ragged(g, f"h{h}_sub", li))
             # PoS Plus row selection (K4)
+            cn = oracle.neighbors({0}, sub) & oracle.neighbors({1}, sub)
+            np.testing.assert_array_equal(sorted(nodes[a] for a in cn), _ragged(g, f"h{h}_cn", li))
+
+
+@pytest.mark.parametrize("name", DIRECTED_NAMES)
+def test_directed_extraction_matches_reference(name):
+    """The directed branch (utils.py:58-63: out-neighbours through A, in-neighbours through A_csc),
+    against what the reference's own k_hop_subgraph(directed=True) produced."""
+    g = load_extract_directed(name)
+    n = int(g["num_nodes"])
+    A = csr_from_arcs(n, g["arcs"])
+    A_csc = A.tocsc()
+    assert (A != A.T).nnz > 0
+    for h in g["hops"]:
+        for li, (s, d) in enumerate(g["links"]):
+            nodes, sub, dists, _, _ = oracle.k_hop_subgraph(int(s), int(d), int(h), A, directed=True, A_csc=A_csc)
+            order = np.lexsort((np.asarray(nodes), np.asarray(dists)))
+            np.testing.assert_array_equal(np.asarray(nodes)[order], _ragged(g, f"h{h}_nodes", li))
+            np.testing.assert_array_equal(np.asarray(dists)[order], _ragged(g, f"h{h}_dists", li))
+            sub = ssp.csr_matrix(sub)
+            r = np.repeat(np.arange(sub.shape[0]), np.diff(sub.indptr))
+            trip = np.stack([np.asarray(nodes)[r], np.asarray(nodes)[sub.indices],
+                             sub.data.astype(np.int64)], axis=1)
+            trip = trip[np.lexsort((trip[:, 1], trip[:, 0]))]
+            np.testing.assert_array_equal(trip, _ragged(g, f"h{h}_sub", li))
             cn = oracle.neighbors({0}, sub) & oracle.neighbors({1}, sub)
             np.testing.assert_array_equal(sorted(nodes[a] for a in cn), _ragged(g, f"h{h}_cn", li))
 

@@ -101,3 +101,33 @@ def test_hybrid_and_pool_contract():
     np.testing.assert_allclose(out[0, :h.shape[1]], h[0] * h[1])
     np.testing.assert_allclose(out[0, h.shape[1]:], h[2:row_ptr[1]].mean(0))
     np.testing.assert_array_equal(out[1, h.shape[1]:], 0)               # link (3,4): no CN -> zeros
+
+
+def test_directed_operator_hand_derived():
+    """Directed graph 0->2, 2->1, 1->3, 3->0, link (0,1), one hop: S = {0,1} + out/in neighbours =
+    {0,1,2,3}; nothing to mask (no arc between 0 and 1); every node has out-degree 1, so D^-1/2 = 1
+    and A_hat = A: row 0 of A_hat is e_2, of A_hat^2 is e_1 (0->2->1), of A_hat^3 is e_3; row 1: e_3,
+    e_0, e_2 (tuned_SIGN.py:153-175: deg = row counts = out-degrees, no symmetrisation)."""
+    import scipy.sparse as ssp
+
+    arcs = np.array([[0, 2], [2, 1], [1, 3], [3, 0]])
+    A = ssp.csr_matrix((np.ones(4, dtype=np.int64), (arcs[:, 0], arcs[:, 1])), shape=(4, 4))
+    X = np.array([[1.0, 0.0], [0.0, 2.0], [3.0, 0.0], [0.0, 5.0]])
+    kw = {"sign_k": 3, "k_node_set_strategy": "intersection"}
+    d = oracle.get_PoS_prepped_ds(np.array([[0], [1]]), 1, A, X, 1, kw, dtype=np.float64, directed=True,
+                                  A_csc=A.tocsc())[0]
+    assert sorted(d["nodes"].tolist()) == [0, 1, 2, 3]
+    np.testing.assert_allclose(d["x"], [[1, 1, 0], [1, 0, 2]])
+    np.testing.assert_allclose(d["x1"], [[0, 3, 0], [0, 0, 5]])          # e_2 X, e_3 X; label column z_2 = z_3 = 0
+    np.testing.assert_allclose(d["x2"], [[1, 0, 2], [1, 1, 0]])          # e_1 [z|X], e_0 [z|X]
+    np.testing.assert_allclose(d["x3"], [[0, 0, 5], [0, 3, 0]])
+    # an undirected BFS would not find node 3 from {0,1} through out-edges alone: the in-edge 3->0 does
+    only_out = oracle.k_hop_subgraph(0, 1, 1, A)[0]
+    assert sorted(only_out) == [0, 1, 2, 3] or 3 in only_out      # (1->3 is an out-edge of dst)
+    # out-degree normalisation: add 0->3; node 0 has out-degree 2, row 0 of A_hat = (e_2 + e_3) / sqrt(2)
+    A2 = ssp.csr_matrix((np.ones(5, dtype=np.int64), ([0, 2, 1, 3, 0], [2, 1, 3, 0, 3])), shape=(4, 4))
+    d2 = oracle.get_PoS_prepped_ds(np.array([[0], [1]]), 1, A2, X, 1, kw, dtype=np.float64, directed=True,
+                                   A_csc=A2.tocsc())[0]
+    np.testing.assert_allclose(d2["x1"][0], (np.array([0, 3.0, 0]) + np.array([0, 0, 5.0])) / np.sqrt(2))
+    # row 1 of A_hat: 1 -> 3, D^-1/2: d_1 = 1, d_3 = 1
+    np.testing.assert_allclose(d2["x1"][1], [0, 0, 5.0])
