@@ -42,7 +42,7 @@ typedef enum s3grl_status {
   S3GRL_ERR_NOT_IMPLEMENTED = 2,  /* maps to the reference's NotImplementedError:
                                      k_node_set_strategy other than "intersection"
                                      (tuned_SIGN.py:235; "union" is unusable as shipped),
-                                     directed graphs (A_csc) */
+                                     SoP on a directed graph */
   S3GRL_ERR_NO_FEATURES = 3,      /* X == NULL: the reference's `assert subgraph_features is not
                                      None` (tuned_SIGN.py:166,221) */
   S3GRL_ERR_OUT_OF_MEMORY = 4,
@@ -83,7 +83,7 @@ typedef struct s3grl_cfg {
   int32_t num_hops;  /* k of the k-hop enclosing subgraph (ignored for SoP, like the reference) */
   int32_t sign_k;    /* number of operators K >= 1 */
   int32_t strategy;  /* s3grl_strategy, PoS Plus only */
-  int32_t directed;  /* must be 0 (A_csc == None in every non-ogbl-citation2 run) */
+  int32_t directed;  /* 1 iff the graph was made by s3grl_graph_create_directed (A and A_csc) */
   uint32_t flags;    /* S3GRL_FLAG_* */
   int32_t rw_m;      /* ScaLed subgraphs (reference utils.py:86-150, rw_kwargs): rw_M random walks */
   int32_t rw_M;      /*   of length rw_m per node, drawn by the engine, replace the BFS (num_hops is
@@ -146,6 +146,16 @@ s3grl_status s3grl_context_destroy(s3grl_context* ctx);
  * checks it). */
 s3grl_status s3grl_graph_create(s3grl_context* ctx, int64_t num_nodes, const int64_t* indptr,
                                 const int32_t* indices, int64_t nnz, s3grl_graph** out);
+/* A DIRECTED graph, as the reference holds it when `directed` is set (sgrl_link_pred.py:107-119: A from the
+ * directed edge_index, A_csc = A.tocsc(); only ogbl-citation2 of the reference's datasets): both forms
+ * of the same nnz arcs — csr_* the successors of every node, csc_* the predecessors (scipy's CSC arrays
+ * as they are: indptr over columns, row ids ascending).  Plans on such a graph need s3grl_cfg.directed
+ * = 1: the BFS follows successors and predecessors (utils.py:58-63), the induced matrix keeps the
+ * directions, D = out-degrees (tuned_SIGN.py:158-161).  That the two forms describe the same arcs is
+ * the caller's promise.  SoP is not available on directed graphs (S3GRL_ERR_NOT_IMPLEMENTED). */
+s3grl_status s3grl_graph_create_directed(s3grl_context* ctx, int64_t num_nodes, const int64_t* csr_indptr,
+                                         const int32_t* csr_indices, const int64_t* csc_indptr,
+                                         const int32_t* csc_indices, int64_t nnz, s3grl_graph** out);
 s3grl_status s3grl_graph_destroy(s3grl_graph* g);
 
 /* PoS / PoS Plus, feature-independent half: BFS to num_hops from {src,dst} on the unmasked

@@ -30,7 +30,7 @@ SYMBOLS = [
     "s3grl_abi_version", "s3grl_status_string", "s3grl_last_error",
     "s3grl_context_create", "s3grl_context_destroy", "s3grl_context_timings",
     "s3grl_context_set_profiling", "s3grl_context_trim", "s3grl_plan_gather_traffic",
-    "s3grl_graph_create", "s3grl_graph_destroy",
+    "s3grl_graph_create", "s3grl_graph_create_directed", "s3grl_graph_destroy",
     "s3grl_plan_create", "s3grl_plan_create_sets", "s3grl_walk_sets", "s3grl_plan_destroy", "s3grl_plan_get_stats", "s3grl_plan_total_rows", "s3grl_plan_row_ptr",
     "s3grl_plan_row_nodes", "s3grl_plan_export_subgraphs", "s3grl_plan_link_cost", "s3grl_run",
     "s3grl_sop_create", "s3grl_sop_destroy", "s3grl_sop_run", "s3grl_sop_features",
@@ -104,6 +104,7 @@ def lib():
         "s3grl_context_trim": [vp, C.POINTER(i64)],
         "s3grl_plan_gather_traffic": [vp, vp, vp, C.POINTER(i64)],
         "s3grl_graph_create": [vp, i64, vp, vp, i64, C.POINTER(vp)],
+        "s3grl_graph_create_directed": [vp, i64, vp, vp, vp, vp, i64, C.POINTER(vp)],
         "s3grl_graph_destroy": [vp],
         "s3grl_plan_create": [vp, vp, vp, i64, C.POINTER(Cfg), C.POINTER(vp)],
         "s3grl_plan_create_sets": [vp, vp, vp, i64, C.POINTER(Cfg), C.POINTER(NodeSets), C.POINTER(vp)],

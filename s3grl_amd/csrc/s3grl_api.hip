@@ -297,6 +297,49 @@ s3grl_status s3grl_context_timings(s3grl_context* ctx, double* what) {
   return S3GRL_OK;
 }
 
+// a caller's CSR (int64 indptr, int32 indices, device) copied into arena arrays with int32 offsets and
+// validated on the device: indptr[0] == 0, monotone, ending at nnz; ids in [0,N); rows strictly ascending
+static s3grl_status upload_csr(s3grl_context* ctx, int64_t num_nodes, const int64_t* indptr, const int32_t* indices,
+                               int64_t nnz, const char* what, int32_t** d_indptr, int32_t** d_indices) {
+  void* p = nullptr;
+  S3GRL_TRY(ctx->arena.alloc((size_t)(num_nodes + 1) * 4, &p));
+  *d_indptr = static_cast<int32_t*>(p);
+  S3GRL_TRY(ctx->arena.alloc((size_t)std::max<int64_t>(nnz, 1) * 4, &p));
+  *d_indices = static_cast<int32_t*>(p);
+  const int64_t n1 = num_nodes + 1;
+  hipLaunchKernelGGL(indptr_to_i32_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0,
+                     ctx->stream, indptr, n1, *d_indptr);
+  S3GRL_HIP_TRY(hipGetLastError());
+  if (nnz)
+    S3GRL_HIP_TRY(hipMemcpyAsync(*d_indices, indices, (size_t)nnz * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  S3GRL_HIP_TRY(hipMemsetAsync(ctx->d_scalars, 0, 16, ctx->stream));
+  // the kernels index LDS bitmaps with the column ids and search rows by bisection: a malformed
+  // CSR would corrupt memory or give silently wrong rows, so it is rejected here
+  hipLaunchKernelGGL(validate_csr_kernel, dim3(512), dim3(256), 0, ctx->stream, *d_indptr, *d_indices,
+                     num_nodes, nnz, ctx->d_scalars + 1);
+  S3GRL_HIP_TRY(hipGetLastError());
+  S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_scalars + 1, ctx->d_scalars + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (const int64_t bad = ctx->h_scalars[1]) {
+    set_last_error(std::string("malformed ") + what + ":" + ((bad & 1) ? " indptr is not monotone from 0 to nnz;" : "") +
+                   ((bad & 2) ? " a column id is outside [0, num_nodes);" : "") +
+                   ((bad & 4) ? " a row is not strictly ascending (unsorted or duplicate entries);" : ""));
+    return S3GRL_ERR_INVALID_ARGUMENT;
+  }
+  return S3GRL_OK;
+}
+
+static s3grl_status graph_max_degree(s3grl_context* ctx, s3grl_graph* g) {
+  S3GRL_HIP_TRY(hipMemsetAsync(ctx->d_scalars, 0, 8, ctx->stream));
+  hipLaunchKernelGGL(max_degree_kernel, dim3(256), dim3(256), 0, ctx->stream, g->indptr, g->num_nodes,
+                     ctx->d_scalars);
+  S3GRL_HIP_TRY(hipGetLastError());
+  S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  g->max_degree = (int32_t)ctx->h_scalars[0];
+  return S3GRL_OK;
+}
+
 s3grl_status s3grl_graph_create(s3grl_context* ctx, int64_t num_nodes, const int64_t* indptr,
                                 const int32_t* indices, int64_t nnz, s3grl_graph** out) {
   if (!ctx || !out || !indptr || num_nodes <= 0 || nnz < 0 || (nnz > 0 && !indices))
@@ -310,48 +353,12 @@ s3grl_status s3grl_graph_create(s3grl_context* ctx, int64_t num_nodes, const int
   g->ctx = ctx;
   g->num_nodes = num_nodes;
   g->nnz = nnz;
-  void* p = nullptr;
-  S3GRL_TRY(ctx->arena.alloc((size_t)(num_nodes + 1) * 4, &p));
-  g->indptr = static_cast<int32_t*>(p);
-  S3GRL_TRY(ctx->arena.alloc((size_t)std::max<int64_t>(nnz, 1) * 4, &p));
-  g->indices = static_cast<int32_t*>(p);
-  const int64_t n1 = num_nodes + 1;
-  hipLaunchKernelGGL(indptr_to_i32_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0,
-                     ctx->stream, indptr, n1, g->indptr);
-  S3GRL_HIP_TRY(hipGetLastError());
-  if (nnz)
-    S3GRL_HIP_TRY(hipMemcpyAsync(g->indices, indices, (size_t)nnz * 4, hipMemcpyDeviceToDevice,
-                                 ctx->stream));
-  S3GRL_HIP_TRY(hipMemsetAsync(ctx->d_scalars, 0, 16, ctx->stream));
-  // the kernels index LDS bitmaps with the column ids and search rows by bisection: a malformed
-  // CSR would corrupt memory or give silently wrong rows, so it is rejected here
-  hipLaunchKernelGGL(validate_csr_kernel, dim3(512), dim3(256), 0, ctx->stream, g->indptr, g->indices,
-                     num_nodes, nnz, ctx->d_scalars + 1);
-  S3GRL_HIP_TRY(hipGetLastError());
-  S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_scalars + 1, ctx->d_scalars + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
-  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
-  if (const int64_t bad = ctx->h_scalars[1]) {
-    set_last_error(std::string("malformed CSR:") + ((bad & 1) ? " indptr is not monotone from 0 to nnz;" : "") +
-                   ((bad & 2) ? " a column id is outside [0, num_nodes);" : "") +
-                   ((bad & 4) ? " a row is not strictly ascending (unsorted or duplicate entries);" : ""));
-    s3grl_graph_destroy(g);
-    return S3GRL_ERR_INVALID_ARGUMENT;
-  }
-  hipLaunchKernelGGL(max_degree_kernel, dim3(256), dim3(256), 0, ctx->stream, g->indptr, num_nodes,
-                     ctx->d_scalars);
-  S3GRL_HIP_TRY(hipGetLastError());
-  S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 8, hipMemcpyDeviceToHost, ctx->stream));
-  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
-  g->max_degree = (int32_t)ctx->h_scalars[0];
-  {   // the same graph in descending degree order: what the link kernels walk
-    const s3grl_status st = build_degree_order(ctx, g);
-    if (st != S3GRL_OK) {
-      s3grl_graph_destroy(g);
-      return st;
-    }
-  }
-  if (onehop_mode_for(g)) {
-    s3grl_status st = build_forward_rows(ctx, g);
+  s3grl_status st = upload_csr(ctx, num_nodes, indptr, indices, nnz, "CSR", &g->indptr, &g->indices);
+  if (st == S3GRL_OK) st = graph_max_degree(ctx, g);
+  // the same graph in descending degree order: what the link kernels walk
+  if (st == S3GRL_OK) st = build_degree_order(ctx, g);
+  if (st == S3GRL_OK && onehop_mode_for(g)) {
+    st = build_forward_rows(ctx, g);
     if (st == S3GRL_OK) {
       s3grl_graph t = *g;   // and the oriented rows of the degree order
       t.indptr = g->r_indptr;
@@ -364,10 +371,47 @@ s3grl_status s3grl_graph_create(s3grl_context* ctx, int64_t num_nodes, const int
       g->r_fwd_indices = t.fwd_indices;
       g->r_fwd_deg = t.fwd_deg;
     }
-    if (st != S3GRL_OK) {
-      s3grl_graph_destroy(g);
-      return st;
-    }
+  }
+  if (st != S3GRL_OK) {
+    s3grl_graph_destroy(g);
+    return st;
+  }
+  *out = g;
+  return S3GRL_OK;
+}
+
+s3grl_status s3grl_graph_create_directed(s3grl_context* ctx, int64_t num_nodes, const int64_t* csr_indptr,
+                                         const int32_t* csr_indices, const int64_t* csc_indptr,
+                                         const int32_t* csc_indices, int64_t nnz, s3grl_graph** out) {
+  if (!ctx || !out || !csr_indptr || !csc_indptr || num_nodes <= 0 || nnz < 0 ||
+      (nnz > 0 && (!csr_indices || !csc_indices)))
+    return S3GRL_ERR_INVALID_ARGUMENT;
+  if (2 * nnz >= (int64_t)INT32_MAX || num_nodes >= (int64_t)INT32_MAX) {
+    set_last_error("graph needs 64-bit edge offsets, not supported");
+    return S3GRL_ERR_GRAPH_TOO_LARGE;
+  }
+  S3GRL_HIP_TRY(hipSetDevice(ctx->device));
+  auto* g = new s3grl_graph();
+  g->ctx = ctx;
+  g->num_nodes = num_nodes;
+  g->directed = true;
+  g->arcs = nnz;
+  s3grl_status st = upload_csr(ctx, num_nodes, csr_indptr, csr_indices, nnz, "CSR", &g->out_indptr, &g->out_indices);
+  if (st == S3GRL_OK)
+    st = upload_csr(ctx, num_nodes, csc_indptr, csc_indices, nnz, "CSC", &g->in_indptr, &g->in_indices);
+  if (st == S3GRL_OK) {   // what the BFS follows: successors and predecessors together (utils.py:60-63)
+    void* p = nullptr;
+    st = ctx->arena.alloc((size_t)(num_nodes + 1) * 4, &p);
+    g->indptr = static_cast<int32_t*>(p);
+    if (st == S3GRL_OK)
+      st = build_union_graph(ctx, num_nodes, g->out_indptr, g->out_indices, g->in_indptr, g->in_indices,
+                             g->indptr, &g->indices, &g->nnz);
+  }
+  if (st == S3GRL_OK) st = graph_max_degree(ctx, g);
+  // (no degree order, no oriented rows: directed plans walk the caller's ids on the bitmap flavour)
+  if (st != S3GRL_OK) {
+    s3grl_graph_destroy(g);
+    return st;
   }
   *out = g;
   return S3GRL_OK;
@@ -387,6 +431,10 @@ s3grl_status s3grl_graph_destroy(s3grl_graph* g) {
   g->ctx->arena.release(g->r_fwd_indptr);
   g->ctx->arena.release(g->r_fwd_indices);
   g->ctx->arena.release(g->r_fwd_deg);
+  g->ctx->arena.release(g->out_indptr);
+  g->ctx->arena.release(g->out_indices);
+  g->ctx->arena.release(g->in_indptr);
+  g->ctx->arena.release(g->in_indices);
   delete g;
   return S3GRL_OK;
 }
@@ -448,9 +496,10 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
     set_last_error("s3grl_plan_create handles PoS / PoS Plus; use s3grl_sop_* for SoP");
     return S3GRL_ERR_INVALID_ARGUMENT;
   }
-  if (cfg->directed) {
-    set_last_error("directed graphs (A_csc) are not implemented");
-    return S3GRL_ERR_NOT_IMPLEMENTED;
+  if ((cfg->directed != 0) != g->directed) {
+    set_last_error(g->directed ? "the graph was created with s3grl_graph_create_directed: s3grl_cfg.directed must be 1"
+                               : "s3grl_cfg.directed = 1 needs a graph made by s3grl_graph_create_directed (A and A_csc)");
+    return S3GRL_ERR_INVALID_ARGUMENT;
   }
   const bool plus = cfg->mode == S3GRL_MODE_POS_PLUS;
   if (plus && cfg->strategy != S3GRL_STRATEGY_INTERSECTION) {
@@ -646,7 +695,7 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   // PoS has no common-neighbour rows: the LDS classes are known without a round trip
   if (!plus)
     S3GRL_TRY(launch_classify(ctx, g, 1, K, plan->n_nodes, p_nodes, lvl_max, L, class_count, class_list,
-                              !sampling, e_cap, stash ? slot : 0));
+                              !sampling && !g->directed, e_cap, stash ? slot : 0));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs, ds, 48 * 8, hipMemcpyDeviceToHost, ctx->stream));   // scalars + class counts
   S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_stats + 3 * kStatRow, st + 3 * kStatRow, 2 * kStatRow * sizeof(int64_t),
                                hipMemcpyDeviceToHost, ctx->stream));
@@ -669,7 +718,7 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   const int cn_cap = ((int)std::max<int64_t>(max_R - 2, 0) + 1) * ((relabel && plus) ? 3 : 1);
   if (plus) {
     S3GRL_TRY(launch_classify(ctx, g, cn_cap, K, plan->n_nodes, p_nodes, lvl_max, L, class_count,
-                              class_list, !sampling, e_cap, stash ? slot : 0));
+                              class_list, !sampling && !g->directed, e_cap, stash ? slot : 0));
     S3GRL_HIP_TRY(hipMemcpyAsync(hs + 32, ds + 32, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
     S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
   }

@@ -170,6 +170,22 @@ struct s3grl_graph {
   int32_t* r_fwd_indptr = nullptr;   // the degree-oriented rows of the relabelled graph (big graphs)
   int32_t* r_fwd_indices = nullptr;
   uint16_t* r_fwd_deg = nullptr;
+  // directed graphs (s3grl_graph_create_directed): indptr / indices above hold the UNION of out- and
+  // in-neighbours (what the reference's directed BFS follows, utils.py:60-63); the arcs themselves:
+  bool directed = false;
+  int64_t arcs = 0;
+  int32_t* out_indptr = nullptr;   // [N+1] CSR of A: successors (degrees, common neighbours)
+  int32_t* out_indices = nullptr;  // [arcs]
+  int32_t* in_indptr = nullptr;    // [N+1] CSC of A = CSR of A^T: predecessors (the pulls r_i = r_{i-1} A_hat)
+  int32_t* in_indices = nullptr;   // [arcs]
+};
+
+// the arcs of a directed graph as the kernels take them (all null for an undirected graph)
+struct DirGraph {
+  const int32_t* out_indptr = nullptr;
+  const int32_t* out_indices = nullptr;
+  const int32_t* in_indptr = nullptr;
+  const int32_t* in_indices = nullptr;
 };
 
 struct s3grl_plan {
@@ -274,6 +290,11 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           int32_t* n_rows, int32_t* n_jobs, int32_t* lvl_max, int32_t* err_flag,
                           int64_t* tot_nodes_alg, HopSampling smp = HopSampling{1.0, 0, 0},
                           int32_t* stash = nullptr, int slot = 0, int32_t* lvl_stash = nullptr);
+// union of two sorted adjacency structures of the same nodes (a directed graph's successors and
+// predecessors): out_indptr [N+1] / *out_indices (arena-owned) / *nnz
+s3grl_status build_union_graph(s3grl_context* ctx, int64_t N, const int32_t* a_indptr, const int32_t* a_indices,
+                               const int32_t* b_indptr, const int32_t* b_indices, int32_t* u_indptr,
+                               int32_t** u_indices, int64_t* u_nnz);
 int num_class_lists();
 s3grl_status launch_random_walks(s3grl_context* ctx, const s3grl_graph* g, int m, int M,
                                  uint32_t seed, int32_t* raw);

@@ -383,6 +383,10 @@ s3grl_status s3grl_sop_create(s3grl_context* ctx, const s3grl_graph* g, const fl
     set_last_error("sign_k must be in 1..8, F > 0, ldx >= F");
     return S3GRL_ERR_INVALID_ARGUMENT;
   }
+  if (g->directed) {
+    set_last_error("SoP on a directed graph is not implemented (the closed form relies on a symmetric operator)");
+    return S3GRL_ERR_NOT_IMPLEMENTED;
+  }
   if (g->num_nodes > kMaxNodesLds) {
     set_last_error("num_nodes exceeds the LDS bitmap limit");
     return S3GRL_ERR_GRAPH_TOO_LARGE;

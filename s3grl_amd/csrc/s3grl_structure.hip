@@ -79,7 +79,8 @@ __global__ __launch_bounds__(kCountBlock) void count_kernel(
     int32_t* __restrict__ n_nodes, int32_t* __restrict__ p_nodes, int32_t* __restrict__ n_rows,
     int32_t* __restrict__ n_jobs, int32_t* __restrict__ lvl_max, int32_t* __restrict__ err_flag,
     unsigned long long* __restrict__ tot_nodes_alg, HopSampling smp, int32_t* __restrict__ stash,
-    int slot, int32_t* __restrict__ lvl_stash) {
+    int slot, int32_t* __restrict__ lvl_stash, const int32_t* __restrict__ cn_indptr,
+    const int32_t* __restrict__ cn_indices, int full_p) {
   extern __shared__ uint32_t smem[];
   const bool walks = walks_on(ws);
   // `cur` (the frontier as a bitmap, for levels too big for the frontier list) is only needed when
@@ -250,11 +251,12 @@ __global__ __launch_bounds__(kCountBlock) void count_kernel(
   if (sampling) __syncthreads();   // mem is complete
   const uint32_t* member = sampling ? mem : vis;
   if (plus && wave_id() == 0)
-    R = 2 + common_neighbours(indptr, indices, [&](int x) { return test_bit(member, x); }, src, dst, nullptr);
+    R = 2 + common_neighbours(cn_indptr, cn_indices, [&](int x) { return test_bit(member, x); }, src, dst, nullptr);
   if (tid == 0) {
     if (lvl_l) lvl_l[kMaxLevels - 1] = nlev_seen;   // levels 0 .. nlev_seen-1 are complete
     n_nodes[l] = n;
-    p_nodes[l] = R > 2 ? cum_b : cum_a;
+    // (directed plans keep D^-1/2 — an OUT-degree — and state for every node of S: full_p)
+    p_nodes[l] = full_p ? n : (R > 2 ? cum_b : cum_a);
     n_rows[l] = R;
     n_jobs[l] = (R + 1) / 2;
     lvl_max[l] = biggest;
@@ -803,7 +805,11 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
 // of two bitmap words + a rank prefix + a popcount.  For graphs whose map (2N bytes) leaves most of
 // the LDS free; the list comes from count_kernel's stash (the host sends no other link here).  Rows
 // are walked in the same order by the same lanes as in the bitmap flavour: same sums bit for bit.
-template <int T, int K, int G, bool GS, bool HS, bool DM = false>
+// DIRECTED (bitmap flavour only): the BFS above ran on the union of successors and predecessors
+// (utils.py:60-63); the operator is D^-1/2 A D^-1/2 of the directed induced matrix with D = OUT-degrees
+// (row counts, tuned_SIGN.py:158-161), so r_i = r_{i-1} A_hat pulls over a node's PREDECESSORS (dg.in_*)
+// and the degrees are counted over its successors (dg.out_*), for every node of S (p == n).
+template <int T, int K, int G, bool GS, bool HS, bool DM = false, bool DIRECTED = false>
 __global__ __launch_bounds__(T) void link_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int W,
     const int64_t* __restrict__ links, const int32_t* __restrict__ class_list, int hops, int plus,
@@ -819,8 +825,14 @@ __global__ __launch_bounds__(T) void link_kernel(
     char* __restrict__ scratch, int64_t scratch_stride, unsigned long long* __restrict__ dbg,
     HopSampling smp, const int32_t* __restrict__ stash, int slot,
     const int32_t* __restrict__ old_of_new, const int32_t* __restrict__ new_of_old, int lo_id,
-    int split_t, int seg_shift) {
+    int split_t, int seg_shift, const DirGraph dg) {
+  static_assert(!DIRECTED || (!HS && !DM), "directed plans run on the bitmap flavour");
   extern __shared__ uint32_t smem[];
+  // rows walked by the operator passes (pull), by the degree count and by the common-neighbour test
+  const int32_t* __restrict__ w_indptr = DIRECTED ? dg.in_indptr : indptr;
+  const int32_t* __restrict__ w_indices = DIRECTED ? dg.in_indices : indices;
+  const int32_t* __restrict__ o_indptr = DIRECTED ? dg.out_indptr : indptr;
+  const int32_t* __restrict__ o_indices = DIRECTED ? dg.out_indices : indices;
   // the caller's id of an internal id (the graph is walked in its degree order, s3grl_relabel.hip)
   auto ext = [&](int v) -> int { return old_of_new ? old_of_new[v] : v; };
   // diagnostic only (S3GRL_DEBUG_STAMPS): cycles per phase, summed over workgroups; the extra
@@ -945,7 +957,7 @@ __global__ __launch_bounds__(T) void link_kernel(
   const int64_t rp = row_ptr[l];
   const int R = (int)(row_ptr[l + 1] - rp);
   const int max_row_hop = R > 2 ? 1 : 0;  // common neighbours sit at hop 1
-  const int p = lvl_end[min(K - 1 + max_row_hop, nlev - 1)];
+  const int p = DIRECTED ? n : lvl_end[min(K - 1 + max_row_hop, nlev - 1)];
 
   // ---- P as bitmap + rank prefix; node list out -------------------------------------------
   if constexpr (!HS) {
@@ -961,7 +973,7 @@ __global__ __launch_bounds__(T) void link_kernel(
     vol_local += indptr[v + 1] - indptr[v];
   }
   if (plus && wave_id() == 0) {
-    const int c = common_neighbours(indptr, indices, in_s, src, dst, cn);
+    const int c = common_neighbours(o_indptr, o_indices, in_s, src, dst, cn);
     if (old_of_new && c > 1) {
       // the common-neighbour rows go out in ascending order of the CALLER's ids: rank sort by one
       // wavefront; the host sized cn[] three times over for it (keys and the sorted copy behind the list)
@@ -1002,8 +1014,8 @@ __global__ __launch_bounds__(T) void link_kernel(
   // degree alone.
   int edges_local = 0;
   int edges_exact = -1;   // set when a pass of pair 0 walked every row of S
-  int dinv_rows = lvl_end[min(max_row_hop, nlev - 1)];
-  if (!walks_on(ws) && !sampling_on(smp) && hops > max_row_hop) {
+  int dinv_rows = DIRECTED ? n : lvl_end[min(max_row_hop, nlev - 1)];
+  if (!DIRECTED && !walks_on(ws) && !sampling_on(smp) && hops > max_row_hop) {
     // A plain BFS to `hops` holds every neighbour of a node that sits below hop `hops`: the
     // subgraph degree of such a row is its global degree, minus the masked target link at src and
     // dst (utils.py:79-80).  No walk.
@@ -1017,7 +1029,7 @@ __global__ __launch_bounds__(T) void link_kernel(
     }
   } else {
     walk_rows<T, G, 2>(
-        0, dinv_rows, list, indptr, indices, hub,
+        0, dinv_rows, list, o_indptr, o_indices, hub,
         [&](RowAcc& a, int v, int u, bool valid) {
           // the target link is masked (utils.py:79-80): one compare per neighbour against the
           // row's partner (-1 for every row but src and dst; hoisted out of the neighbour loop)
@@ -1084,8 +1096,8 @@ __global__ __launch_bounds__(T) void link_kernel(
   }
   auto walk_split = [&](int limit, auto visit, auto commit) __attribute__((always_inline)) {
     const int a_end = min(limit, lo_begin);
-    walk_rows<T, G, 2>(0, a_end, list, indptr, indices, hub, visit, commit);
-    if (limit > a_end) walk_rows<T, 1, 2>(a_end, limit, list, indptr, indices, nullptr, visit, commit);
+    walk_rows<T, G, 2>(0, a_end, list, w_indptr, w_indices, hub, visit, commit);
+    if (limit > a_end) walk_rows<T, 1, 2>(a_end, limit, list, w_indptr, w_indices, nullptr, visit, commit);
   };
   const int npairs = (R + 1) / 2;
   for (int pr = 0; pr < npairs; ++pr) {
@@ -1304,7 +1316,9 @@ __global__ __launch_bounds__(T) void link_kernel(
           [&](RowAcc& a, int t, int v) {
             edges_pass += a.n;
             if (t < support) {
-              const float dw = a.n > 0 ? 1.0f / sqrtf((float)a.n) : 0.0f;
+              // (directed: a.n counted predecessors; D^-1/2 is the out-degree's, known for all of S)
+              const float dw = DIRECTED ? dinvP[p_index_of_row(t, v)]
+                                        : (a.n > 0 ? 1.0f / sqrtf((float)a.n) : 0.0f);
               const float rx = dw * a.x, ry = dw * a.y;
               coef[cidx(i, t)] = make_float2(rx, ry);
               if (v == src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
@@ -1399,8 +1413,10 @@ s3grl_status launch_find_mirrors(s3grl_context* ctx, const int64_t* links, int64
 s3grl_status launch_random_walks(s3grl_context* ctx, const s3grl_graph* g, int m, int M,
                                  uint32_t seed, int32_t* raw) {
   const int64_t total = g->num_nodes * M;
+  // (a directed graph is walked along its arcs, like torch_cluster walks the directed edge_index)
   hipLaunchKernelGGL(random_walks_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     ctx->stream, g->indptr, g->indices, g->num_nodes, m, M, seed, raw);
+                     ctx->stream, g->directed ? g->out_indptr : g->indptr, g->directed ? g->out_indices : g->indices,
+                     g->num_nodes, m, M, seed, raw);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -1439,7 +1455,8 @@ s3grl_status launch_walk_sets(s3grl_context* ctx, const s3grl_graph* g, const in
   tmp.ptrs.push_back(ws);
   S3GRL_HIP_TRY(hipMemsetAsync(ctx->d_scalars, 0, 8, ctx->stream));
   hipLaunchKernelGGL(walk_sets_kernel, dim3((unsigned)num_starts), dim3(kWalkSetBlock), (size_t)P * 4, ctx->stream,
-                     g->indptr, g->indices, g->num_nodes, starts, m, M, seed, P, cap, static_cast<int32_t*>(scratch),
+                     g->directed ? g->out_indptr : g->indptr, g->directed ? g->out_indices : g->indices,
+                     g->num_nodes, starts, m, M, seed, P, cap, static_cast<int32_t*>(scratch),
                      static_cast<int32_t*>(cnt), reinterpret_cast<int32_t*>(ctx->d_scalars));
   S3GRL_HIP_TRY(hipGetLastError());
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, static_cast<int32_t*>(cnt), num_starts, set_ptr,
@@ -1517,7 +1534,9 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
                      g->indices, (int)g->num_nodes, W, links, hops, plus, K,
                      g->max_degree > kHubArmDegree ? 1 : 0, ws, partner, mirror_of, n_nodes,
                      p_nodes, n_rows, n_jobs, lvl_max, err_flag,
-                     reinterpret_cast<unsigned long long*>(tot_nodes_alg), smp, stash, slot, lvl_stash);
+                     reinterpret_cast<unsigned long long*>(tot_nodes_alg), smp, stash, slot, lvl_stash,
+                     g->directed ? g->out_indptr : g->indptr, g->directed ? g->out_indices : g->indices,
+                     g->directed ? 1 : 0);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -1899,6 +1918,7 @@ struct LinkArgs {
   const int32_t *old_of_new, *new_of_old;   // non-null: the graph is walked in its degree order
   int lo_id;                                // then: ids >= lo_id have at most two stored neighbours (else -1)
   int split_t, seg_shift;                   // lists longer than split_t are laid out in pieces of 2^seg_shift
+  DirGraph dg;                              // arcs of a directed graph (null otherwise)
 };
 
 // One-hop full-reach classes (link_full_kernel).  Small classes run one wavefront per link (no
@@ -1926,7 +1946,7 @@ s3grl_status launch_full_class(s3grl_context* ctx, const LinkArgs& a, int64_t L,
   return S3GRL_OK;
 }
 
-template <int T, int K, int G, bool GS, bool HS, bool DM = false>
+template <int T, int K, int G, bool GS, bool HS, bool DM = false, bool DIRECTED = false>
 s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t L, int cls, int count,
                                  hipStream_t stream) {
   const int W = words_for(a.g->num_nodes);
@@ -1940,7 +1960,7 @@ s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t 
   else
     lds = (size_t)4 * link_fixed_words(a.g->num_nodes, a.cn_cap, K) +
           (GS ? 0 : (size_t)class_bounds(a.g->num_nodes, a.cn_cap, K).b[cls]);
-  auto kern = link_kernel<T, K, G, GS, HS, DM>;
+  auto kern = link_kernel<T, K, G, GS, HS, DM, DIRECTED>;
   S3GRL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(T), lds, stream, a.g->indptr,
@@ -1951,7 +1971,8 @@ s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t 
                      reinterpret_cast<unsigned long long*>(a.tot_edges),
                      reinterpret_cast<unsigned long long*>(a.tot_support),
                      reinterpret_cast<unsigned long long*>(a.tot_vol), a.scratch, a.scratch_stride,
-                     a.dbg, a.smp, a.stash, a.slot, a.old_of_new, a.new_of_old, a.lo_id, a.split_t, a.seg_shift);
+                     a.dbg, a.smp, a.stash, a.slot, a.old_of_new, a.new_of_old, a.lo_id, a.split_t, a.seg_shift,
+                     a.dg);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -1963,6 +1984,10 @@ s3grl_status launch_link_class(s3grl_context* ctx, const LinkArgs& a, int64_t L,
   const double mean_deg = (double)a.g->nnz / (double)std::max<int64_t>(a.g->num_nodes, 1);
   static const int force_g = getenv("S3GRL_LANES_PER_ROW") ? atoi(getenv("S3GRL_LANES_PER_ROW")) : 0;
   const int gsel = force_g ? force_g : (mean_deg <= 6.0 ? 4 : 8);
+  if (a.dg.out_indptr) {   // directed plans: bitmap flavour, four lanes per row (two instantiations per sign_k)
+    if (cls == kNumClasses) return launch_link_class_g<1024, K, 4, true, false, false, true>(ctx, a, L, cls, count, stream);
+    return launch_link_class_g<256, K, 4, false, false, false, true>(ctx, a, L, cls, count, stream);
+  }
   if (cls == kNumClasses) {   // HBM-scratch overflow class
     if (gsel <= 4) return launch_link_class_g<1024, K, 4, true, false>(ctx, a, L, cls, count, stream);
     return launch_link_class_g<1024, K, 8, true, false>(ctx, a, L, cls, count, stream);
@@ -2128,7 +2153,8 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
              tot_support, tot_vol, scratch, scratch_stride,
              getenv("S3GRL_DEBUG_STAMPS") ? reinterpret_cast<unsigned long long*>(ctx->d_scalars + 16) : nullptr,
              smp, stash, slot, e_cap, nullptr, 0, 0, 0, old_of_new, new_of_old,
-             (old_of_new && !getenv("S3GRL_NO_LEAF_WALK")) ? g->deg_le2_from : -1, split_t, seg_shift};
+             (old_of_new && !getenv("S3GRL_NO_LEAF_WALK")) ? g->deg_le2_from : -1, split_t, seg_shift,
+             DirGraph{g->out_indptr, g->out_indices, g->in_indptr, g->in_indices}};
   // the class whose bit matrix does not fit LDS: one slice per resident workgroup of a persistent grid
   if (class_count_host[kFullBig] > 0) {
     // slice = list of found edges (uint32, at most ecap / 2) + CSR columns (uint16 x ecap) of the

@@ -40,15 +40,24 @@ class Graph:
     """Device CSR of the train graph A.  Values are ignored (reference tuned_SIGN.py:153-156
     drops them at `ssp.find` -> `SparseTensor(row, col)`)."""
 
-    def __init__(self, engine, indptr, indices, num_nodes):
+    def __init__(self, engine, indptr, indices, num_nodes, csc=None):
+        """csc = (indptr, indices) of the same arcs in CSC form: a DIRECTED graph (the reference's
+        `directed=True` with A and A_csc, sgrl_link_pred.py:116-119)."""
         self.engine = engine
         self.num_nodes = int(num_nodes)
         self.indptr = indptr      # int64 [N+1] device (kept alive for the caller's benefit)
         self.indices = indices    # int32 [nnz] device
         self.nnz = int(indices.numel())
+        self.directed = csc is not None
         h = C.c_void_p()
-        N.check(N.lib().s3grl_graph_create(engine._ctx, self.num_nodes, _ptr(indptr), _ptr(indices),
-                                           self.nnz, C.byref(h)), "s3grl_graph_create")
+        if csc is None:
+            N.check(N.lib().s3grl_graph_create(engine._ctx, self.num_nodes, _ptr(indptr), _ptr(indices),
+                                               self.nnz, C.byref(h)), "s3grl_graph_create")
+        else:
+            assert int(csc[1].numel()) == self.nnz
+            N.check(N.lib().s3grl_graph_create_directed(engine._ctx, self.num_nodes, _ptr(indptr), _ptr(indices),
+                                                        _ptr(csc[0]), _ptr(csc[1]), self.nnz, C.byref(h)),
+                    "s3grl_graph_create_directed")
         self._h = h
         engine._children.add(self)
 
@@ -263,8 +272,11 @@ class Engine:
         self._children = weakref.WeakSet()
 
     # ---- inputs ---------------------------------------------------------------------------
-    def graph(self, A=None, *, indptr=None, indices=None, num_nodes=None):
-        """From a scipy CSR matrix (what the reference hands its operators) or raw CSR arrays."""
+    def graph(self, A=None, *, indptr=None, indices=None, num_nodes=None, directed=False, A_csc=None):
+        """From a scipy CSR matrix (what the reference hands its operators) or raw CSR arrays.
+        `directed` (with the reference's `A_csc`, or derived from A when it is None): the arcs of A
+        keep their direction — plans on the graph must then say `directed=True` too."""
+        csc = None
         if A is not None:
             import scipy.sparse as ssp
 
@@ -275,13 +287,24 @@ class Engine:
             if A.nnz and (A.data == 0).any():
                 raise ValueError("stored zeros in A are not supported (the reference's BFS would "
                                  "follow them while its operator drops them)")
-            if (A != A.T).nnz:
-                raise NotImplementedError("A must be structurally symmetric (directed graphs are "
-                                          "not implemented)")
+            if directed:
+                C_ = ssp.csc_matrix(A if A_csc is None else A_csc)
+                if not C_.has_canonical_format:
+                    C_ = C_.copy()
+                    C_.sum_duplicates()
+                if C_.shape != A.shape or C_.nnz != A.nnz:
+                    raise ValueError("A_csc does not hold the arcs of A")
+                csc = (torch.as_tensor(np.asarray(C_.indptr, dtype=np.int64)).to(self.device),
+                       torch.as_tensor(np.asarray(C_.indices, dtype=np.int32)).to(self.device))
+            elif (A != A.T).nnz:
+                raise ValueError("A is not structurally symmetric: a directed graph needs directed=True "
+                                 "(and its A_csc), like the reference's callers pass them")
             indptr, indices, num_nodes = A.indptr, A.indices, A.shape[0]
+        elif directed:
+            raise ValueError("a directed graph is given as a scipy matrix (A, A_csc)")
         ip = torch.as_tensor(np.asarray(indptr, dtype=np.int64)).to(self.device)
         ix = torch.as_tensor(np.asarray(indices, dtype=np.int32)).to(self.device)
-        return Graph(self, ip, ix, num_nodes)
+        return Graph(self, ip, ix, num_nodes, csc)
 
     def features(self, x, mode="auto"):
         """Upload x (fp32 [N,F]) and prepare it for the gather; see `Features`."""
@@ -365,7 +388,7 @@ class Engine:
         if strategy not in N.STRATEGY:
             raise NotImplementedError(f"check strat {strategy}")      # tuned_SIGN.py:235
         cfg.strategy = N.STRATEGY[strategy]
-        cfg.directed = int(bool(directed))
+        cfg.directed = int(bool(directed) or graph.directed)
         cfg.flags = (N.FLAG_FULL_STATS if full_stats else 0) | (0 if fold_reversed else N.FLAG_NO_FOLD) | \
             (N.FLAG_COUNT_ONLY if count_only else 0)
         cfg.seed = int(seed) & 0xffffffff

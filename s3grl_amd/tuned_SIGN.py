@@ -7,7 +7,7 @@ static method uploads (and caches) A and x, runs the HIP engine once for the who
 returns a `list` of per-link `Data`-like objects that are views into one collated tensor.
 
 What is NOT mirrored (raises NotImplementedError, the reference's own convention for unsupported
-flows): directed graphs (`A_csc`), and `k_node_set_strategy='union'`, which the reference itself
+flows): `k_node_set_strategy='union'`, which the reference itself
 cannot execute (tuned_SIGN.py:243 builds a ragged tensor).  ScaLed subgraphs (`rw_kwargs`): the
 walk caches the caller hands in (`cached_pos_rws` / `cached_neg_rws`, `unique_nodes`; reference
 utils.py:94-108) are honoured as they are — the extracted node sets are the caller's, bit for
@@ -120,20 +120,20 @@ def _fingerprint_x(x):
     return ("n", a.shape, a.dtype.str, _hash_bytes(a))
 
 
-def _device_graph(A):
+def _device_graph(A, directed=False, A_csc=None):
     eng = _engine.default_engine()
     ent = _cache.get("A")
-    fp = _fingerprint_A(A)
+    fp = _fingerprint_A(A) + (bool(directed),)
     if ent is None or ent[0] is not A or ent[1] != fp:
         if ent is not None:
             ent[2].close()
-        ent = (A, fp, eng.graph(A))
+        ent = (A, fp, eng.graph(A, directed=bool(directed), A_csc=A_csc))
         _cache["A"] = ent
     return eng, ent[2]
 
 
-def _device_inputs(A, x):
-    eng, g = _device_graph(A)
+def _device_inputs(A, x, directed=False, A_csc=None):
+    eng, g = _device_graph(A, directed, A_csc)
     ent = _cache.get("x")
     fp = _fingerprint_x(x)
     if ent is None or ent[0] is not x or ent[1] != fp:
@@ -391,11 +391,6 @@ def _rw_of(eng, rw_kwargs, y, link_index, num_nodes):
 SAMPLING_SEED = 0
 
 
-def _check_unsupported(directed, A_csc):
-    if directed or A_csc is not None:
-        raise NotImplementedError("directed graphs are not implemented")
-
-
 def _sampling_of(ratio_per_hop, max_nodes_per_hop):
     return {"ratio_per_hop": 1.0 if ratio_per_hop is None else ratio_per_hop,
             "max_nodes_per_hop": max_nodes_per_hop, "seed": SAMPLING_SEED}
@@ -420,10 +415,9 @@ class OptimizedSignOperations:
                            x, y, sign_kwargs, rw_kwargs):
         """Reference tuned_SIGN.py:137-189."""
         print("PoS Optimized Flow.")
-        _check_unsupported(directed, A_csc)
         K = sign_kwargs['sign_k']
         assert x is not None                                  # tuned_SIGN.py:166
-        eng, g, xd = _device_inputs(A, x)
+        eng, g, xd = _device_inputs(A, x, directed, A_csc)
         res = eng.precompute(g, xd, eng.links(link_index), mode="pos", num_hops=num_hops, sign_k=K,
                              **_rw_of(eng, rw_kwargs, y, link_index, g.num_nodes),
                              **_sampling_of(ratio_per_hop, max_nodes_per_hop))
@@ -434,7 +428,6 @@ class OptimizedSignOperations:
                                 A_csc, x, y, sign_kwargs, rw_kwargs):
         """Reference tuned_SIGN.py:192-262."""
         print("PoS Plus Optimized Flow.")
-        _check_unsupported(directed, A_csc)
         K = sign_kwargs['sign_k']
         strat = sign_kwargs['k_node_set_strategy']
         if strat not in ('union', 'intersection'):
@@ -443,7 +436,7 @@ class OptimizedSignOperations:
             raise NotImplementedError("check strategy union: unusable in the reference "
                                       "(tuned_SIGN.py:243), not implemented here")
         assert x is not None                                  # tuned_SIGN.py:221
-        eng, g, xd = _device_inputs(A, x)
+        eng, g, xd = _device_inputs(A, x, directed, A_csc)
         res = eng.precompute(g, xd, eng.links(link_index), mode="pos_plus", num_hops=num_hops,
                              sign_k=K, strategy=strat, **_rw_of(eng, rw_kwargs, y, link_index, g.num_nodes),
                              **_sampling_of(ratio_per_hop, max_nodes_per_hop))
