@@ -678,11 +678,6 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
                             n_rows, n_jobs, lvl_max, e_cap, reinterpret_cast<int32_t*>(ds), st + 3 * kStatRow,
                             st + 4 * kStatRow));
   } else {
-    if (g->num_nodes > kMaxNodesLds) {
-      set_last_error("num_nodes " + std::to_string(g->num_nodes) + " exceeds the LDS bitmap limit " +
-                     std::to_string(kMaxNodesLds) + " of multi-hop / sampled / random-walk plans");
-      return S3GRL_ERR_GRAPH_TOO_LARGE;
-    }
     S3GRL_TRY(launch_count(ctx, &g_walk, links_walk, L, cfg->num_hops, plus ? 1 : 0, K, ws,
                            partner, mirror_of,
                            plan->n_nodes, p_nodes, n_rows, n_jobs, lvl_max,
@@ -726,11 +721,6 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
                                   // [8..13] hash classes, [14..19] one-hop classes, [20] one-hop
                                   // class with its bit matrix in HBM (see classify_kernel)
   std::memcpy(class_count_host, hs + 32, sizeof(class_count_host));
-  if (g->num_nodes > kMaxNodesLds && class_count_host[6] > 0) {
-    set_last_error(std::to_string(class_count_host[6]) + " link(s) of a graph above the LDS bitmap limit "
-                   "do not fit the on-chip one-hop / hash paths");
-    return S3GRL_ERR_GRAPH_TOO_LARGE;
-  }
   if (getenv("S3GRL_DEBUG")) {
     fprintf(stderr, "[s3grl] L=%lld max_n=%lld classes:", (long long)L, (long long)max_n);
     for (int c = 0; c < 21; ++c) fprintf(stderr, " %d", class_count_host[c]);

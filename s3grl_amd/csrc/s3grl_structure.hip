@@ -71,7 +71,10 @@ __device__ __forceinline__ int common_neighbours(const int32_t* __restrict__ ind
 // room for only a few workgroups per CU get four waves per link.
 constexpr int kCountList = 1024;
 
-template <int G, int kCountBlock>
+// EXT: the N-bit bitmaps live in an HBM slice per workgroup (`ext`, `ext_stride` words) instead of
+// LDS — graphs of more than kMaxNodesLds nodes; same code, slower memory.  Launched over chunks of the
+// link list (`link_base`), so that a bounded number of slices serves any number of links.
+template <int G, int kCountBlock, bool EXT = false>
 __global__ __launch_bounds__(kCountBlock) void count_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int N, int W,
     const int64_t* __restrict__ links, int hops, int plus, int K, int hubs,
@@ -80,7 +83,8 @@ __global__ __launch_bounds__(kCountBlock) void count_kernel(
     int32_t* __restrict__ n_jobs, int32_t* __restrict__ lvl_max, int32_t* __restrict__ err_flag,
     unsigned long long* __restrict__ tot_nodes_alg, HopSampling smp, int32_t* __restrict__ stash,
     int slot, int32_t* __restrict__ lvl_stash, const int32_t* __restrict__ cn_indptr,
-    const int32_t* __restrict__ cn_indices, int full_p) {
+    const int32_t* __restrict__ cn_indices, int full_p, uint32_t* __restrict__ ext, int64_t ext_stride,
+    int link_base) {
   extern __shared__ uint32_t smem[];
   const bool walks = walks_on(ws);
   // `cur` (the frontier as a bitmap, for levels too big for the frontier list) is only needed when
@@ -88,16 +92,27 @@ __global__ __launch_bounds__(kCountBlock) void count_kernel(
   // leaves it out — a third of the LDS of a big graph
   const bool one_hop = hops <= 1 || walks;
   const int nbm = one_hop ? 2 : 3;
-  uint32_t* vis = smem;
-  uint32_t* cur = one_hop ? nullptr : smem + W;
-  uint32_t* nxt = smem + (nbm - 1) * W;
-  int* sh = reinterpret_cast<int*>(smem + nbm * W);
   // per-hop sampling: `vis` also holds discovered-but-dropped nodes, so the members of S get a
   // bitmap of their own (the launcher adds W words behind the list when sampling is on)
   const bool sampling = !walks && sampling_on(smp);
-  uint32_t* mem = sampling ? smem + nbm * W + 8 + kHubWords + kCountList : nullptr;
+  uint32_t *vis, *cur, *nxt, *mem;
+  int* sh;
+  if constexpr (EXT) {
+    uint32_t* bm = ext + (int64_t)blockIdx.x * ext_stride;
+    vis = bm;
+    cur = one_hop ? nullptr : bm + W;
+    nxt = bm + (nbm - 1) * W;
+    mem = sampling ? bm + nbm * W : nullptr;
+    sh = reinterpret_cast<int*>(smem);
+  } else {
+    vis = smem;
+    cur = one_hop ? nullptr : smem + W;
+    nxt = smem + (nbm - 1) * W;
+    sh = reinterpret_cast<int*>(smem + nbm * W);
+    mem = sampling ? smem + nbm * W + 8 + kHubWords + kCountList : nullptr;
+  }
   const int tid = threadIdx.x;
-  const int l = blockIdx.x;
+  const int l = link_base + blockIdx.x;
   const int64_t s64 = links[2 * (int64_t)l], d64 = links[2 * (int64_t)l + 1];
   if (s64 < 0 || s64 >= N || d64 < 0 || d64 >= N || s64 == d64) {
     if (tid == 0) {
@@ -822,7 +837,7 @@ __global__ __launch_bounds__(T) void link_kernel(
     int64_t* __restrict__ row_nodes,
     int32_t* __restrict__ lvl_out, unsigned long long* __restrict__ tot_edges,
     unsigned long long* __restrict__ tot_support, unsigned long long* __restrict__ tot_vol,
-    char* __restrict__ scratch, int64_t scratch_stride, unsigned long long* __restrict__ dbg,
+    char* __restrict__ scratch, int64_t scratch_stride, int bm_ext_words, unsigned long long* __restrict__ dbg,
     HopSampling smp, const int32_t* __restrict__ stash, int slot,
     const int32_t* __restrict__ old_of_new, const int32_t* __restrict__ new_of_old, int lo_id,
     int split_t, int seg_shift, const DirGraph dg) {
@@ -864,6 +879,10 @@ __global__ __launch_bounds__(T) void link_kernel(
     hmask = (uint32_t)(C - 1);
     set_words = 2 * C;
   }
+  // GS on a graph whose three N-bit bitmaps do not fit LDS (num_nodes > ~327 680): they sit at the head
+  // of the workgroup's HBM slice (bm_ext_words > 0) and LDS holds the small fixed part only
+  const bool bm_ext = GS && bm_ext_words > 0;
+  if (bm_ext) set_words = 0;
   uint16_t* dmap = reinterpret_cast<uint16_t*>(smem);
   uint32_t* vis = smem;
   uint32_t* inP = smem + W;
@@ -880,6 +899,12 @@ __global__ __launch_bounds__(T) void link_kernel(
   float2* cur;
   if constexpr (GS) {
     char* base = scratch + (int64_t)blockIdx.x * scratch_stride;   // 256-byte aligned slices
+    if (bm_ext) {
+      vis = reinterpret_cast<uint32_t*>(base);
+      inP = vis + W;
+      wpreP = vis + 2 * W;
+      base += (size_t)bm_ext_words * 4;
+    }
     list = reinterpret_cast<int32_t*>(base);
     dinvP = reinterpret_cast<float*>(list + n_alloc);
     cur = reinterpret_cast<float2*>(base + (((size_t)(n_alloc + p_alloc) * 4 + 7) & ~(size_t)7));
@@ -1519,12 +1544,34 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
   if (L == 0) return S3GRL_OK;
   const int W = words_for(g->num_nodes);
   const int nbm = (hops <= 1 || walks_on(ws)) ? 2 : 3;   // see count_kernel: no frontier bitmap for one hop
-  const size_t lds = (size_t)(nbm * W + 8 + kHubWords + kCountList + (hop_sampling_on(smp) ? W : 0)) * 4;
-  if (lds > 163840) {
-    set_last_error("num_nodes " + std::to_string(g->num_nodes) + ": the LDS bitmaps exceed 160 KiB");
-    return S3GRL_ERR_GRAPH_TOO_LARGE;
-  }
+  const int nsets = nbm + (hop_sampling_on(smp) ? 1 : 0);
+  const size_t lds = (size_t)(nsets * W + 8 + kHubWords + kCountList) * 4;
   const bool sparse = (double)g->nnz / (double)std::max<int64_t>(g->num_nodes, 1) <= 6.0;
+  const int32_t* cn_ip = g->directed ? g->out_indptr : g->indptr;
+  const int32_t* cn_ix = g->directed ? g->out_indices : g->indices;
+  if (lds > 163840 || getenv("S3GRL_FORCE_EXT_BITMAPS")) {
+    // The N-bit bitmaps do not fit a CU's LDS (num_nodes > ~327 680): they live in HBM, one slice per
+    // workgroup of a launch, and the list is processed in chunks that share the slices.
+    const int64_t stride = ((int64_t)nsets * W + 63) / 64 * 64;
+    const int chunk = (int)std::min<int64_t>(L, std::max<int64_t>(256, ((int64_t)1 << 29) / (stride * 4)));   // <= 512 MiB of slices
+    Transient tmp{ctx, {}};
+    void* q = nullptr;
+    S3GRL_TRY(ctx->arena.alloc((size_t)stride * 4 * chunk, &q));
+    tmp.ptrs.push_back(q);
+    const size_t lds_ext = (size_t)(8 + kHubWords + kCountList) * 4;
+    auto kern = sparse ? count_kernel<4, 256, true> : count_kernel<8, 256, true>;
+    for (int64_t base = 0; base < L; base += chunk) {
+      const int64_t cnt = std::min<int64_t>(chunk, L - base);
+      hipLaunchKernelGGL(kern, dim3((unsigned)cnt), dim3(256), lds_ext, ctx->stream, g->indptr, g->indices,
+                         (int)g->num_nodes, W, links, hops, plus, K, g->max_degree > kHubArmDegree ? 1 : 0, ws,
+                         partner, mirror_of, n_nodes, p_nodes, n_rows, n_jobs, lvl_max, err_flag,
+                         reinterpret_cast<unsigned long long*>(tot_nodes_alg), smp, stash, slot, lvl_stash, cn_ip,
+                         cn_ix, g->directed ? 1 : 0, static_cast<uint32_t*>(q), stride, (int)base);
+      S3GRL_HIP_TRY(hipGetLastError());
+    }
+    S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));   // the slices are released on return
+    return S3GRL_OK;
+  }
   const bool small = lds <= 24 * 1024;
   auto kern = small ? (sparse ? count_kernel<4, 128> : count_kernel<8, 128>)
                     : (sparse ? count_kernel<4, 256> : count_kernel<8, 256>);
@@ -1535,8 +1582,7 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
                      g->max_degree > kHubArmDegree ? 1 : 0, ws, partner, mirror_of, n_nodes,
                      p_nodes, n_rows, n_jobs, lvl_max, err_flag,
                      reinterpret_cast<unsigned long long*>(tot_nodes_alg), smp, stash, slot, lvl_stash,
-                     g->directed ? g->out_indptr : g->indptr, g->directed ? g->out_indices : g->indices,
-                     g->directed ? 1 : 0);
+                     cn_ip, cn_ix, g->directed ? 1 : 0, nullptr, 0, 0);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -1863,14 +1909,10 @@ s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_ca
   if (L == 0) return S3GRL_OK;
   ClassBounds cb = class_bounds(g->num_nodes, cn_cap, K);
   const bool dm = allow_hash && stash_slot > 0 && dm_mode_for(g);
-  if (cb.b[kNumClasses - 1] < 0) {
-    // the N-bit bitmaps of the bitmap flavour do not fit: only the hash / one-hop classes exist
-    if (!(allow_hash && sparse_mode_for(g))) {
-      set_last_error("num_nodes " + std::to_string(g->num_nodes) +
-                     ": the LDS bitmaps alone exceed 160 KiB");
-      return S3GRL_ERR_GRAPH_TOO_LARGE;
-    }
-    for (int c = 0; c < kNumClasses; ++c) cb.b[c] = -1;   // every link "overflows" them
+  if (cb.b[kNumClasses - 1] < 0 || getenv("S3GRL_FORCE_EXT_BITMAPS")) {
+    // the N-bit bitmaps of the bitmap flavour do not fit LDS: apart from the hash / one-hop classes
+    // there is only the HBM-scratch class, with its bitmaps in the slice too
+    for (int c = 0; c < kNumClasses; ++c) cb.b[c] = -1;   // every link "overflows" the LDS classes
   }
   hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream,
                      n_nodes, p_nodes, lvl_max, L, cb, dm ? 2 : ((allow_hash && sparse_mode_for(g)) ? 1 : 0),
@@ -1919,6 +1961,9 @@ struct LinkArgs {
   int lo_id;                                // then: ids >= lo_id have at most two stored neighbours (else -1)
   int split_t, seg_shift;                   // lists longer than split_t are laid out in pieces of 2^seg_shift
   DirGraph dg;                              // arcs of a directed graph (null otherwise)
+  int bm_ext_words;                         // HBM-scratch class: words of the bitmaps at the head of a slice (0: LDS)
+  int gs_chunk;                             // ... and how many slices there are (the class runs in chunks)
+  int64_t list_offset;                      // first entry of the class list a launch works on
 };
 
 // One-hop full-reach classes (link_full_kernel).  Small classes run one wavefront per link (no
@@ -1957,6 +2002,8 @@ s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t 
   else if (HS)
     lds = (size_t)4 * link_fixed_words_sparse(a.cn_cap, K) +
           class_bounds_sparse(a.cn_cap, K).b[cls - kSparseBase];
+  else if (GS && a.bm_ext_words > 0)
+    lds = (size_t)4 * link_fixed_words_sparse(a.cn_cap, K);
   else
     lds = (size_t)4 * link_fixed_words(a.g->num_nodes, a.cn_cap, K) +
           (GS ? 0 : (size_t)class_bounds(a.g->num_nodes, a.cn_cap, K).b[cls]);
@@ -1964,14 +2011,14 @@ s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t 
   S3GRL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(T), lds, stream, a.g->indptr,
-                     a.g->indices, W, a.links, a.class_list + (int64_t)cls * L, a.hops, a.plus,
+                     a.g->indices, W, a.links, a.class_list + (int64_t)cls * L + a.list_offset, a.hops, a.plus,
                      a.cn_cap, a.full_stats, a.g->max_degree > kHubArmDegree ? 1 : 0, a.ws,
                      a.p_nodes, a.node_off, a.row_ptr, a.job_off, a.coef_off,
                      a.mirror_of, a.c_ids, a.c_coef, a.jobs, a.job_z, a.job_lim, a.row_nodes, a.lvl,
                      reinterpret_cast<unsigned long long*>(a.tot_edges),
                      reinterpret_cast<unsigned long long*>(a.tot_support),
                      reinterpret_cast<unsigned long long*>(a.tot_vol), a.scratch, a.scratch_stride,
-                     a.dbg, a.smp, a.stash, a.slot, a.old_of_new, a.new_of_old, a.lo_id, a.split_t, a.seg_shift,
+                     GS ? a.bm_ext_words : 0, a.dbg, a.smp, a.stash, a.slot, a.old_of_new, a.new_of_old, a.lo_id, a.split_t, a.seg_shift,
                      a.dg);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
@@ -2033,8 +2080,19 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
     return k == 0 ? ctx->stream : ctx->side[k - 1];
   };
   // largest subgraphs first: they are the long poles of the tail
-  if (class_count_host[kNumClasses] > 0)
-    S3GRL_TRY((launch_link_class<1024, K>(ctx, a, L, kNumClasses, class_count_host[kNumClasses], next_stream())));
+  if (class_count_host[kNumClasses] > 0) {
+    if (a.bm_ext_words > 0) {   // bounded number of slices: the class runs in chunks, one after the other
+      hipStream_t st = next_stream();
+      for (int off = 0; off < class_count_host[kNumClasses]; off += a.gs_chunk) {
+        LinkArgs b = a;
+        b.list_offset = off;
+        S3GRL_TRY((launch_link_class<1024, K>(ctx, b, L, kNumClasses,
+                                               std::min(a.gs_chunk, class_count_host[kNumClasses] - off), st)));
+      }
+    } else {
+      S3GRL_TRY((launch_link_class<1024, K>(ctx, a, L, kNumClasses, class_count_host[kNumClasses], next_stream())));
+    }
+  }
   if (class_count_host[kFullBig] > 0)
     S3GRL_TRY((launch_full_class<1024, K, true>(ctx, a, L, kFullBig, class_count_host[kFullBig], next_stream(),
                                                   a.bm_scratch, a.bm_stride_words, a.bm_grid)));
@@ -2140,10 +2198,20 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
   Transient scratch_owner{ctx, {}};
   char* scratch = nullptr;
   int64_t scratch_stride = 0;
+  int bm_ext_words = 0, gs_chunk = 0;
   if (class_count_host[kNumClasses] > 0) {
     scratch_stride = ((int64_t)class_count_host[kNumClasses + 1] + 255) / 256 * 256;
+    int64_t slices = class_count_host[kNumClasses];
+    if (4 * (int64_t)link_fixed_words(g->num_nodes, cn_cap, K) > 163840 || getenv("S3GRL_FORCE_EXT_BITMAPS")) {
+      // the graph's bitmaps do not fit LDS: they go to the head of every slice, and the class runs in
+      // chunks over at most 512 MiB of slices
+      bm_ext_words = (3 * words_for(g->num_nodes) + 63) / 64 * 64;
+      scratch_stride += (int64_t)bm_ext_words * 4;
+      gs_chunk = (int)std::min<int64_t>(slices, std::max<int64_t>(64, ((int64_t)1 << 29) / scratch_stride));
+      slices = gs_chunk;
+    }
     void* q = nullptr;
-    S3GRL_TRY(ctx->arena.alloc((size_t)scratch_stride * class_count_host[kNumClasses], &q));
+    S3GRL_TRY(ctx->arena.alloc((size_t)scratch_stride * slices, &q));
     scratch_owner.ptrs.push_back(q);
     scratch = static_cast<char*>(q);
   }
@@ -2154,7 +2222,7 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
              getenv("S3GRL_DEBUG_STAMPS") ? reinterpret_cast<unsigned long long*>(ctx->d_scalars + 16) : nullptr,
              smp, stash, slot, e_cap, nullptr, 0, 0, 0, old_of_new, new_of_old,
              (old_of_new && !getenv("S3GRL_NO_LEAF_WALK")) ? g->deg_le2_from : -1, split_t, seg_shift,
-             DirGraph{g->out_indptr, g->out_indices, g->in_indptr, g->in_indices}};
+             DirGraph{g->out_indptr, g->out_indices, g->in_indptr, g->in_indices}, bm_ext_words, gs_chunk, 0};
   // the class whose bit matrix does not fit LDS: one slice per resident workgroup of a persistent grid
   if (class_count_host[kFullBig] > 0) {
     // slice = list of found edges (uint32, at most ecap / 2) + CSR columns (uint16 x ecap) of the

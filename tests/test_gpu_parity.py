@@ -1111,6 +1111,77 @@ def test_split_jobs_on_the_one_hop_path(eng, monkeypatch):
     G_plain.close()
 
 
+@pytest.mark.parametrize("name,hops,mode", [("usair", 2, "pos_plus"), ("cora", 3, "pos"), ("rand300", 3, "pos_plus")])
+def test_bitmaps_in_hbm_change_nothing(eng, monkeypatch, name, hops, mode):
+    """Graphs of more than ~327 680 nodes do not fit their N-bit bitmaps into a CU's LDS: the sizing
+    pass and the link kernel of the HBM-scratch class then keep them in HBM slices, processed in
+    chunks.  S3GRL_FORCE_EXT_BITMAPS sends a small fixture down that road: node lists, distances,
+    row nodes and statistics equal exactly, rows to fp32 round-off (the walk follows the caller's id
+    order there), sampled plans included."""
+    import torch
+
+    g = load_extract(name)
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = np.random.default_rng(8).standard_normal((n, 13))
+    links = np.concatenate([g["links"], g["links"][:4, ::-1]])
+    G = eng.graph(A)
+    f = eng.features(X)
+    L = eng.links(links.T)
+    for kw in ({}, {"ratio_per_hop": 0.7, "max_nodes_per_hop": 30, "seed": 4}):
+        out = []
+        for ext in (False, True):
+            if ext:
+                monkeypatch.setenv("S3GRL_FORCE_EXT_BITMAPS", "1")
+            else:
+                monkeypatch.delenv("S3GRL_FORCE_EXT_BITMAPS", raising=False)
+            plan = eng.plan(G, L, mode=mode, num_hops=hops, sign_k=3, full_stats=True, **kw)
+            exp = [t.clone() for t in plan.export_subgraphs()]
+            st = dict(plan.stats)
+            st.pop("workspace_bytes", None)
+            rows = plan.run(f).clone()
+            out.append((exp, st, rows, plan.row_ptr().clone(), plan.row_nodes().clone()))
+            plan.close()
+        monkeypatch.delenv("S3GRL_FORCE_EXT_BITMAPS", raising=False)
+        (ea, sa, ra, pa, na), (eb, sb, rb, pb, nb) = out
+        assert all(torch.equal(x, y) for x, y in zip(ea, eb))
+        assert sa == sb and torch.equal(pa, pb) and torch.equal(na, nb)
+        assert rel_err(rb.cpu().numpy(), ra.cpu().numpy()) < 3e-6
+    G.close()
+
+
+@pytest.mark.parametrize("mode", ["pos", "pos_plus"])
+def test_half_million_nodes_two_hops_vs_c(eng, mode):
+    """A 500 000-node power-law graph, two hops: beyond the LDS bitmap limit.  The sizing pass keeps
+    its bitmaps in HBM; the links run on the hash flavour where their subgraph fits and on the
+    HBM-scratch class with external bitmaps where it does not (hub links of tens of thousands of
+    nodes) — against the C restatement."""
+    from oracle import c_oracle
+    from s3grl_amd import workloads
+
+    n, e = workloads.chung_lu(500000, 1400000, d_max=400, seed=21)
+    A = csr_from_undirected(n, e)
+    rng = np.random.default_rng(22)
+    X = (rng.random((n, 16)) * (rng.random((n, 16)) < 0.4)).astype(np.float32)
+    deg = np.diff(A.indptr)
+    pos = e[rng.choice(len(e), 120, replace=False)]
+    hub = e[np.argsort(-(deg[e[:, 0]] + deg[e[:, 1]]))[:12]]
+    neg = rng.integers(0, n, size=(120, 2))
+    neg = neg[neg[:, 0] != neg[:, 1]]
+    links = np.concatenate([pos, hub, neg, pos[:8, ::-1]]).T
+    G = eng.graph(A)
+    res = eng.precompute(G, eng.features(X), eng.links(links), mode=mode, num_hops=2, sign_k=3)
+    ref, ptr, nodes, _ = c_oracle.pos_rows(links, 2, A, X.astype(np.float64), 3, plus=(mode == "pos_plus"))
+    np.testing.assert_array_equal(res.row_ptr.cpu().numpy(), ptr)
+    np.testing.assert_array_equal(res.row_nodes.cpu().numpy(), nodes)
+    got = res.rows.cpu().numpy()
+    c32 = c_oracle.pos_rows(links, 2, A, X.astype(np.float64), 3, plus=(mode == "pos_plus"), f32=True)[0]
+    report_errors(f"half_million_nodes_two_hops[{mode}]", rel_err(got, ref), elem_rel_err(got, ref),
+                  (rel_err(c32, ref), _elem_floor(c32, ref)))
+    assert res.stats["max_nodes"] > 5000 and rel_err(got, ref) < 3e-6
+    G.close()
+
+
 # ------------------------------------------------------------------------------------------
 # per-hop sampling (reference utils.py:66-70: ratio_per_hop, max_nodes_per_hop)
 # ------------------------------------------------------------------------------------------
