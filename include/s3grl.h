@@ -259,6 +259,15 @@ s3grl_status s3grl_run_features(s3grl_context* ctx, const s3grl_plan* p, const s
  * Â = D^-1/2 A D^-1/2 of the whole graph and Y_i = Â^i X, i = 1..K. */
 s3grl_status s3grl_sop_create(s3grl_context* ctx, const s3grl_graph* g, const float* X,
                               int64_t ldx, int64_t num_features, int32_t sign_k, s3grl_sop** out);
+/* The same on a MULTIGRAPH: the reference builds its global operator from the uncoalesced edge_index
+ * (sgrl_link_pred.py:161-172: `SparseTensor(row, col)`, degree = entries per row), so a pair that
+ * occurs m times counts m times in the degree and weighs m in every product, while the CSR of A
+ * holds it once (scipy sums duplicates).  multiplicity: device fp32 [nnz], aligned with the graph's
+ * `indices` as handed to s3grl_graph_create (NULL = all 1 = s3grl_sop_create); copied.
+ * A_hat = D^-1/2 M D^-1/2 with D = row sums of M.  Every paper dataset is coalesced (m = 1). */
+s3grl_status s3grl_sop_create_weighted(s3grl_context* ctx, const s3grl_graph* g, const float* X,
+                                       int64_t ldx, int64_t num_features, int32_t sign_k,
+                                       const float* multiplicity, s3grl_sop** out);
 s3grl_status s3grl_sop_destroy(s3grl_sop* s);
 /* the global SIGN features themselves, out fp32 [K, N, F]: out[i-1] = Â^i X.  This is what the
  * reference's non-optimised twin `TunedSIGN.__call__` (tuned_SIGN.py:18-23, PyG SIGN(K)) computes

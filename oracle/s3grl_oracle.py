@@ -282,18 +282,25 @@ def get_PoS_Plus_prepped_ds(link_index, num_hops, A, x, y, sign_kwargs, *, dtype
 # --------------------------------------------------------------------------------------
 # SoP  (reference sgrl_link_pred.py:161-178 and tuned_SIGN.py:49-134)
 # --------------------------------------------------------------------------------------
-def global_normalized_powers(A, K, dtype=np.float32):
+def global_normalized_powers(A, K, dtype=np.float32, edge_index=None):
     """[Â, Â², …, Â^K] of the WHOLE train graph — reference sgrl_link_pred.py:161-178.
     Binary structure, deg = row count, inf -> 0, no self-loops added, target links NOT
-    removed."""
+    removed.  `edge_index` ([2, E], optional): the caller's UNCOALESCED edge list, which is what
+    the reference builds the operator from (`SparseTensor(row, col)`, :164-167) — an entry listed m
+    times counts m times in the degree and weighs m in every product; without it the structure of
+    A is taken (every entry once), which is the same thing for a coalesced graph."""
     A = ssp.csr_matrix(A)
     N = A.shape[0]
-    coo = A.tocoo()
-    u, v = coo.row, coo.col
+    if edge_index is None:
+        coo = A.tocoo()
+        u, v = coo.row, coo.col
+    else:
+        u, v = np.asarray(edge_index[0], dtype=np.int64), np.asarray(edge_index[1], dtype=np.int64)
     deg = np.bincount(u, minlength=N).astype(dtype)
     with np.errstate(divide="ignore"):
         dinv = np.power(deg, dtype(-0.5))
     dinv[np.isinf(dinv)] = 0
+    # (duplicate (u, v) pairs are summed by csr_matrix: the additive reading of an uncoalesced tensor)
     op = ssp.csr_matrix(((dinv[u] * dinv[v]).astype(dtype), (u, v)), shape=(N, N), dtype=dtype)
     out = [op]
     for _ in range(2, K + 1):

@@ -33,7 +33,7 @@ SYMBOLS = [
     "s3grl_graph_create", "s3grl_graph_create_directed", "s3grl_graph_destroy",
     "s3grl_plan_create", "s3grl_plan_create_sets", "s3grl_walk_sets", "s3grl_plan_destroy", "s3grl_plan_get_stats", "s3grl_plan_total_rows", "s3grl_plan_row_ptr",
     "s3grl_plan_row_nodes", "s3grl_plan_export_subgraphs", "s3grl_plan_link_cost", "s3grl_run",
-    "s3grl_sop_create", "s3grl_sop_destroy", "s3grl_sop_run", "s3grl_sop_features",
+    "s3grl_sop_create", "s3grl_sop_create_weighted", "s3grl_sop_destroy", "s3grl_sop_run", "s3grl_sop_features",
     "s3grl_features_create", "s3grl_features_destroy", "s3grl_features_info", "s3grl_run_features",
     "s3grl_centre_pool_forward", "s3grl_centre_pool_backward", "s3grl_calibration_read",
 ]
@@ -118,6 +118,7 @@ def lib():
         "s3grl_plan_link_cost": [vp, vp],
         "s3grl_run": [vp, vp, vp, i64, i64, vp],
         "s3grl_sop_create": [vp, vp, vp, i64, i64, i32, C.POINTER(vp)],
+        "s3grl_sop_create_weighted": [vp, vp, vp, i64, i64, i32, vp, C.POINTER(vp)],
         "s3grl_sop_destroy": [vp],
         "s3grl_sop_run": [vp, vp, vp, i64, vp],
         "s3grl_sop_features": [vp, vp, vp],

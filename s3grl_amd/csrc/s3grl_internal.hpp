@@ -259,6 +259,7 @@ struct s3grl_sop {
   int32_t K = 0;
   int64_t F = 0;
   int64_t ldy = 0;        // leading dimension of Y_i (even)
+  const float* mult = nullptr;  // [nnz] multiplicity of the stored entries (null: 1), see s3grl_sop_create_weighted
   double* dinv = nullptr; // [N] global D^-1/2
   double* Y = nullptr;    // [K+1, N, ldy] f64; Y[0] = X, Y[i] = Â Y[i-1]
   std::vector<void*> owned;

@@ -36,13 +36,21 @@ __global__ void to_f64_pad_kernel(const float* __restrict__ X, int64_t ldx, int6
   }
 }
 
-// deg = stored entries per row (reference sgrl_link_pred.py:170-172), deg^-1/2, inf -> 0
-__global__ void global_dinv_kernel(const int32_t* __restrict__ indptr, int64_t N,
-                                   double* __restrict__ dinv) {
+// deg = stored entries per row (reference sgrl_link_pred.py:170-172), deg^-1/2, inf -> 0.
+// `mult` (may be null): multiplicity of every stored entry — the reference builds its SparseTensor
+// from the UNCOALESCED edge_index (sgrl_link_pred.py:161-167), so a pair that appears m times counts
+// m times in the degree and carries m times the weight in every product; scipy's A holds such a
+// pair once (duplicates summed).
+__global__ void global_dinv_kernel(const int32_t* __restrict__ indptr, const float* __restrict__ mult,
+                                   int64_t N, double* __restrict__ dinv) {
   const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= N) return;
-  const int deg = indptr[v + 1] - indptr[v];
-  dinv[v] = deg > 0 ? 1.0 / sqrt((double)deg) : 0.0;
+  double deg = (double)(indptr[v + 1] - indptr[v]);
+  if (mult) {
+    deg = 0.0;
+    for (int e = indptr[v]; e < indptr[v + 1]; ++e) deg += (double)mult[e];
+  }
+  dinv[v] = deg > 0 ? 1.0 / sqrt(deg) : 0.0;
 }
 
 // Y_out[v,:] = dinv[v] · Σ_{u ∈ N(v)} dinv[u] · Y_in[u,:]      f64, neighbours in stored order.
@@ -55,7 +63,7 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void spmm_norm_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
     const double* __restrict__ dinv, const double* __restrict__ Yin, double* __restrict__ Yout,
-    int64_t N, int64_t ldy, int tiles) {
+    int64_t N, int64_t ldy, int tiles, const float* __restrict__ mult) {
   const int lane = threadIdx.x & 63;
   const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (w >= N * tiles) return;
@@ -74,7 +82,7 @@ __global__ __launch_bounds__(256) void spmm_norm_kernel(
     for (int k = 0; k < 4; ++k) u[k] = indices[min(e + k, e1 - 1)];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      du[k] = e + k < e1 ? dinv[u[k]] : 0.0;
+      du[k] = e + k < e1 ? dinv[u[k]] * (mult ? (double)mult[e + k] : 1.0) : 0.0;
       const double* __restrict__ yr = Yin + (int64_t)u[k] * ldy;
       ya[k] = *reinterpret_cast<const double2_t*>(yr + la);
       yb[k] = *reinterpret_cast<const double2_t*>(yr + lb);
@@ -106,7 +114,7 @@ __global__ __launch_bounds__(T) void sop_scalar_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int W,
     const double* __restrict__ gdinv, const int64_t* __restrict__ links,
     const int32_t* __restrict__ class_list, const int64_t* __restrict__ node_off, int K, int HB, int RB,
-    int hubs, double* __restrict__ scal /* [L][K][3] = sd, ss, dd */) {
+    int hubs, double* __restrict__ scal /* [L][K][3] = sd, ss, dd */, const float* __restrict__ mult) {
   extern __shared__ uint32_t smem[];
   const int tid = threadIdx.x;
   const int l = class_list[blockIdx.x];
@@ -155,12 +163,13 @@ __global__ __launch_bounds__(T) void sop_scalar_kernel(
         double sx = 0.0, sy = 0.0;
         for (int c = indptr[v] + g; c < e1; c += G) {
           const int u = indices[c];
+          const double m = mult ? (double)mult[c] : 1.0;
           if (j == 1) {
-            if (u == src) sx += gdinv[u];
-            if (u == dst) sy += gdinv[u];
+            if (u == src) sx += gdinv[u] * m;
+            if (u == dst) sy += gdinv[u] * m;
           } else if (test_bit(vis, u)) {
             const double2 rv = in[rank_of(vis, wpre, u)];
-            const double du = gdinv[u];
+            const double du = gdinv[u] * m;
             sx += du * rv.x;
             sy += du * rv.y;
           }
@@ -374,6 +383,11 @@ s3grl_status s3grl_sop_destroy(s3grl_sop* s) {
 
 s3grl_status s3grl_sop_create(s3grl_context* ctx, const s3grl_graph* g, const float* X, int64_t ldx,
                               int64_t F, int32_t K, s3grl_sop** out) {
+  return s3grl_sop_create_weighted(ctx, g, X, ldx, F, K, nullptr, out);
+}
+
+s3grl_status s3grl_sop_create_weighted(s3grl_context* ctx, const s3grl_graph* g, const float* X, int64_t ldx,
+                                       int64_t F, int32_t K, const float* multiplicity, s3grl_sop** out) {
   if (!ctx || !g || !out) return S3GRL_ERR_INVALID_ARGUMENT;
   if (!X) {
     set_last_error("node features are None");
@@ -400,6 +414,12 @@ s3grl_status s3grl_sop_create(s3grl_context* ctx, const s3grl_graph* g, const fl
   s->ldy = (F + 1) / 2 * 2;
   const int64_t N = g->num_nodes;
   void* p = nullptr;
+  if (multiplicity && g->nnz > 0) {   // copied: the caller may free its array
+    S3GRL_TRY(ctx->arena.alloc((size_t)g->nnz * 4, &p));
+    s->owned.push_back(p);
+    S3GRL_HIP_TRY(hipMemcpyAsync(p, multiplicity, (size_t)g->nnz * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    s->mult = static_cast<float*>(p);
+  }
   S3GRL_TRY(ctx->arena.alloc((size_t)N * 8, &p));
   s->owned.push_back(p);
   s->dinv = static_cast<double*>(p);
@@ -408,7 +428,7 @@ s3grl_status s3grl_sop_create(s3grl_context* ctx, const s3grl_graph* g, const fl
   s->Y = static_cast<double*>(p);
   if (ctx->profiling) S3GRL_HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
   hipLaunchKernelGGL(global_dinv_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream,
-                     g->indptr, N, s->dinv);
+                     g->indptr, s->mult, N, s->dinv);
   const int64_t total = N * s->ldy;
   hipLaunchKernelGGL(to_f64_pad_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 8192)),
                      dim3(256), 0, ctx->stream, X, ldx, N, F, s->Y, s->ldy);
@@ -417,7 +437,7 @@ s3grl_status s3grl_sop_create(s3grl_context* ctx, const s3grl_graph* g, const fl
   for (int i = 1; i <= K; ++i)
     hipLaunchKernelGGL(spmm_norm_kernel, dim3((unsigned)((N * spmm_tiles + 3) / 4)), dim3(256), 0, ctx->stream,
                        g->indptr, g->indices, s->dinv, s->Y + (int64_t)(i - 1) * N * s->ldy,
-                       s->Y + (int64_t)i * N * s->ldy, N, s->ldy, spmm_tiles);
+                       s->Y + (int64_t)i * N * s->ldy, N, s->ldy, spmm_tiles, s->mult);
   S3GRL_HIP_TRY(hipGetLastError());
   if (ctx->profiling) {
     S3GRL_HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
@@ -567,7 +587,7 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
     hipLaunchKernelGGL(kern, dim3((unsigned)cc[c]), dim3(TT), lds, ctx->stream, g->indptr,         \
                        g->indices, W, s->dinv, links, class_list + (int64_t)c * L, node_off, K,    \
-                       HB, RB, g->max_degree > kHubArmDegree ? 1 : 0, scal);                                                                  \
+                       HB, RB, g->max_degree > kHubArmDegree ? 1 : 0, scal, s->mult);                 \
   } while (0)
     if (c == 0 && RB <= 1) {   // a ball of a dozen nodes: one wavefront per link, no cross-wave barriers
       if (sparse) S3GRL_SOP_LAUNCH(64, 4); else S3GRL_SOP_LAUNCH(64, 8);

@@ -214,15 +214,25 @@ class Sop:
     """SoP global state: Â = D^-1/2 A D^-1/2 of the whole graph and Y_i = Â^i X
     (reference sgrl_link_pred.py:161-178 + tuned_SIGN.py:92-100 in closed form)."""
 
-    def __init__(self, engine, graph, x, sign_k):
+    def __init__(self, engine, graph, x, sign_k, multiplicity=None):
+        """multiplicity (optional, fp32 [nnz] aligned with the graph's CSR entries): how often every
+        stored pair occurs in the caller's uncoalesced edge_index — the reference's SoP operator counts
+        and weighs duplicates (sgrl_link_pred.py:161-172); None = a coalesced graph."""
         if isinstance(x, Features):
             x = x.tensor
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
         self.engine, self.graph, self.sign_k = engine, graph, int(sign_k)
         self.F = int(x.shape[1])
         h = C.c_void_p()
-        N.check(N.lib().s3grl_sop_create(engine._ctx, graph._h, _ptr(x), x.stride(0), self.F,
-                                         self.sign_k, C.byref(h)), "s3grl_sop_create")
+        if multiplicity is None:
+            N.check(N.lib().s3grl_sop_create(engine._ctx, graph._h, _ptr(x), x.stride(0), self.F,
+                                             self.sign_k, C.byref(h)), "s3grl_sop_create")
+        else:
+            m = torch.as_tensor(multiplicity).to(device=engine.device, dtype=torch.float32).contiguous()
+            if m.numel() != graph.nnz:
+                raise ValueError("multiplicity must have one entry per stored entry of A")
+            N.check(N.lib().s3grl_sop_create_weighted(engine._ctx, graph._h, _ptr(x), x.stride(0), self.F,
+                                                      self.sign_k, _ptr(m), C.byref(h)), "s3grl_sop_create_weighted")
         self._h = h
         engine._children.add(self)
 
@@ -423,7 +433,7 @@ class Engine:
 
     def precompute(self, graph, x, links, *, mode="pos", num_hops=1, sign_k=3,
                    strategy="intersection", directed=False, out=None, rw=None, ratio_per_hop=1.0,
-                   max_nodes_per_hop=None, seed=0, node_sets=None):
+                   max_nodes_per_hop=None, seed=0, node_sets=None, multiplicity=None):
         """links: int64 [L,2] device tensor (see `links()`); x: fp32 [N,F] device tensor."""
         if x is None:
             N.check(N.ERR_NO_FEATURES, "precompute")
@@ -434,11 +444,11 @@ class Engine:
                                   seed=seed, node_sets=node_sets)
             if sign_k == 1:
                 return pos
-            sop = self.precompute(graph, x, links, mode="sop", sign_k=sign_k)
+            sop = self.precompute(graph, x, links, mode="sop", sign_k=sign_k, multiplicity=multiplicity)
             rows = torch.cat([pos.rows, sop.rows[:, 2:, :]], dim=1)
             return Precomputed(rows, pos.row_ptr, pos.row_nodes, dict(pos.stats))
         if mode == "sop":
-            sop = Sop(self, graph, x, sign_k)
+            sop = Sop(self, graph, x, sign_k, multiplicity)
             try:
                 rows = sop.run(links, out)
             finally:

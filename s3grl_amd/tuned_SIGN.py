@@ -396,6 +396,26 @@ def _sampling_of(ratio_per_hop, max_nodes_per_hop):
             "max_nodes_per_hop": max_nodes_per_hop, "seed": SAMPLING_SEED}
 
 
+def _multiplicity_of(A):
+    """The reference's SoP operator is built from the UNCOALESCED edge_index: a pair that occurs m times
+    counts m times (sgrl_link_pred.py:161-172).  `A` is what the caller made of the same edge_index
+    with int ones as weights (sgrl_link_pred.py:107-114), so an integer A.data > 1 IS that multiplicity
+    (scipy sums duplicates).  A float-weighted A (a dataset with edge_weight) says nothing about
+    duplicates: treated as coalesced."""
+    import numpy as np
+
+    data = getattr(A, "data", None)
+    if data is None or not len(data) or data.dtype.kind not in "iu" or int(data.max()) <= 1:
+        return None
+    import scipy.sparse as ssp
+
+    C_ = ssp.csr_matrix(A)
+    if not C_.has_canonical_format:
+        C_ = C_.copy()
+        C_.sum_duplicates()
+    return np.asarray(C_.data, dtype=np.float32)
+
+
 class OptimizedSignOperations:
     @staticmethod
     def get_SoP_prepped_ds(powers_of_A, link_index, A, x, y):
@@ -407,7 +427,7 @@ class OptimizedSignOperations:
         if K < 1:
             raise ValueError("powers_of_A is empty")
         eng, g, xd = _device_inputs(A, x)
-        res = eng.precompute(g, xd, eng.links(link_index), mode="sop", sign_k=K)
+        res = eng.precompute(g, xd, eng.links(link_index), mode="sop", sign_k=K, multiplicity=_multiplicity_of(A))
         return _as_data_list(res, K, y, fixed_rows=2)
 
     @staticmethod

@@ -168,8 +168,10 @@ def test_onehop_path_vs_oracle_with_self_loops_and_hubs(eng, monkeypatch, mode, 
 
 
 def test_onehop_plans_have_no_node_limit(eng):
-    """A graph beyond the LDS-bitmap limit of the multi-hop paths (327 680 nodes): one-hop PoS /
-    PoS Plus run (the setting the reference uses on its large graphs), multi-hop plans refuse."""
+    """A graph beyond the LDS-bitmap limit (327 680 nodes): one-hop PoS / PoS Plus run on the
+    row-intersection path (the setting the reference uses on its large graphs); multi-hop plans run
+    too, with their bitmaps in HBM (tests/test_gpu_parity.py::test_half_million_nodes_two_hops_vs_c
+    checks their rows); a hub-hub link beyond the on-chip one-hop classes takes that road as well."""
     from s3grl_amd import workloads
 
     n, e = workloads.chung_lu(400000, 1200000, seed=21)
@@ -195,6 +197,16 @@ def test_onehop_plans_have_no_node_limit(eng):
         take = np.concatenate([np.arange(ptr[l], ptr[l + 1]) for l in sel])
         assert np.array_equal(np.diff(ptr)[sel], np.diff(ref_ptr))
         assert rel_err(res.rows.cpu().numpy()[take], ref) < TOL
-    with pytest.raises(Exception, match="(?i)too large|bitmap"):
-        eng.plan(G, eng.links(links), mode="pos", num_hops=2, sign_k=3)
+    # a link between the two biggest hubs (~5 000 nodes) does not fit the on-chip one-hop classes: it
+    # falls back to the general path, whose bitmaps live in HBM on a graph of this size
+    from oracle import c_oracle
+
+    big = np.array([[hubs[0], hubs[1]], [int(pos[2, 0]), int(pos[2, 1])]]).T
+    res = eng.precompute(G, eng.features(X), eng.links(big), mode="pos_plus", num_hops=1, sign_k=3)
+    ref, ptr, nodes, _ = c_oracle.pos_rows(big, 1, A, X, 3, plus=True)
+    assert np.array_equal(res.row_ptr.cpu().numpy(), ptr) and np.array_equal(res.row_nodes.cpu().numpy(), nodes)
+    assert rel_err(res.rows.cpu().numpy(), ref) < TOL
+    p2 = eng.plan(G, eng.links(links[:, :40]), mode="pos", num_hops=2, sign_k=3)     # multi-hop: no refusal
+    assert p2.stats["max_nodes"] > 2
+    p2.close()
     G.close()

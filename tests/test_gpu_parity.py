@@ -239,9 +239,13 @@ def test_dropin_operator_api(eng):
         assert d.y == 1 and d.x.shape == r["x"].shape and d["x2"].shape == r["x2"].shape
         for k in ("x", "x1", "x2"):
             assert rel_err(d[k].numpy(), r[k]) < TOL
-    with pytest.raises(NotImplementedError):
-        OptimizedSignOperations.get_PoS_prepped_ds(link_index, 1, A, 1.0, None, True, A.tocsc(), X, 1, kw,
-                                                   None)
+    # directed=True with A_csc on a symmetric A (arcs both ways): the same operator as the undirected call
+    und = OptimizedSignOperations.get_PoS_prepped_ds(link_index, 1, A, 1.0, None, False, None, X, 1, kw, None)
+    dirl = OptimizedSignOperations.get_PoS_prepped_ds(link_index, 1, A, 1.0, None, True, A.tocsc(), X, 1, kw,
+                                                      None)
+    for a, b in zip(und, dirl):
+        for k in ("x", "x1", "x2"):
+            assert rel_err(b[k].numpy(), a[k].numpy()) < 3e-6
     with pytest.raises(AssertionError):
         OptimizedSignOperations.get_PoS_prepped_ds(link_index, 1, A, 1.0, None, False, None, None, 1,
                                                    kw, None)
@@ -624,8 +628,8 @@ def test_corner_cases_vs_oracle(eng, mode, hops, K):
 def test_wrapper_rejects_what_the_engine_cannot_mirror(eng):
     import scipy.sparse as ssp
 
-    A = ssp.csr_matrix(np.array([[0, 1, 0], [0, 0, 1], [0, 0, 0]]))     # not symmetric
-    with pytest.raises(NotImplementedError):
+    A = ssp.csr_matrix(np.array([[0, 1, 0], [0, 0, 1], [0, 0, 0]]))     # not symmetric: needs directed=True
+    with pytest.raises(ValueError, match="directed"):
         eng.graph(A)
     B = csr_from_undirected(3, [[0, 1], [1, 2]]).astype(np.float64)
     B.data[0] = 0.0                                                      # stored zero
@@ -1109,6 +1113,40 @@ def test_split_jobs_on_the_one_hop_path(eng, monkeypatch):
     assert rel_err(split.rows.cpu().numpy(), whole.rows.cpu().numpy()) < 2e-6
     G.close()
     G_plain.close()
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 4])
+def test_sop_on_a_multigraph(eng, K):
+    """SoP's global operator counts duplicate entries of the caller's edge_index (the reference builds
+    it from the uncoalesced SparseTensor, sgrl_link_pred.py:161-172).  A carries the multiplicity as
+    its integer data (duplicates summed by scipy, sgrl_link_pred.py:107-114): the drop-in operator
+    reads it from there; against the oracle's operator built from the edge list itself."""
+    import scipy.sparse as ssp
+    import torch
+    from s3grl_amd.tuned_SIGN import OptimizedSignOperations as ops, clear_cache
+
+    g = load_extract("usair")
+    n = int(g["num_nodes"])
+    e = g["edges"].astype(np.int64)
+    rng = np.random.default_rng(K)
+    extra = e[rng.choice(len(e), 300, replace=True)]            # some pairs twice, some three times
+    both = np.concatenate([e, extra])
+    ei = np.concatenate([both, both[:, ::-1]]).T
+    A = ssp.csr_matrix((np.ones(ei.shape[1], dtype=np.int64), (ei[0], ei[1])), shape=(n, n))
+    assert A.data.max() >= 2
+    X = rng.standard_normal((n, 7)).astype(np.float32)
+    links = g["links"].T
+    lst = ops.get_SoP_prepped_ds([None] * K, torch.from_numpy(links), A, torch.from_numpy(X), 1)
+    P = oracle.global_normalized_powers(A, K, np.float64, edge_index=ei)
+    ref = oracle.get_SoP_prepped_ds(P, links, A, X.astype(np.float64), 1, dtype=np.float64)
+    for i in range(links.shape[1]):
+        for k in ["x"] + [f"x{j}" for j in range(1, K + 1)]:
+            assert rel_err(lst[i][k].numpy(), ref[i][k]) < TOL
+    # the multiplicity matters: the coalesced operator gives other numbers
+    plain = oracle.get_SoP_prepped_ds(oracle.global_normalized_powers(A, K, np.float64), links, A,
+                                      X.astype(np.float64), 1, dtype=np.float64)
+    assert max(rel_err(lst[i]["x1"].numpy(), plain[i]["x1"]) for i in range(links.shape[1])) > 1e-3
+    clear_cache()
 
 
 @pytest.mark.parametrize("name,hops,mode", [("usair", 2, "pos_plus"), ("cora", 3, "pos"), ("rand300", 3, "pos_plus")])

@@ -131,3 +131,21 @@ def test_directed_operator_hand_derived():
     np.testing.assert_allclose(d2["x1"][0], (np.array([0, 3.0, 0]) + np.array([0, 0, 5.0])) / np.sqrt(2))
     # row 1 of A_hat: 1 -> 3, D^-1/2: d_1 = 1, d_3 = 1
     np.testing.assert_allclose(d2["x1"][1], [0, 0, 5.0])
+
+
+def test_sop_operator_counts_duplicate_edges():
+    """Multigraph, hand-derived: the pair 0-1 listed twice, 1-2 once (both directions each).  The
+    reference's SparseTensor(row, col) keeps the duplicates (sgrl_link_pred.py:161-172): degrees
+    (2, 3, 1), A_hat[0,1] = 2 / sqrt(2*3), A_hat[1,2] = 1 / sqrt(3*1); on the coalesced structure
+    the degrees would be (1, 2, 1)."""
+    import scipy.sparse as ssp
+
+    ei = np.array([[0, 1, 0, 1, 1, 2], [1, 0, 1, 0, 2, 1]])
+    A = ssp.csr_matrix((np.ones(6, dtype=np.int64), (ei[0], ei[1])), shape=(3, 3))
+    assert A[0, 1] == 2
+    P = oracle.global_normalized_powers(A, 2, np.float64, edge_index=ei)
+    np.testing.assert_allclose(P[0].toarray(), [[0, 2 / np.sqrt(6), 0], [2 / np.sqrt(6), 0, 1 / np.sqrt(3)],
+                                                [0, 1 / np.sqrt(3), 0]])
+    np.testing.assert_allclose(P[1].toarray()[0], [4 / 6, 0, 2 / np.sqrt(18)])
+    Q = oracle.global_normalized_powers(A, 1, np.float64)
+    np.testing.assert_allclose(Q[0].toarray()[0, 1], 1 / np.sqrt(2))
