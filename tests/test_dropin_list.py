@@ -165,7 +165,7 @@ def test_upload_cache_detects_new_and_mutated_inputs(monkeypatch):
             self.closed = True
 
     class FakeEngine:
-        def graph(self, A):
+        def graph(self, A, directed=False, A_csc=None):
             return Handle("g")
 
         def features(self, x):
