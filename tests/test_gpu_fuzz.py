@@ -80,6 +80,11 @@ def test_random_configuration(eng, monkeypatch, case):
         monkeypatch.setenv("S3GRL_NO_RELABEL", "1")                    # the caller's node order instead of the degree order
     if case % 6 == 4:
         monkeypatch.setenv("S3GRL_NO_DM", "1")                         # bitmap flavour instead of the direct map
+    if case % 5 == 0:
+        monkeypatch.setenv("S3GRL_SPLIT_T", "64")                      # most jobs gathered in pieces of 32
+        monkeypatch.setenv("S3GRL_SPLIT_SEG_SHIFT", "5")
+    if case % 9 == 5:
+        monkeypatch.setenv("S3GRL_FORCE_EXT_BITMAPS", "1")             # bitmaps in HBM slices (graphs beyond the LDS limit)
     G = eng.graph(A)
     f = eng.features(X, ["auto", "dense", "packed"][case % 3])
     res = eng.precompute(G, f, eng.links(links.T), mode="pos_plus" if plus else "pos", num_hops=hops, sign_k=K)
@@ -89,6 +94,55 @@ def test_random_configuration(eng, monkeypatch, case):
     err = rel_err(res.rows.cpu().numpy(), ref)
     assert err < TOL, (case, kind, n, hops, K, plus, F, density, err)
     f.close()
+    G.close()
+
+
+@pytest.mark.parametrize("case", list(range(int(os.environ.get("S3GRL_FUZZ_CASES", "18")))))
+def test_random_directed_configuration(eng, monkeypatch, case):
+    """The same sweep on DIRECTED graphs (every undirected edge keeps one direction, some both),
+    against the reference-structured Python restatement with directed=True / A_csc: hops, sign_k,
+    PoS / PoS Plus, per-hop sampling, reversed duplicates, split jobs, HBM-scratch class."""
+    import scipy.sparse as ssp
+
+    import oracle
+
+    rng = np.random.default_rng(9000 + case)
+    kind = ["uniform", "powerlaw", "isolated"][case % 3]
+    n, edges = _graph(rng, kind, int(rng.choice([30, 150, 600])))
+    flip = rng.random(len(edges)) < 0.5
+    arcs = np.where(flip[:, None], edges[:, ::-1], edges)
+    both = edges[rng.random(len(edges)) < 0.3]
+    arcs = np.unique(np.vstack([arcs, both, both[:, ::-1]]), axis=0)
+    A = ssp.csr_matrix((np.ones(len(arcs), dtype=np.int64), (arcs[:, 0], arcs[:, 1])), shape=(n, n))
+    A_csc = A.tocsc()
+    hops = int(rng.integers(1, 4))
+    K = int(rng.integers(1, 5))
+    plus = bool(rng.integers(0, 2))
+    F = int(rng.choice([3, 20, 70]))
+    X = (rng.standard_normal((n, F)) * (rng.random((n, F)) < float(rng.choice([1.0, 0.3])))).astype(np.float32)
+    pos = arcs[rng.choice(len(arcs), min(15, len(arcs)), replace=False)]
+    neg = rng.integers(0, n, size=(25, 2))
+    neg = neg[neg[:, 0] != neg[:, 1]]
+    links = np.concatenate([pos, neg, pos[:4, ::-1]])
+    smp = {}
+    if case % 3 == 1:
+        smp = {"ratio_per_hop": 0.6, "max_nodes_per_hop": 12, "seed": case}
+    if case % 4 == 2:
+        monkeypatch.setenv("S3GRL_LDS_BUDGET", "2048")
+    if case % 5 == 3:
+        monkeypatch.setenv("S3GRL_SPLIT_T", "32")
+        monkeypatch.setenv("S3GRL_SPLIT_SEG_SHIFT", "4")
+    G = eng.graph(A, directed=True, A_csc=A_csc)
+    res = eng.precompute(G, eng.features(X), eng.links(links.T), mode="pos_plus" if plus else "pos", num_hops=hops,
+                         sign_k=K, **smp)
+    kw = {"sign_k": K, "k_node_set_strategy": "intersection"}
+    fn = oracle.get_PoS_Plus_prepped_ds if plus else oracle.get_PoS_prepped_ds
+    okw = {} if not smp else {"ratio_per_hop": 0.6, "max_nodes_per_hop": 12, "sample_seed": case}
+    ref, ptr, _ = oracle.collate_rows(fn(links.T, hops, A, X.astype(np.float64), 1, kw, dtype=np.float64,
+                                         directed=True, A_csc=A_csc, **okw), K)
+    np.testing.assert_array_equal(res.row_ptr.cpu().numpy(), ptr)
+    err = rel_err(res.rows.cpu().numpy(), ref)
+    assert err < TOL, (case, kind, n, hops, K, plus, F, err)
     G.close()
 
 
