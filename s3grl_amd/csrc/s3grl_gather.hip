@@ -13,6 +13,8 @@
 // 2K·4·CH fp32 accumulators in VGPRs; every X row of the support is fetched ONCE per pair with
 // 16-byte loads (64 lanes × 16 B = one 1 KiB wave-instruction per 256 columns), UNROLL rows
 // in flight per wave.  No LDS, no MFMA: 2·2K flop per 4 B of X.
+#include <cstdlib>
+
 #include "s3grl_internal.hpp"
 #include "s3grl_gather_common.hpp"
 
@@ -98,12 +100,93 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_kernel(
   write_pair_rows<K, CH>(job, jid, acc, coff, cok, job_z, X, ldx, F, rows, blockIdx.y == 0);
 }
 
+// F <= 128 (node2vec / ogbl-style features): a row of X is at most 512 bytes, i.e. 32 lanes x 16 B —
+// with one row per wave-load half of the wavefront would idle in every load and every multiply-add
+// (the collab-scale config: 128 features).  Here the two halves of the wavefront take ALTERNATE list
+// entries (even entries lanes 0..31, odd entries lanes 32..63): one load instruction fetches two rows,
+// ids and coefficients still arrive through the scalar cache and are picked per half with one
+// v_cndmask each.  The halves' partial sums are added at the end (lane l + lane l+32): a fixed order.
+template <int K>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void gather_half_kernel(
+    const Job* __restrict__ jobs, int njobs, const int32_t* __restrict__ c_ids,
+    const float* __restrict__ c_coef, const float* __restrict__ job_z, const float* __restrict__ X,
+    int64_t ldx, int F, float* __restrict__ rows) {
+  constexpr int U = 8;   // pairs of list entries per trip: 16 rows of X in flight per wavefront
+  const int lane = threadIdx.x & 63;
+  const bool odd = lane >= 32;
+  const int jid = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+  if (jid >= njobs) return;
+  const Job job = jobs[jid];
+  if (job.split) return;   // gathered piece by piece (s3grl_plan::gjobs)
+  const int cnt = __builtin_amdgcn_readfirstlane(job.support);
+  const int32_t* __restrict__ ids = c_ids + job.ids_off;
+  const float2* __restrict__ cf = reinterpret_cast<const float2*>(c_coef) + job.coef_off;
+  int coff[1] = {(lane & 31) * 4};
+  const bool col_ok = coff[0] < F;
+  float4_t acc[K][2][1];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    acc[i][0][0] = (float4_t)(0.f);
+    acc[i][1][0] = (float4_t)(0.f);
+  }
+  int j = 0;
+  for (; j + 2 * U <= cnt; j += 2 * U) {
+    int id[U];
+    float4_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int a = ids[j + 2 * u], b = ids[j + 2 * u + 1];   // scalar loads
+      id[u] = odd ? b : a;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      v[u] = col_ok ? *reinterpret_cast<const float4_t*>(X + (int64_t)id[u] * ldx + coff[0]) : (float4_t)(0.f);
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float2 qa = cf[(int64_t)i * cnt + j + 2 * u], qb = cf[(int64_t)i * cnt + j + 2 * u + 1];
+        const float qx = odd ? qb.x : qa.x, qy = odd ? qb.y : qa.y;
+        acc[i][0][0] += qx * v[u];
+        acc[i][1][0] += qy * v[u];
+      }
+    }
+  }
+  for (; j < cnt; j += 2) {   // at most 2U - 1 entries; the odd half may run past the end
+    const bool has_b = j + 1 < cnt;
+    const int a = ids[j], b = ids[has_b ? j + 1 : j];
+    const int id = odd ? b : a;
+    const bool live = col_ok && (!odd || has_b);
+    const float4_t v = live ? *reinterpret_cast<const float4_t*>(X + (int64_t)id * ldx + coff[0]) : (float4_t)(0.f);
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const float2 qa = cf[(int64_t)i * cnt + j], qb = cf[(int64_t)i * cnt + (has_b ? j + 1 : j)];
+      const float qx = odd ? qb.x : qa.x, qy = odd ? qb.y : qa.y;
+      acc[i][0][0] += qx * v;
+      acc[i][1][0] += qy * v;
+    }
+  }
+  // even + odd entries; afterwards both halves hold the sums, the lower half writes them
+#pragma unroll
+  for (int i = 0; i < K; ++i)
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][r][0][e] += __shfl_xor(acc[i][r][0][e], 32);
+  const bool cok[1] = {col_ok && !odd};
+  write_pair_rows<K, 1>(job, jid, acc, coff, cok, job_z, X, ldx, F, rows, true);
+}
+
 template <int K>
 s3grl_status launch_k(s3grl_context* ctx, const Job* jobs, int64_t njobs, const int32_t* c_ids,
                       const float* c_coef, const float* job_z, const float* X, int64_t ldx,
                       int64_t F, float* rows, hipStream_t stream) {
   const unsigned gx = (unsigned)((njobs + kWavesPerBlock - 1) / kWavesPerBlock);
-  if (F <= 256) {
+  static const bool no_half = getenv("S3GRL_GATHER_NO_HALF") != nullptr;   // comparison hook
+  if (F <= 128 && !no_half) {
+    hipLaunchKernelGGL((gather_half_kernel<K>), dim3(gx, 1), dim3(kWavesPerBlock * 64), 0, stream,
+                       jobs, (int)njobs, c_ids, c_coef, job_z, X, ldx, (int)F, rows);
+  } else if (F <= 256) {
     hipLaunchKernelGGL((gather_kernel<K, 1>), dim3(gx, 1), dim3(kWavesPerBlock * 64), 0, stream,
                        jobs, (int)njobs, c_ids, c_coef, job_z, X, ldx, (int)F, rows);
   } else {
