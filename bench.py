@@ -661,7 +661,8 @@ def main():
             kname = "gather_packed_kernel" if x.is_packed else ("gather_half_kernel" if F <= 128 else "gather_kernel")
             traffic, traffic_source, l2_hit = None, None, None
             if args.collect_pmc and world == 1:
-                rec = collect_pmc(args, kname)
+                # (the child runs ONE step: the sum over the family's dispatches is the launch of a step)
+                rec = collect_pmc(args, kname, per_step=True)
                 if rec:
                     traffic, l2_hit = rec["hbm_bytes_per_launch"], rec.get("l2_hit_rate")
                     traffic_source = "collected by this run: child rocprofv3 --pmc passes of the same command"

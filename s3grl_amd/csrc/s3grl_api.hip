@@ -817,14 +817,17 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
     if (split_t > 0 && hs[21] > 0) {
       const int64_t np = hs[21];
       plan->npieces = np;
-      S3GRL_TRY(arena_alloc(ctx, (size_t)np, &plan->gjobs, own));
-      S3GRL_TRY(arena_alloc(ctx, (size_t)np * K * 2, &plan->g_z, own));
-      S3GRL_TRY(arena_alloc(ctx, (size_t)np * K, &plan->g_lim, own));
-      S3GRL_TRY(arena_alloc(ctx, (size_t)np, &plan->g_order, own));
+      const size_t units = (size_t)(njobs + np);   // the jobs, then their pieces: one array of gather units
+      S3GRL_TRY(arena_alloc(ctx, units, &plan->gjobs, own));
+      S3GRL_TRY(arena_alloc(ctx, units * K * 2, &plan->g_z, own));
+      S3GRL_TRY(arena_alloc(ctx, units * K, &plan->g_lim, own));
+      S3GRL_TRY(arena_alloc(ctx, units, &plan->g_order, own));
       S3GRL_TRY(arena_alloc(ctx, (size_t)np, &plan->piece_job, own));
-      S3GRL_HIP_TRY(hipMemsetAsync(plan->g_z, 0, (size_t)np * K * 2 * sizeof(float), ctx->stream));
-      S3GRL_TRY(launch_split_fill(ctx, plan->jobs, plan->job_lim, njobs, K, seg_shift, plan->piece_off, plan->gjobs,
-                                  plan->g_lim, plan->g_order, plan->piece_job));
+      S3GRL_HIP_TRY(hipMemcpyAsync(plan->g_z, plan->job_z, (size_t)njobs * K * 2 * sizeof(float),
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+      S3GRL_HIP_TRY(hipMemsetAsync(plan->g_z + (size_t)njobs * K * 2, 0, (size_t)np * K * 2 * sizeof(float), ctx->stream));
+      S3GRL_TRY(launch_split_fill(ctx, plan->jobs, plan->job_lim, njobs, plan->job_order, K, seg_shift,
+                                  plan->piece_off, np, plan->gjobs, plan->g_lim, plan->g_order, plan->piece_job));
     }
     if (getenv("S3GRL_DEBUG_STAMPS")) {   // diagnostic build aid: cycles per link_kernel phase
       S3GRL_HIP_TRY(hipMemcpy(hs + 16, ds + 16, 8 * 8, hipMemcpyDeviceToHost));
@@ -938,34 +941,22 @@ static s3grl_status run_with(s3grl_context* ctx, const s3grl_plan* p, const s3gr
   }
   if (ctx->profiling) S3GRL_TRY(resolve_pending_gather(ctx));
   S3GRL_TRY(record(ctx, 3));
-  auto gather = [&](const GatherView& v, float* out, hipStream_t stream) -> s3grl_status {
-    if (f->sparse) return launch_gather_sparse(ctx, p, v, f, out, stream);
-    if (f->packed) return launch_gather_packed(ctx, p, v, f, out, stream);
-    return launch_gather(ctx, v, p->c_ids, p->c_coef, p->cfg.sign_k, f->dense, f->ld, f->F, out, stream);
+  auto gather = [&](const GatherView& v) -> s3grl_status {
+    if (f->sparse) return launch_gather_sparse(ctx, p, v, f, rows);
+    if (f->packed) return launch_gather_packed(ctx, p, v, f, rows);
+    return launch_gather(ctx, v, p->c_ids, p->c_coef, p->cfg.sign_k, f->dense, f->ld, f->F, rows);
   };
-  const GatherView whole{p->jobs, p->njobs, p->job_z, p->job_lim, p->job_order};
   if (p->npieces == 0) {
-    S3GRL_TRY(gather(whole, rows, ctx->stream));
+    S3GRL_TRY(gather(GatherView{p->jobs, p->njobs, p->job_z, p->job_lim, p->job_order, nullptr}));
   } else {
-    // the pieces of the split jobs (the longest lists of the plan) first, into partial rows; then the
-    // other jobs; then the split jobs' rows from their pieces
+    // ONE launch over the jobs and the pieces of the split ones (the pieces first: they belong to the
+    // longest lists); the pieces write partial rows, from which the split jobs' rows are then added up
     Transient tmp{ctx, {}};
     void* q = nullptr;
     S3GRL_TRY(ctx->arena.alloc((size_t)p->npieces * 2 * (p->cfg.sign_k + 1) * (f->F + 1) * sizeof(float), &q));
     tmp.ptrs.push_back(q);
     float* prows = static_cast<float*>(q);
-    const GatherView pieces{p->gjobs, p->npieces, p->g_z, p->g_lim, p->g_order};
-    // the pieces are few: on the context's stream their launch would hold the chip nearly empty in
-    // front of the main one (measured: +0.3 ms on the headline for a hundred split jobs) — they run on
-    // a side stream next to it and are joined before the combine step
-    S3GRL_TRY(ensure_side_streams(ctx));
-    hipEvent_t fork = ctx->side_ev[s3grl_context::kSide], join = ctx->side_ev[0];
-    S3GRL_HIP_TRY(hipEventRecord(fork, ctx->stream));
-    S3GRL_HIP_TRY(hipStreamWaitEvent(ctx->side[0], fork, 0));
-    S3GRL_TRY(gather(pieces, prows, ctx->side[0]));
-    S3GRL_HIP_TRY(hipEventRecord(join, ctx->side[0]));
-    S3GRL_TRY(gather(whole, rows, ctx->stream));
-    S3GRL_HIP_TRY(hipStreamWaitEvent(ctx->stream, join, 0));
+    S3GRL_TRY(gather(GatherView{p->gjobs, p->njobs + p->npieces, p->g_z, p->g_lim, p->g_order, prows}));
     S3GRL_TRY(launch_combine(ctx, p, prows, f->dense, f->ld, f->F, rows));
   }
   S3GRL_TRY(record(ctx, 4));

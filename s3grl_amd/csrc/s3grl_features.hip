@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void gather_sparse_kernel(
     const Job* __restrict__ jobs, int njobs, const int32_t* __restrict__ c_ids,
     const float* __restrict__ c_coef, const float* __restrict__ job_z,
     const int64_t* __restrict__ xptr, const Entry* __restrict__ ent, const float* __restrict__ X,
-    int64_t ldx, int64_t N, int F, float* __restrict__ rows) {
+    int64_t ldx, int64_t N, int F, float* __restrict__ rows_out, float* __restrict__ prows) {
   extern __shared__ float2 lds2[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void gather_sparse_kernel(
   const int col0 = tile * kTileCols;
   const int width = min(kTileCols, F - col0);
   const Job job = jobs[jid];
-  if (job.split) return;   // gathered piece by piece (s3grl_plan::gjobs)
+  if (job.split == 1) return;   // gathered piece by piece (the entries with split == 2)
+  float* __restrict__ rows = job.split == 2 ? prows : rows_out;   // a piece writes partial rows
   const int cnt = __builtin_amdgcn_readfirstlane(job.support);
   const int32_t* __restrict__ ids = c_ids + job.ids_off;
   const float2* __restrict__ cf = reinterpret_cast<const float2*>(c_coef) + job.coef_off;
@@ -202,15 +203,15 @@ __global__ __launch_bounds__(256) void gather_sparse_kernel(
 
 template <int K>
 s3grl_status launch_sparse_k(s3grl_context* ctx, const s3grl_plan* p, const GatherView& v,
-                             const s3grl_features* f, float* rows, hipStream_t stream) {
+                             const s3grl_features* f, float* rows) {
   const unsigned gx = (unsigned)((v.njobs + 3) / 4);
   const size_t lds = (size_t)4 * 2 * K * kTileCols * sizeof(float);
   auto kern = gather_sparse_kernel<K>;
   S3GRL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(gx, (unsigned)f->tiles), dim3(256), lds, stream, v.jobs,
+  hipLaunchKernelGGL(kern, dim3(gx, (unsigned)f->tiles), dim3(256), lds, ctx->stream, v.jobs,
                      (int)v.njobs, p->c_ids, p->c_coef, v.job_z, f->sp_ptr,
-                     reinterpret_cast<const Entry*>(f->sp_ent), f->dense, f->ld, f->N, (int)f->F, rows);
+                     reinterpret_cast<const Entry*>(f->sp_ent), f->dense, f->ld, f->N, (int)f->F, rows, v.prows);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -228,17 +229,17 @@ s3grl_status launch_copy_pad(s3grl_context* ctx, const float* X, int64_t ldx, in
 }
 
 s3grl_status launch_gather_sparse(s3grl_context* ctx, const s3grl_plan* p, const GatherView& v,
-                                  const s3grl_features* f, float* rows, hipStream_t stream) {
+                                  const s3grl_features* f, float* rows) {
   if (v.njobs == 0) return S3GRL_OK;
   switch (p->cfg.sign_k) {
-    case 1: return launch_sparse_k<1>(ctx, p, v, f, rows, stream);
-    case 2: return launch_sparse_k<2>(ctx, p, v, f, rows, stream);
-    case 3: return launch_sparse_k<3>(ctx, p, v, f, rows, stream);
-    case 4: return launch_sparse_k<4>(ctx, p, v, f, rows, stream);
-    case 5: return launch_sparse_k<5>(ctx, p, v, f, rows, stream);
-    case 6: return launch_sparse_k<6>(ctx, p, v, f, rows, stream);
-    case 7: return launch_sparse_k<7>(ctx, p, v, f, rows, stream);
-    case 8: return launch_sparse_k<8>(ctx, p, v, f, rows, stream);
+    case 1: return launch_sparse_k<1>(ctx, p, v, f, rows);
+    case 2: return launch_sparse_k<2>(ctx, p, v, f, rows);
+    case 3: return launch_sparse_k<3>(ctx, p, v, f, rows);
+    case 4: return launch_sparse_k<4>(ctx, p, v, f, rows);
+    case 5: return launch_sparse_k<5>(ctx, p, v, f, rows);
+    case 6: return launch_sparse_k<6>(ctx, p, v, f, rows);
+    case 7: return launch_sparse_k<7>(ctx, p, v, f, rows);
+    case 8: return launch_sparse_k<8>(ctx, p, v, f, rows);
     default:
       set_last_error("sign_k must be in 1..8");
       return S3GRL_ERR_INVALID_ARGUMENT;

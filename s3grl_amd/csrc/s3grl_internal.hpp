@@ -82,7 +82,8 @@ struct Job {
                       // that link is in the list too and was folded into this one, else -1
   int32_t mirror_swap;// rows a,b go to mirror_row+1, mirror_row (the src/dst pair), else same order
   int32_t split;      // 1: the list is cut into pieces that are gathered on their own (s3grl_plan::gjobs)
-                      // and summed by combine_kernel; the gather launch over the jobs skips this one
+                      // and summed by combine_kernel — the gather skips this entry; 2: this entry IS such a
+                      // piece: its two rows go to the partial-row scratch instead of the output
 };
 
 // Jobs whose list is longer than kSplitThreshold entries are cut into pieces of 2^kSplitSegShift
@@ -90,21 +91,22 @@ struct Job {
 // wavefront — the tail of a launch once the list is sharded over 8 GPUs), and no fp32 running sum is
 // longer than the threshold (the pieces are added in f64): the accumulation error stops growing
 // with the subgraph.  A piece costs a wavefront's fixed work and 2 partial rows.  Measured on the
-// headline (164 000 links, gather 6.96 ms unsplit): threshold 4096 7.03 ms, 3072 7.16, 2048 7.48; the
-// pieces on the context's own stream in front of the main launch: +0.3 ms even for a hundred split
-// jobs (they run on a side stream).  The threshold is a constant, NOT a function of the plan: whether
+// headline (164 000 links, gather 6.96 ms unsplit): threshold 4096 7.00 ms, 3072 7.16, 2048 7.48; the
+// pieces in a launch of their own in front of the main one: +0.3 ms even for a hundred split jobs
+// (they are gather units of the same launch).  The threshold is a constant, NOT a function of the plan: whether
 // a job is split decides its summation order, and a link must come out bit for bit the same in a
 // sharded and in an unsharded run.  S3GRL_SPLIT_T / S3GRL_SPLIT_SEG_SHIFT override (0 = never split).
 constexpr int kSplitThreshold = 4096;
 constexpr int kSplitSegShift = 10;
 
-// what a gather launch works on: the jobs of a plan, or the pieces of its split jobs
+// what a gather launch works on: the jobs of a plan — followed, when some are split, by their pieces
 struct GatherView {
   const Job* jobs;
   int64_t njobs;
   const float* job_z;
   const int32_t* job_lim;
   const int32_t* job_order;
+  float* prows;   // partial rows of the pieces (Job::split == 2), or null
 };
 
 // Grow-only caching device allocator: plans are created and destroyed every benchmark step,
@@ -219,10 +221,11 @@ struct s3grl_plan {
   int split_t = 0, seg_shift = 0;  // threshold and piece size the link kernels laid the coefficients out for
   int64_t npieces = 0;
   int64_t* piece_off = nullptr;  // [njobs + 1] first piece of every job (no pieces for an unsplit job)
-  s3grl::Job* gjobs = nullptr;   // [npieces] out_row = 2 * piece index into the partial-row scratch
-  float* g_z = nullptr;          // [npieces, K, 2] zeros (the label column is written by the combine step)
-  int32_t* g_lim = nullptr;      // [npieces, K]
-  int32_t* g_order = nullptr;    // [npieces] identity
+  // the gather units of a plan with split jobs: its njobs jobs followed by the npieces pieces
+  s3grl::Job* gjobs = nullptr;   // [njobs + npieces]; piece q: out_row = 2q into the partial-row scratch
+  float* g_z = nullptr;          // [njobs + npieces, K, 2] (zeros for pieces: combine_kernel writes the label column)
+  int32_t* g_lim = nullptr;      // [njobs + npieces, K]
+  int32_t* g_order = nullptr;    // [njobs + npieces] the pieces first, then job_order
   int32_t* piece_job = nullptr;  // [npieces] the job a piece belongs to
   std::vector<void*> owned;      // everything above, for release
 };
@@ -358,8 +361,8 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
 s3grl_status launch_split_count(s3grl_context* ctx, const Job* jobs, int64_t njobs, int seg_shift,
                                 int32_t* cnt, int64_t* piece_off, int64_t* scan_ws);
 s3grl_status launch_split_fill(s3grl_context* ctx, const Job* jobs, const int32_t* job_lim, int64_t njobs,
-                               int K, int seg_shift, const int64_t* piece_off, Job* gjobs, int32_t* g_lim,
-                               int32_t* g_order, int32_t* piece_job);
+                               const int32_t* job_order, int K, int seg_shift, const int64_t* piece_off,
+                               int64_t npieces, Job* gjobs, int32_t* g_lim, int32_t* g_order, int32_t* piece_job);
 // rows of the split jobs = f64 sum of their pieces' partial rows (+ operator 0, label column, mirror)
 s3grl_status launch_combine(s3grl_context* ctx, const s3grl_plan* p, const float* prows, const float* X,
                             int64_t ldx, int64_t F, float* rows);
@@ -367,16 +370,15 @@ s3grl_status launch_dists(s3grl_context* ctx, const int64_t* node_off, const int
                           int8_t* dists);
 // gather.hip
 s3grl_status launch_gather(s3grl_context* ctx, const GatherView& v, const int32_t* c_ids,
-                           const float* c_coef, int K, const float* X, int64_t ldx, int64_t F, float* rows,
-                           hipStream_t stream);
+                           const float* c_coef, int K, const float* X, int64_t ldx, int64_t F, float* rows);
 // features.hip
 s3grl_status build_packed_rows(s3grl_context* ctx, s3grl_features* f, double max_density);
 s3grl_status launch_gather_packed(s3grl_context* ctx, const s3grl_plan* p, const GatherView& v,
-                                  const s3grl_features* f, float* rows, hipStream_t stream);
+                                  const s3grl_features* f, float* rows);
 s3grl_status launch_gather_traffic(s3grl_context* ctx, const s3grl_plan* p, const s3grl_features* f,
                                    unsigned long long* d_out /* [8] device, zeroed */);
 s3grl_status launch_gather_sparse(s3grl_context* ctx, const s3grl_plan* p, const GatherView& v,
-                                  const s3grl_features* f, float* rows, hipStream_t stream);
+                                  const s3grl_features* f, float* rows);
 s3grl_status launch_copy_pad(s3grl_context* ctx, const float* X, int64_t ldx, int64_t N, int64_t F,
                              float* Y, int64_t ldy);
 

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) S3GRL_GATHER_OCC void gather_p
     const int32_t* __restrict__ job_lim, const int32_t* __restrict__ job_order,
     const PackedHdr* __restrict__ hdr,
     const float4_t* __restrict__ data, uint32_t data_bytes, int64_t N, const float* __restrict__ X,
-    int64_t ldx, int F, float* __restrict__ rows) {
+    int64_t ldx, int F, float* __restrict__ rows_out, float* __restrict__ prows) {
   constexpr int CH = 2;
   constexpr int U = 4;   // rows per group
   const int lane = threadIdx.x & 63;
@@ -164,7 +164,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) S3GRL_GATHER_OCC void gather_p
   const int jid = __builtin_amdgcn_readfirstlane(job_order[wid]);   // longest jobs start first
   const int col0 = blockIdx.y * kTile;
   const Job job = jobs[jid];
-  if (job.split) return;   // gathered piece by piece (s3grl_plan::gjobs)
+  if (job.split == 1) return;   // gathered piece by piece (the entries with split == 2)
+  float* __restrict__ rows = job.split == 2 ? prows : rows_out;   // a piece writes partial rows
   const int cnt = __builtin_amdgcn_readfirstlane(job.support);
   const uint32_t* __restrict__ uid = reinterpret_cast<const uint32_t*>(c_ids + job.ids_off);
   const float2* __restrict__ cf = reinterpret_cast<const float2*>(c_coef) + job.coef_off;
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(256) void gather_traffic_kernel(
   const int jid = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (jid >= njobs) return;
   const Job job = jobs[jid];
-  if (job.split) {   // gathered piece by piece; the combine step writes its rows (and reads X for operator 0)
+  if (job.split == 1) {   // gathered piece by piece; the combine step writes its rows (and reads X for operator 0)
     if (lane == 0) {
       const unsigned long long nr = (job.node_b >= 0 ? 2 : 1) * (job.mirror_row >= 0 ? 2 : 1);
       atomicAdd(&out[4], 4ull * nr * (K + 1) * (unsigned long long)(F + 1));
@@ -566,7 +567,8 @@ __global__ __launch_bounds__(256) void gather_traffic_kernel(
 
 template <int K>
 s3grl_status launch_packed_k(s3grl_context* ctx, const s3grl_plan* p, const GatherView& v,
-                             const s3grl_features* f, float* rows, hipStream_t stream) {
+                             const s3grl_features* f, float* rows) {
+  hipStream_t stream = ctx->stream;
   const unsigned gx = (unsigned)((v.njobs + kWavesPerBlock - 1) / kWavesPerBlock);
   static const bool masked = !getenv("S3GRL_GATHER_UNMASKED");   // comparison hook: the unconditional loads
   const uint32_t data_bytes = (uint32_t)((f->pk_chunks + 1) * 16);
@@ -579,7 +581,7 @@ s3grl_status launch_packed_k(s3grl_context* ctx, const s3grl_plan* p, const Gath
     hipLaunchKernelGGL((gather_packed_kernel<K, true, (K >= 2 ? 2 : 1)>), dim3(gx, (unsigned)f->tiles),
                        dim3(kWavesPerBlock * 64), lds_cap, stream, v.jobs, (int)v.njobs, p->c_ids, p->c_coef,
                        v.job_z, v.job_lim, v.job_order, static_cast<const PackedHdr*>(f->pk_hdr),
-                       static_cast<const float4_t*>(f->pk_data), data_bytes, f->N, f->dense, f->ld, (int)f->F, rows);
+                       static_cast<const float4_t*>(f->pk_data), data_bytes, f->N, f->dense, f->ld, (int)f->F, rows, v.prows);
     S3GRL_HIP_TRY(hipGetLastError());
     return S3GRL_OK;
   }
@@ -587,12 +589,12 @@ s3grl_status launch_packed_k(s3grl_context* ctx, const s3grl_plan* p, const Gath
     hipLaunchKernelGGL((gather_packed_kernel<K, true, 1>), dim3(gx, (unsigned)f->tiles), dim3(kWavesPerBlock * 64),
                        lds_cap, stream, v.jobs, (int)v.njobs, p->c_ids, p->c_coef, v.job_z, v.job_lim,
                        v.job_order, static_cast<const PackedHdr*>(f->pk_hdr),
-                       static_cast<const float4_t*>(f->pk_data), data_bytes, f->N, f->dense, f->ld, (int)f->F, rows);
+                       static_cast<const float4_t*>(f->pk_data), data_bytes, f->N, f->dense, f->ld, (int)f->F, rows, v.prows);
   else
     hipLaunchKernelGGL((gather_packed_kernel<K, false, 1>), dim3(gx, (unsigned)f->tiles), dim3(kWavesPerBlock * 64),
                        0, stream, v.jobs, (int)v.njobs, p->c_ids, p->c_coef, v.job_z, v.job_lim,
                        v.job_order, static_cast<const PackedHdr*>(f->pk_hdr),
-                       static_cast<const float4_t*>(f->pk_data), data_bytes, f->N, f->dense, f->ld, (int)f->F, rows);
+                       static_cast<const float4_t*>(f->pk_data), data_bytes, f->N, f->dense, f->ld, (int)f->F, rows, v.prows);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -655,24 +657,25 @@ s3grl_status launch_gather_traffic(s3grl_context* ctx, const s3grl_plan* p, cons
                      static_cast<const PackedHdr*>(f->pk_hdr), f->N, (int)f->F, 0, d_out);
   if (p->npieces)
     hipLaunchKernelGGL(gather_traffic_kernel, dim3((unsigned)((p->npieces + 3) / 4)), dim3(256), 0, ctx->stream,
-                       p->gjobs, (int)p->npieces, p->c_ids, p->g_lim, p->cfg.sign_k, f->packed ? 1 : 0,
-                       static_cast<const PackedHdr*>(f->pk_hdr), f->N, (int)f->F, 1, d_out);
+                       p->gjobs + p->njobs, (int)p->npieces, p->c_ids, p->g_lim + p->njobs * p->cfg.sign_k,
+                       p->cfg.sign_k, f->packed ? 1 : 0, static_cast<const PackedHdr*>(f->pk_hdr), f->N, (int)f->F, 1,
+                       d_out);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
 
 s3grl_status launch_gather_packed(s3grl_context* ctx, const s3grl_plan* p, const GatherView& v,
-                                  const s3grl_features* f, float* rows, hipStream_t stream) {
+                                  const s3grl_features* f, float* rows) {
   if (v.njobs == 0) return S3GRL_OK;
   switch (p->cfg.sign_k) {
-    case 1: return launch_packed_k<1>(ctx, p, v, f, rows, stream);
-    case 2: return launch_packed_k<2>(ctx, p, v, f, rows, stream);
-    case 3: return launch_packed_k<3>(ctx, p, v, f, rows, stream);
-    case 4: return launch_packed_k<4>(ctx, p, v, f, rows, stream);
-    case 5: return launch_packed_k<5>(ctx, p, v, f, rows, stream);
-    case 6: return launch_packed_k<6>(ctx, p, v, f, rows, stream);
-    case 7: return launch_packed_k<7>(ctx, p, v, f, rows, stream);
-    case 8: return launch_packed_k<8>(ctx, p, v, f, rows, stream);
+    case 1: return launch_packed_k<1>(ctx, p, v, f, rows);
+    case 2: return launch_packed_k<2>(ctx, p, v, f, rows);
+    case 3: return launch_packed_k<3>(ctx, p, v, f, rows);
+    case 4: return launch_packed_k<4>(ctx, p, v, f, rows);
+    case 5: return launch_packed_k<5>(ctx, p, v, f, rows);
+    case 6: return launch_packed_k<6>(ctx, p, v, f, rows);
+    case 7: return launch_packed_k<7>(ctx, p, v, f, rows);
+    case 8: return launch_packed_k<8>(ctx, p, v, f, rows);
     default:
       set_last_error("sign_k must be in 1..8");
       return S3GRL_ERR_INVALID_ARGUMENT;

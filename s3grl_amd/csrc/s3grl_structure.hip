@@ -418,15 +418,21 @@ __global__ void split_count_kernel(const Job* __restrict__ jobs, int64_t njobs, 
 // piece s of job j as a gather unit of its own: list entries [s·SEG, min((s+1)·SEG, support)), its
 // coefficient block (laid out by the link kernel), operator reach clamped to the piece, and two
 // rows of the partial-row scratch as output.  No mirror, no label column: combine_kernel does those.
+// The pieces sit behind the plan's jobs in ONE array of gather units (gjobs[njobs + q]); the launch
+// order starts with the pieces (they belong to the longest lists of the plan) and goes on with the
+// plan's own largest-first order.
 __global__ void split_fill_kernel(const Job* __restrict__ jobs, const int32_t* __restrict__ job_lim,
-                                  int64_t njobs, int K, int seg_shift, const int64_t* __restrict__ piece_off,
-                                  Job* __restrict__ gjobs, int32_t* __restrict__ g_lim,
-                                  int32_t* __restrict__ g_order, int32_t* __restrict__ piece_job) {
+                                  const int32_t* __restrict__ job_order, int64_t njobs, int K, int seg_shift,
+                                  const int64_t* __restrict__ piece_off, int64_t npieces, Job* __restrict__ gjobs,
+                                  int32_t* __restrict__ g_lim, int32_t* __restrict__ g_order,
+                                  int32_t* __restrict__ piece_job) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= njobs) return;
-  const int64_t p0 = piece_off[j], p1 = piece_off[j + 1];
-  if (p1 == p0) return;
   const Job job = jobs[j];
+  gjobs[j] = job;
+  for (int i = 0; i < K; ++i) g_lim[j * K + i] = job_lim[j * K + i];
+  g_order[npieces + j] = job_order[j];
+  const int64_t p0 = piece_off[j], p1 = piece_off[j + 1];
   for (int64_t q = p0; q < p1; ++q) {
     const int s0 = (int)(q - p0) << seg_shift;
     const int len = min(1 << seg_shift, job.support - s0);
@@ -437,10 +443,10 @@ __global__ void split_fill_kernel(const Job* __restrict__ jobs, const int32_t* _
     g.support = len;
     g.mirror_row = -1;
     g.mirror_swap = 0;
-    g.split = 0;
-    gjobs[q] = g;
-    for (int i = 0; i < K; ++i) g_lim[q * K + i] = min(max(job_lim[j * K + i] - s0, 0), len);
-    g_order[q] = (int32_t)q;
+    g.split = 2;
+    gjobs[njobs + q] = g;
+    for (int i = 0; i < K; ++i) g_lim[(njobs + q) * K + i] = min(max(job_lim[j * K + i] - s0, 0), len);
+    g_order[q] = (int32_t)(njobs + q);
     piece_job[q] = (int32_t)j;
   }
 }
@@ -1508,11 +1514,11 @@ s3grl_status launch_split_count(s3grl_context* ctx, const Job* jobs, int64_t njo
 }
 
 s3grl_status launch_split_fill(s3grl_context* ctx, const Job* jobs, const int32_t* job_lim, int64_t njobs,
-                               int K, int seg_shift, const int64_t* piece_off, Job* gjobs, int32_t* g_lim,
-                               int32_t* g_order, int32_t* piece_job) {
+                               const int32_t* job_order, int K, int seg_shift, const int64_t* piece_off,
+                               int64_t npieces, Job* gjobs, int32_t* g_lim, int32_t* g_order, int32_t* piece_job) {
   if (njobs == 0) return S3GRL_OK;
   hipLaunchKernelGGL(split_fill_kernel, dim3((unsigned)((njobs + 255) / 256)), dim3(256), 0, ctx->stream, jobs,
-                     job_lim, njobs, K, seg_shift, piece_off, gjobs, g_lim, g_order, piece_job);
+                     job_lim, job_order, njobs, K, seg_shift, piece_off, npieces, gjobs, g_lim, g_order, piece_job);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
