@@ -837,8 +837,9 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
               (long long)hs[20], (long long)hs[21]);
       S3GRL_HIP_TRY(hipMemcpy(hs + 24, ds + 24, 8 * 8, hipMemcpyDeviceToHost));
       fprintf(stderr, "[s3grl] link_full_kernel, big class: merge %lld  hash+ids %lld  probes %lld  "
-                      "csr+sort %lld  passes %lld\n",
-              (long long)hs[24], (long long)hs[25], (long long)hs[26], (long long)hs[27], (long long)hs[28]);
+                      "csr+sort %lld  passes %lld   links %lld, columns in HBM for %lld\n",
+              (long long)hs[24], (long long)hs[25], (long long)hs[26], (long long)hs[27], (long long)hs[28],
+              (long long)hs[30], (long long)hs[31]);
     }
   }
   *out = plan.release();

@@ -426,6 +426,10 @@ __global__ __launch_bounds__(T) void link_full_kernel(
       }
       if (tid == 0) off[n] = total;
       big_on_chip = total <= cols_b_cap;
+      if (dbg && tid == 0) {   // diagnostic: links of the class / whose columns had to stay in the HBM slice
+        atomicAdd(&dbg[8 + 6], 1ull);
+        if (!big_on_chip) atomicAdd(&dbg[8 + 7], 1ull);
+      }
       __syncthreads();
       const int found = min(sh[30], ecap / 2);
       for (int k = tid; k < found; k += T) {
