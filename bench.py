@@ -408,6 +408,9 @@ def main():
                     help="N > 1: pieces per rank (all-gather of piece c overlaps the compute of c+1)")
     ap.add_argument("--contiguous-shards", action="store_true",
                     help="N > 1: contiguous ranges of the list instead of pair-aware shards (comparison)")
+    ap.add_argument("--exchange-operator0", action="store_true",
+                    help="N > 1: all-gather whole rows (operator 0 = X[node] included) instead of letting every rank "
+                         "fill operator 0 from its own copy of X (comparison)")
     ap.add_argument("--no-allgather", action="store_true",
                     help="N > 1: every rank keeps its shard (data-parallel consumer); no collective")
     ap.add_argument("--verify", action="store_true",
@@ -511,11 +514,21 @@ def main():
         if fixed_rows:
             compute = parallel.engine_compute(eng, g, x, mode=w.mode, num_hops=w.num_hops, sign_k=K, stats=fold_stats)
 
+            x_dev = x.tensor
+
+            def fill_operator0(fl):
+                """operator 0 of every link, [z | X[node]] with z = 1 for both centre rows (what the engine
+                writes there: plain copies of the replicated X) — formed on every rank instead of exchanged"""
+                fl[:, :, 0, 0] = 1.0
+                fl[:, 0, 0, 1:] = x_dev[li_dev[0]]
+                fl[:, 1, 0, 1:] = x_dev[li_dev[1]]
+
             def step_sharded():
                 return parallel.sharded_precompute(
                     compute, li_dev, rank=rank, world_size=world, gather=gather,
                     rows_per_link=2, chunks=args.chunks if gather else 1, row_shape=(K + 1, F + 1),
-                    device=eng.device, timers=timers, reuse_buffers=True, shards=shards)
+                    device=eng.device, timers=timers, reuse_buffers=True, shards=shards,
+                    local_operator0=None if args.exchange_operator0 else fill_operator0)
         else:
             def compute_ragged(shard):
                 res = eng.precompute(g, x, eng.links(shard), mode=w.mode, num_hops=w.num_hops, sign_k=K)
@@ -599,7 +612,8 @@ def main():
     allgather_alone = None
     if world > 1 and fixed_rows and not args.no_allgather and backend == "nccl":
         rmax = 2 * max(shard_info["links_per_rank"])
-        buf = torch.empty((world * rmax, K + 1, F + 1), dtype=torch.float32, device=eng.device)
+        kx = K + 1 if args.exchange_operator0 else K          # operators that travel
+        buf = torch.empty((world * rmax, kx, F + 1), dtype=torch.float32, device=eng.device)
         torch.cuda.synchronize()
         dist.barrier()
         ts = []
@@ -641,7 +655,9 @@ def main():
                 "folded_links_total": sum(r["folded_links"] for r in per_rank),
                 "collective": None if args.no_allgather else
                               ("%d padded all_gather_into_tensor per step (pieces of a shard are gathered on "
-                               "RCCL's stream while the next piece is computed) + scatter into list order" % args.chunks
+                               "RCCL's stream while the next piece is computed) + scatter into list order" % args.chunks +
+                               ("" if args.exchange_operator0 else
+                                "; operators 1..K travel, operator 0 (= [1 | X[node]]) is filled by every rank itself")
                                if fixed_rows else "sizes + one padded all_gather_into_tensor + compaction"),
                 "backend": backend, "links_per_rank": shard_info["links_per_rank"],
                 "per_rank": per_rank,

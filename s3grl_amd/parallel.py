@@ -147,7 +147,7 @@ def _all_gather(out, inp, group, async_op=False):
 def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, group=None, gather=True,
                        rows_per_link=None, chunks=1, row_shape=None, dtype=torch.float32,
                        device=None, timers=None, collective_at_world1=False, reuse_buffers=False,
-                       pair_aware=False, shards=None):
+                       pair_aware=False, shards=None, local_operator0=None):
     """Shard `link_index` ([2, L]) over the ranks and (when `gather`) reassemble the whole result
     on every rank.
 
@@ -160,8 +160,12 @@ def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, grou
     `gather`, else the local shard; `where` = (lo, hi) for contiguous shards, or — `pair_aware`, see
     `shard_assignment` — the int64 tensor of the list positions this rank computed (the rows of a
     local shard are in that order).  `shards`: a `ShardPlan` made once for this list (a step must not
-    redo the assignment); `cost` / `pair_aware` are then taken from it.  `timers` (dict, optional)
-    receives host-side timestamps.
+    redo the assignment); `cost` / `pair_aware` are then taken from it.  `local_operator0` (fixed
+    flavour): a callable `fill(final [L, rows_per_link, *row_shape])` that writes operator 0 of every
+    link (`[:, :, 0, :]` = [z | X[node]], which every rank can form from the replicated X and the
+    link list) — the ranks then exchange operators 1..K only: 1 / (K+1) fewer bytes on the wire, and
+    at 8 ranks the step is bound by the wire.  `timers` (dict, optional) receives host-side
+    timestamps.
     `collective_at_world1`: run the pieces / in-place all-gather / compaction path even on a
     one-rank group (a test hook: it is how the collective code meets real RCCL on a one-GPU box).
     `reuse_buffers` (fixed flavour): the returned `rows` live in a process-wide buffer that the NEXT
@@ -188,7 +192,7 @@ def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, grou
     if rows_per_link is not None:
         rows, row_ptr, _ = _fixed(compute, li, b, rank, world_size, cost, group, gather, int(rows_per_link),
                                   max(int(chunks), 1), tuple(row_shape), dtype, device, timers,
-                                  collective_at_world1, bool(reuse_buffers), order_t)
+                                  collective_at_world1, bool(reuse_buffers), order_t, local_operator0)
         return rows, row_ptr, where
     rows, row_ptr = compute(li[:, lo:hi])
     if not gather or world_size == 1:
@@ -266,9 +270,10 @@ def _result(key, shape, dtype, device, reuse):
 
 
 def _fixed(compute, li, b, rank, world, cost, group, gather, rpl, chunks, row_shape, dtype, device,
-           timers, collective_at_world1=False, reuse=False, order=None):
+           timers, collective_at_world1=False, reuse=False, order=None, local_op0=None):
     """`li` is the list grouped by rank (rank r owns columns b[r]:b[r+1]); `order` (device-resident
-    positions in the caller's list, or None = identity) says where every column belongs."""
+    positions in the caller's list, or None = identity) says where every column belongs;
+    `local_op0`: see `sharded_precompute(local_operator0=…)`."""
     L = int(li.shape[1])
     lo, hi = b[rank], b[rank + 1]
     row_ptr = torch.arange(0, rpl * L + 1, rpl, dtype=torch.int64, device=device)
@@ -285,8 +290,12 @@ def _fixed(compute, li, b, rank, world, cost, group, gather, rpl, chunks, row_sh
     slots = [None] * chunks
     pmaxes = [rpl * max(pb[r][c + 1] - pb[r][c] for r in range(world)) for c in range(chunks)]
     cap = max(max(pmaxes), 1)
+    # what travels: whole rows, or operators 1..K when every rank fills operator 0 itself
+    xshape = row_shape if local_op0 is None else (row_shape[0] - 1,) + row_shape[1:]
 
     final_links = final.view((L, rpl) + row_shape)
+    final_x = final if local_op0 is None else final[:, 1:]
+    final_links_x = final_links if local_op0 is None else final_links[:, :, 1:]
 
     def compact(c):
         slot, pmax = slots[c]
@@ -296,23 +305,31 @@ def _fixed(compute, li, b, rank, world, cost, group, gather, rpl, chunks, row_sh
             if not n:
                 continue
             if order is None:
-                final[rpl * p0: rpl * p0 + n].copy_(slot[r, :n], non_blocking=True)
-            else:      # scatter by list position: 2 rows x (K+1) x (1+F) floats per link, contiguous
-                final_links.index_copy_(0, order[p0:p1], slot[r, :n].view((p1 - p0, rpl) + row_shape))
+                final_x[rpl * p0: rpl * p0 + n].copy_(slot[r, :n], non_blocking=True)
+            else:      # scatter by list position: 2 rows x K(+1) x (1+F) floats per link
+                final_links_x.index_copy_(0, order[p0:p1], slot[r, :n].view((p1 - p0, rpl) + xshape))
 
     t_comm = 0.0
     for c in range(chunks):
         pmax = max(pmaxes[c], 1)
-        buf = _Buffers.get(("slot", rank, c % 2), (world * cap,) + row_shape, dtype, device)
-        slot = buf[:world * pmax].view((world, pmax) + row_shape)
+        buf = _Buffers.get(("slot", rank, c % 2, local_op0 is None), (world * cap,) + xshape, dtype, device)
+        slot = buf[:world * pmax].view((world, pmax) + xshape)
         slots[c] = (slot, pmax)
         p0, p1 = pb[rank][c], pb[rank][c + 1]
         if p1 > p0:
-            compute(li[:, p0:p1], slot[rank, :rpl * (p1 - p0)])
+            n = rpl * (p1 - p0)
+            if local_op0 is None:
+                compute(li[:, p0:p1], slot[rank, :n])
+            else:      # the engine writes whole rows: pack operators 1..K into the slot
+                full = _Buffers.get(("full", rank), (cap,) + row_shape, dtype, device)
+                compute(li[:, p0:p1], full[:n])
+                slot[rank, :n].copy_(full[:n, 1:], non_blocking=True)
         t0 = time.perf_counter()
         # in place: this rank's contribution already sits in its slice of the output
-        works[c] = _all_gather(slot.view((world * slot.shape[1],) + row_shape), slot[rank], group,
+        works[c] = _all_gather(slot.view((world * slot.shape[1],) + xshape), slot[rank], group,
                                async_op=True)
+        if c == 0 and local_op0 is not None:
+            local_op0(final_links)          # while the first pieces travel
         if c >= 1:
             works[c - 1].wait()
             compact(c - 1)

@@ -123,6 +123,17 @@ def _worker_fixed(rank, world, port, chunks, q):
                                                      **{k: v for k, v in kwargs.items() if k != "chunks"})
     ok = ok and np.array_equal(rows_l.numpy(), rows_of(both[:, where_l.numpy()]))
     calls.clear()
+    # operator 0 filled by every rank itself, operators 1.. exchanged: the same tensor, fewer bytes on the wire
+    full_both = rows_of(both)
+
+    def fill0(fl):
+        fl[:, :, 0, :] = torch.from_numpy(full_both).view(both.shape[1], 2, 3, 7)[:, :, 0, :]
+
+    for sp_ in (None, plan):
+        rows_x, _, _ = parallel.sharded_precompute(compute, both, shards=sp_, local_operator0=fill0,
+                                                   cost=parallel.link_cost(A, both), **kwargs)
+        ok = ok and np.array_equal(rows_x.numpy(), full_both)
+    calls.clear()
     # gather=False hands back the local shard only
     rows_l, ptr_l, _ = parallel.sharded_precompute(
         compute, links, rank=rank, world_size=world, cost=parallel.link_cost(A, links),
