@@ -505,7 +505,7 @@ def main():
         # a reversed duplicate is priced at what it costs once it is folded into its primary, and the
         # assignment keeps the two directions of a pair on one rank (parallel.shard_assignment)
         cost = parallel.measured_cost(eng, g, link_index, w.num_hops, mode=w.mode) if w.mode != "sop" \
-            else parallel.link_cost(w.A, link_index) + 64.0
+            else parallel.sop_cost(eng, g, w.A, link_index)
         li_dev = torch.as_tensor(link_index).to(eng.device)
         shards = parallel.ShardPlan(li_dev, world, cost, pair_aware=not args.contiguous_shards, device=eng.device)
         gather = not args.no_allgather

@@ -120,6 +120,15 @@ def measured_cost(engine, graph, link_index, num_hops, mode="pos"):
     return engine.link_costs(graph, engine.links(link_index), num_hops=num_hops, mode=mode).cpu().numpy().astype(np.float64)
 
 
+def sop_cost(engine, graph, A, link_index):
+    """Per-link cost of the SoP flow: the row kernel reads the same 2(K+1) table rows for every link,
+    the scalar phase grows with the 1-hop ball (deg src + deg dst), and a reversed duplicate that the
+    engine folds into its primary costs its output rows only (it is recognised by the sizing pass of a
+    count-only plan, like for PoS)."""
+    folded = engine.link_costs(graph, engine.links(link_index), num_hops=1).cpu().numpy() == 250.0
+    return np.where(folded, 8.0, link_cost(A, link_index) + 32.0)
+
+
 def chunk_bounds(lo, hi, chunks, cost=None):
     """Cut [lo, hi) into `chunks` contiguous cost-balanced pieces (empty pieces allowed)."""
     c = None if cost is None else np.asarray(cost)[lo:hi]
