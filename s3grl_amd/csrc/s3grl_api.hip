@@ -670,18 +670,28 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
     links_walk = lr;
   }
   plan->relabelled = relabel;
+  // Big graph, long list: the links are worked on in the order of their higher-degree endpoint
+  // (launch_link_order) — sizing pass, link kernels (through the class lists) and gather.  Small graphs
+  // sit in the caches whatever the order and keep the longest-first gather order.
+  int32_t* perm = nullptr;
+  bool hub_order = g->num_nodes > kHubOrderMinNodes && L >= kHubOrderMinLinks;
+  if (const char* e = getenv("S3GRL_HUB_ORDER")) hub_order = atoi(e) != 0;   // test hook
+  if (hub_order) {
+    S3GRL_TRY(arena_alloc(ctx, (size_t)L, &perm, tr));
+    S3GRL_TRY(launch_link_order(ctx, links_walk, L, g->num_nodes, g_walk.indptr, perm));
+  }
   int32_t* e_cap = nullptr;
   if (onehop) {
     S3GRL_TRY(arena_alloc(ctx, (size_t)L, &e_cap, own));
     plan->e_cap = e_cap;
     S3GRL_TRY(launch_count1(ctx, &g_walk, links_walk, L, plus ? 1 : 0, K, partner, mirror_of, plan->n_nodes, p_nodes,
                             n_rows, n_jobs, lvl_max, e_cap, reinterpret_cast<int32_t*>(ds), st + 3 * kStatRow,
-                            st + 4 * kStatRow));
+                            st + 4 * kStatRow, perm));
   } else {
     S3GRL_TRY(launch_count(ctx, &g_walk, links_walk, L, cfg->num_hops, plus ? 1 : 0, K, ws,
                            partner, mirror_of,
                            plan->n_nodes, p_nodes, n_rows, n_jobs, lvl_max,
-                           reinterpret_cast<int32_t*>(ds), st + 3 * kStatRow, smp, stash, slot, plan->lvl));
+                           reinterpret_cast<int32_t*>(ds), st + 3 * kStatRow, smp, stash, slot, plan->lvl, perm));
   }
   if (fold) S3GRL_TRY(launch_mirror_rows(ctx, partner, L, n_rows));
   // offsets of nodes / rows / row pairs, their maxima (ds[1], ds[5]) and totals (ds[9..11]) in one go
@@ -690,7 +700,7 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   // PoS has no common-neighbour rows: the LDS classes are known without a round trip
   if (!plus)
     S3GRL_TRY(launch_classify(ctx, g, 1, K, plan->n_nodes, p_nodes, lvl_max, L, class_count, class_list,
-                              !sampling && !g->directed, e_cap, stash ? slot : 0));
+                              !sampling && !g->directed, e_cap, stash ? slot : 0, perm));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs, ds, 48 * 8, hipMemcpyDeviceToHost, ctx->stream));   // scalars + class counts
   S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_stats + 3 * kStatRow, st + 3 * kStatRow, 2 * kStatRow * sizeof(int64_t),
                                hipMemcpyDeviceToHost, ctx->stream));
@@ -713,7 +723,7 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   const int cn_cap = ((int)std::max<int64_t>(max_R - 2, 0) + 1) * ((relabel && plus) ? 3 : 1);
   if (plus) {
     S3GRL_TRY(launch_classify(ctx, g, cn_cap, K, plan->n_nodes, p_nodes, lvl_max, L, class_count,
-                              class_list, !sampling && !g->directed, e_cap, stash ? slot : 0));
+                              class_list, !sampling && !g->directed, e_cap, stash ? slot : 0, perm));
     S3GRL_HIP_TRY(hipMemcpyAsync(hs + 32, ds + 32, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
     S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
@@ -750,8 +760,16 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
     int32_t* hist;
     S3GRL_TRY(arena_alloc(ctx, (size_t)256, &hist, tr));
     S3GRL_TRY(arena_alloc(ctx, (size_t)std::max<int64_t>(njobs, 1), &plan->job_order, own));
-    S3GRL_TRY(launch_job_order(ctx, plan->n_nodes, n_jobs, plan->job_off, L, hist, plan->job_order));
+    int32_t* pc = nullptr;
+    int64_t* po = nullptr;
+    if (perm) {
+      S3GRL_TRY(arena_alloc(ctx, (size_t)L, &pc, tr));
+      S3GRL_TRY(arena_alloc(ctx, (size_t)(L + 1), &po, tr));
+    }
+    S3GRL_TRY(launch_job_order(ctx, plan->n_nodes, n_jobs, plan->job_off, L, hist, plan->job_order, perm, pc, po,
+                               scan_ws));
   }
+  plan->hub_order = perm != nullptr;
 
   // coefficient lists: one per row pair, sized by the link's node count
   const int64_t* coef_off = nullptr;          // PoS: one pair per link, list at node_off[link]
@@ -945,7 +963,7 @@ static s3grl_status run_with(s3grl_context* ctx, const s3grl_plan* p, const s3gr
   auto gather = [&](const GatherView& v) -> s3grl_status {
     if (f->sparse) return launch_gather_sparse(ctx, p, v, f, rows);
     if (f->packed) return launch_gather_packed(ctx, p, v, f, rows);
-    return launch_gather(ctx, v, p->c_ids, p->c_coef, p->cfg.sign_k, f->dense, f->ld, f->F, rows);
+    return launch_gather(ctx, v, p->c_ids, p->c_coef, p->cfg.sign_k, f->dense, f->ld, f->F, rows, p->hub_order);
   };
   if (p->npieces == 0) {
     S3GRL_TRY(gather(GatherView{p->jobs, p->njobs, p->job_z, p->job_lim, p->job_order, nullptr}));

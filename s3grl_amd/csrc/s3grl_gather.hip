@@ -28,10 +28,13 @@ template <int K, int CH>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_kernel(
     const Job* __restrict__ jobs, int njobs, const int32_t* __restrict__ c_ids,
     const float* __restrict__ c_coef, const float* __restrict__ job_z, const float* __restrict__ X,
-    int64_t ldx, int F, float* __restrict__ rows_out, float* __restrict__ prows) {
+    int64_t ldx, int F, float* __restrict__ rows_out, float* __restrict__ prows,
+    const int32_t* __restrict__ job_order) {
   const int lane = threadIdx.x & 63;
-  const int jid = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
-  if (jid >= njobs) return;
+  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+  if (wid >= njobs) return;
+  // (job_order: plans that work in hub order, s3grl_relabel.hip launch_link_order; else list order)
+  const int jid = job_order ? __builtin_amdgcn_readfirstlane(job_order[wid]) : wid;
   const int col0 = blockIdx.y * (CH * 256);  // first feature column of this wave's tile
   const Job job = jobs[jid];
   if (job.split == 1) return;   // gathered piece by piece (the entries with split == 2)
@@ -111,12 +114,14 @@ template <int K>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_half_kernel(
     const Job* __restrict__ jobs, int njobs, const int32_t* __restrict__ c_ids,
     const float* __restrict__ c_coef, const float* __restrict__ job_z, const float* __restrict__ X,
-    int64_t ldx, int F, float* __restrict__ rows_out, float* __restrict__ prows) {
+    int64_t ldx, int F, float* __restrict__ rows_out, float* __restrict__ prows,
+    const int32_t* __restrict__ job_order) {
   constexpr int U = 8;   // pairs of list entries per trip: 16 rows of X in flight per wavefront
   const int lane = threadIdx.x & 63;
   const bool odd = lane >= 32;
-  const int jid = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
-  if (jid >= njobs) return;
+  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+  if (wid >= njobs) return;
+  const int jid = job_order ? __builtin_amdgcn_readfirstlane(job_order[wid]) : wid;
   const Job job = jobs[jid];
   if (job.split == 1) return;   // gathered piece by piece (the entries with split == 2)
   float* __restrict__ rows = job.split == 2 ? prows : rows_out;   // a piece writes partial rows
@@ -182,20 +187,20 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_half_kernel(
 template <int K>
 s3grl_status launch_k(s3grl_context* ctx, const Job* jobs, int64_t njobs, const int32_t* c_ids,
                       const float* c_coef, const float* job_z, const float* X, int64_t ldx,
-                      int64_t F, float* rows, float* prows) {
+                      int64_t F, float* rows, float* prows, const int32_t* job_order) {
   hipStream_t stream = ctx->stream;
   const unsigned gx = (unsigned)((njobs + kWavesPerBlock - 1) / kWavesPerBlock);
   static const bool no_half = getenv("S3GRL_GATHER_NO_HALF") != nullptr;   // comparison hook
   if (F <= 128 && !no_half) {
     hipLaunchKernelGGL((gather_half_kernel<K>), dim3(gx, 1), dim3(kWavesPerBlock * 64), 0, stream,
-                       jobs, (int)njobs, c_ids, c_coef, job_z, X, ldx, (int)F, rows, prows);
+                       jobs, (int)njobs, c_ids, c_coef, job_z, X, ldx, (int)F, rows, prows, job_order);
   } else if (F <= 256) {
     hipLaunchKernelGGL((gather_kernel<K, 1>), dim3(gx, 1), dim3(kWavesPerBlock * 64), 0, stream,
-                       jobs, (int)njobs, c_ids, c_coef, job_z, X, ldx, (int)F, rows, prows);
+                       jobs, (int)njobs, c_ids, c_coef, job_z, X, ldx, (int)F, rows, prows, job_order);
   } else {
     const unsigned gy = (unsigned)((F + 511) / 512);
     hipLaunchKernelGGL((gather_kernel<K, 2>), dim3(gx, gy), dim3(kWavesPerBlock * 64), 0,
-                       stream, jobs, (int)njobs, c_ids, c_coef, job_z, X, ldx, (int)F, rows, prows);
+                       stream, jobs, (int)njobs, c_ids, c_coef, job_z, X, ldx, (int)F, rows, prows, job_order);
   }
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
@@ -204,20 +209,22 @@ s3grl_status launch_k(s3grl_context* ctx, const Job* jobs, int64_t njobs, const 
 }  // namespace
 
 s3grl_status launch_gather(s3grl_context* ctx, const GatherView& v, const int32_t* c_ids,
-                           const float* c_coef, int K, const float* X, int64_t ldx, int64_t F, float* rows) {
+                           const float* c_coef, int K, const float* X, int64_t ldx, int64_t F, float* rows,
+                           bool in_job_order) {
   const Job* jobs = v.jobs;
   const int64_t njobs = v.njobs;
   const float* job_z = v.job_z;
+  const int32_t* order = in_job_order ? v.job_order : nullptr;
   if (njobs == 0) return S3GRL_OK;
   switch (K) {
-    case 1: return launch_k<1>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, v.prows);
-    case 2: return launch_k<2>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, v.prows);
-    case 3: return launch_k<3>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, v.prows);
-    case 4: return launch_k<4>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, v.prows);
-    case 5: return launch_k<5>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, v.prows);
-    case 6: return launch_k<6>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, v.prows);
-    case 7: return launch_k<7>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, v.prows);
-    case 8: return launch_k<8>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, v.prows);
+    case 1: return launch_k<1>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, v.prows, order);
+    case 2: return launch_k<2>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, v.prows, order);
+    case 3: return launch_k<3>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, v.prows, order);
+    case 4: return launch_k<4>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, v.prows, order);
+    case 5: return launch_k<5>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, v.prows, order);
+    case 6: return launch_k<6>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, v.prows, order);
+    case 7: return launch_k<7>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, v.prows, order);
+    case 8: return launch_k<8>(ctx, jobs, njobs, c_ids, c_coef, job_z, X, ldx, F, rows, v.prows, order);
     default:
       set_last_error("sign_k must be in 1..8");
       return S3GRL_ERR_INVALID_ARGUMENT;

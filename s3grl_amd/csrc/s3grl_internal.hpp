@@ -98,6 +98,9 @@ struct Job {
 // sharded and in an unsharded run.  S3GRL_SPLIT_T / S3GRL_SPLIT_SEG_SHIFT override (0 = never split).
 constexpr int kSplitThreshold = 4096;
 constexpr int kSplitSegShift = 10;
+// plans on graphs / lists at least this big work on their links in hub order (launch_link_order)
+constexpr int64_t kHubOrderMinNodes = 65536;
+constexpr int64_t kHubOrderMinLinks = 65536;
 
 // what a gather launch works on: the jobs of a plan — followed, when some are split, by their pieces
 struct GatherView {
@@ -206,6 +209,7 @@ struct s3grl_plan {
   int32_t* e_cap = nullptr;      // [L] bound of the induced entries (one-hop plans on big graphs), else null
   bool relabelled = false;       // the kernels walked the graph's degree order (s3grl_relabel.hip)
   bool stats_pending = false;    // total_sub_edges / total_support / total_volume not read back yet
+  bool hub_order = false;        // links worked on in hub order (launch_link_order); job_order follows it
   bool walk_plan = false;        // ScaLed: subgraph = walk nodes of src and dst (one "hop", whatever num_hops)
   int32_t* c_ids = nullptr;      // [Σn] subgraph nodes, hop-major (ascending id inside a hop unless relabelled)
   // per job (row pair)
@@ -285,6 +289,10 @@ s3grl_status ensure_side_streams(s3grl_context* ctx);
 s3grl_status build_degree_order(s3grl_context* ctx, s3grl_graph* g);
 s3grl_status launch_translate_links(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                                     int64_t* out);
+// perm [L]: the link indices ordered by (higher-degree endpoint, other endpoint) — the order in which a
+// plan on a big graph works on its links (locality; outputs stay in the caller's order)
+s3grl_status launch_link_order(s3grl_context* ctx, const int64_t* links, int64_t L, int64_t N,
+                               const int32_t* indptr, int32_t* perm);
 s3grl_status launch_sort_hops(s3grl_context* ctx, const s3grl_plan* p, int32_t* nodes);
 
 // structure.hip
@@ -293,7 +301,8 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           const int32_t* partner, const int32_t* mirror_of, int32_t* n_nodes, int32_t* p_nodes,
                           int32_t* n_rows, int32_t* n_jobs, int32_t* lvl_max, int32_t* err_flag,
                           int64_t* tot_nodes_alg, HopSampling smp = HopSampling{1.0, 0, 0},
-                          int32_t* stash = nullptr, int slot = 0, int32_t* lvl_stash = nullptr);
+                          int32_t* stash = nullptr, int slot = 0, int32_t* lvl_stash = nullptr,
+                          const int32_t* perm = nullptr);
 // union of two sorted adjacency structures of the same nodes (a directed graph's successors and
 // predecessors): out_indptr [N+1] / *out_indices (arena-owned) / *nnz
 s3grl_status build_union_graph(s3grl_context* ctx, int64_t N, const int32_t* a_indptr, const int32_t* a_indices,
@@ -319,7 +328,9 @@ s3grl_status launch_find_mirrors(s3grl_context* ctx, const int64_t* links, int64
 s3grl_status launch_mirror_rows(s3grl_context* ctx, const int32_t* partner, int64_t L,
                                 int32_t* n_rows);
 s3grl_status launch_job_order(s3grl_context* ctx, const int32_t* n_nodes, const int32_t* n_jobs,
-                              const int64_t* job_off, int64_t L, int32_t* hist, int32_t* job_order);
+                              const int64_t* job_off, int64_t L, int32_t* hist, int32_t* job_order,
+                              const int32_t* perm = nullptr, int32_t* scratch_cnt = nullptr,
+                              int64_t* scratch_off = nullptr, int64_t* scan_ws = nullptr);
 int64_t scan_workspace_elems(int64_t n);
 s3grl_status launch_scan_i32_to_i64(s3grl_context* ctx, const int32_t* in, int64_t n, int64_t* out,
                                     int64_t* workspace);
@@ -333,7 +344,7 @@ s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_ca
                              const int32_t* n_nodes, const int32_t* p_nodes,
                              const int32_t* lvl_max, int64_t L, int32_t* class_count,
                              int32_t* class_list, bool allow_hash = true, const int32_t* e_cap = nullptr,
-                             int stash_slot = 0);
+                             int stash_slot = 0, const int32_t* perm = nullptr);
 // one-hop plans on big graphs (s3grl_onehop.inl): degree-oriented rows of the graph, and the
 // sizing pass that needs no bitmaps
 bool sparse_mode_for(const s3grl_graph* g);
@@ -343,7 +354,7 @@ s3grl_status launch_count1(s3grl_context* ctx, const s3grl_graph* g, const int64
                            int plus, int K, const int32_t* partner, const int32_t* mirror_of,
                            int32_t* n_nodes, int32_t* p_nodes, int32_t* n_rows, int32_t* n_jobs,
                            int32_t* lvl_max, int32_t* e_cap, int32_t* err_flag, int64_t* tot_nodes_alg,
-                           int64_t* tot_oriented);
+                           int64_t* tot_oriented, const int32_t* perm = nullptr);
 s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                           const int32_t* class_list, const int32_t* class_count_host, int hops,
                           int plus, int cn_cap, int full_stats, int K, WalkSets ws, const int32_t* p_nodes,
@@ -370,7 +381,8 @@ s3grl_status launch_dists(s3grl_context* ctx, const int64_t* node_off, const int
                           int8_t* dists);
 // gather.hip
 s3grl_status launch_gather(s3grl_context* ctx, const GatherView& v, const int32_t* c_ids,
-                           const float* c_coef, int K, const float* X, int64_t ldx, int64_t F, float* rows);
+                           const float* c_coef, int K, const float* X, int64_t ldx, int64_t F, float* rows,
+                           bool in_job_order = false);
 // features.hip
 s3grl_status build_packed_rows(s3grl_context* ctx, s3grl_features* f, double max_density);
 s3grl_status launch_gather_packed(s3grl_context* ctx, const s3grl_plan* p, const GatherView& v,

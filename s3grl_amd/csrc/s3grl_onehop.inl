@@ -91,10 +91,11 @@ __global__ __launch_bounds__(64 * kCount1Waves) void count1_kernel(
     int32_t* __restrict__ n_nodes, int32_t* __restrict__ p_nodes, int32_t* __restrict__ n_rows,
     int32_t* __restrict__ n_jobs, int32_t* __restrict__ lvl_max, int32_t* __restrict__ e_cap,
     int32_t* __restrict__ err_flag, unsigned long long* __restrict__ tot_nodes_alg,
-    unsigned long long* __restrict__ tot_oriented) {
+    unsigned long long* __restrict__ tot_oriented, const int32_t* __restrict__ perm) {
   const int lane = threadIdx.x & 63;
-  const int64_t l = (int64_t)blockIdx.x * kCount1Waves + (threadIdx.x >> 6);
-  if (l >= L) return;
+  const int64_t li = (int64_t)blockIdx.x * kCount1Waves + (threadIdx.x >> 6);
+  if (li >= L) return;
+  const int64_t l = perm ? perm[li] : li;   // processing order (launch_link_order)
   const int64_t s64 = links[2 * l], d64 = links[2 * l + 1];
   const bool bad = s64 < 0 || s64 >= N || d64 < 0 || d64 >= N || s64 == d64;
   if (bad || (partner && partner[l] >= 0)) {   // invalid link, or a reversed duplicate (its primary works)

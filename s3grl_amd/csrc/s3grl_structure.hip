@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kCountBlock) void count_kernel(
     unsigned long long* __restrict__ tot_nodes_alg, HopSampling smp, int32_t* __restrict__ stash,
     int slot, int32_t* __restrict__ lvl_stash, const int32_t* __restrict__ cn_indptr,
     const int32_t* __restrict__ cn_indices, int full_p, uint32_t* __restrict__ ext, int64_t ext_stride,
-    int link_base) {
+    int link_base, const int32_t* __restrict__ perm) {
   extern __shared__ uint32_t smem[];
   const bool walks = walks_on(ws);
   // `cur` (the frontier as a bitmap, for levels too big for the frontier list) is only needed when
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kCountBlock) void count_kernel(
     mem = sampling ? smem + nbm * W + 8 + kHubWords + kCountList : nullptr;
   }
   const int tid = threadIdx.x;
-  const int l = link_base + blockIdx.x;
+  const int l = perm ? perm[link_base + blockIdx.x] : link_base + blockIdx.x;
   const int64_t s64 = links[2 * (int64_t)l], d64 = links[2 * (int64_t)l + 1];
   if (s64 < 0 || s64 >= N || d64 < 0 || d64 >= N || s64 == d64) {
     if (tid == 0) {
@@ -738,8 +738,11 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
                                 const int32_t* __restrict__ lvl_max, int64_t L, ClassBounds bound,
                                 int sparse_mode, ClassBounds sbound, const int32_t* __restrict__ e_cap,
                                 ClassBounds fbound, int bm_limit, int dm_max_n, int dm_class_mask,
-                                int32_t* __restrict__ class_count, int32_t* __restrict__ class_list) {
-  const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                int32_t* __restrict__ class_count, int32_t* __restrict__ class_list,
+                                const int32_t* __restrict__ perm) {
+  const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // (perm: the class lists come out in the plan's processing order, up to the order of the atomics)
+  const int64_t l = li < L ? (perm ? (int64_t)perm[li] : li) : L;
   const int n = l < L ? n_nodes[l] : 0;
   const int p = l < L ? p_nodes[l] : 0;
   int need = link_lds_need(n, p);
@@ -1546,7 +1549,7 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           const int32_t* partner, const int32_t* mirror_of, int32_t* n_nodes, int32_t* p_nodes,
                           int32_t* n_rows, int32_t* n_jobs, int32_t* lvl_max, int32_t* err_flag,
                           int64_t* tot_nodes_alg, HopSampling smp, int32_t* stash, int slot,
-                          int32_t* lvl_stash) {
+                          int32_t* lvl_stash, const int32_t* perm) {
   if (L == 0) return S3GRL_OK;
   const int W = words_for(g->num_nodes);
   const int nbm = (hops <= 1 || walks_on(ws)) ? 2 : 3;   // see count_kernel: no frontier bitmap for one hop
@@ -1572,7 +1575,7 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
                          (int)g->num_nodes, W, links, hops, plus, K, g->max_degree > kHubArmDegree ? 1 : 0, ws,
                          partner, mirror_of, n_nodes, p_nodes, n_rows, n_jobs, lvl_max, err_flag,
                          reinterpret_cast<unsigned long long*>(tot_nodes_alg), smp, stash, slot, lvl_stash, cn_ip,
-                         cn_ix, g->directed ? 1 : 0, static_cast<uint32_t*>(q), stride, (int)base);
+                         cn_ix, g->directed ? 1 : 0, static_cast<uint32_t*>(q), stride, (int)base, perm);
       S3GRL_HIP_TRY(hipGetLastError());
     }
     S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));   // the slices are released on return
@@ -1588,7 +1591,7 @@ s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_
                      g->max_degree > kHubArmDegree ? 1 : 0, ws, partner, mirror_of, n_nodes,
                      p_nodes, n_rows, n_jobs, lvl_max, err_flag,
                      reinterpret_cast<unsigned long long*>(tot_nodes_alg), smp, stash, slot, lvl_stash,
-                     cn_ip, cn_ix, g->directed ? 1 : 0, nullptr, 0, 0);
+                     cn_ip, cn_ix, g->directed ? 1 : 0, nullptr, 0, 0, perm);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -1673,10 +1676,41 @@ __global__ __launch_bounds__(kOrderThreads) void order_fill_kernel(
   }
 }
 
+// Plans with a processing order (launch_link_order): the gather takes the jobs link by link in that
+// order — neighbours in the order read the same rows of X — instead of longest first.
+__global__ void perm_jobs_kernel(const int32_t* __restrict__ perm, const int32_t* __restrict__ n_jobs, int64_t L,
+                                 int32_t* __restrict__ cnt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < L) cnt[i] = n_jobs[perm[i]];
+}
+
+__global__ void perm_fill_kernel(const int32_t* __restrict__ perm, const int32_t* __restrict__ n_jobs,
+                                 const int64_t* __restrict__ job_off, const int64_t* __restrict__ at, int64_t L,
+                                 int32_t* __restrict__ job_order) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L) return;
+  const int l = perm[i];
+  const int nj = n_jobs[l];
+  const int j0 = (int)job_off[l];
+  const int64_t a = at[i];
+  for (int j = 0; j < nj; ++j) job_order[a + j] = j0 + j;
+}
+
 s3grl_status launch_job_order(s3grl_context* ctx, const int32_t* n_nodes, const int32_t* n_jobs,
                               const int64_t* job_off, int64_t L, int32_t* hist /* [256] scratch */,
-                              int32_t* job_order) {
+                              int32_t* job_order, const int32_t* perm, int32_t* scratch_cnt,
+                              int64_t* scratch_off, int64_t* scan_ws) {
   if (L == 0) return S3GRL_OK;
+  if (perm) {
+    const unsigned grid = (unsigned)((L + 255) / 256);
+    hipLaunchKernelGGL(perm_jobs_kernel, dim3(grid), dim3(256), 0, ctx->stream, perm, n_jobs, L, scratch_cnt);
+    S3GRL_HIP_TRY(hipGetLastError());
+    S3GRL_TRY(launch_scan_i32_to_i64(ctx, scratch_cnt, L, scratch_off, scan_ws));
+    hipLaunchKernelGGL(perm_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, perm, n_jobs, job_off, scratch_off,
+                       L, job_order);
+    S3GRL_HIP_TRY(hipGetLastError());
+    return S3GRL_OK;
+  }
   S3GRL_HIP_TRY(hipMemsetAsync(hist, 0, kOrderBuckets * sizeof(int32_t), ctx->stream));
   const int64_t per_block = std::max<int64_t>((L + 255) / 256, 4 * kOrderThreads);
   const unsigned grid = (unsigned)((L + per_block - 1) / per_block);
@@ -1897,13 +1931,13 @@ s3grl_status launch_count1(s3grl_context* ctx, const s3grl_graph* g, const int64
                            int plus, int K, const int32_t* partner, const int32_t* mirror_of,
                            int32_t* n_nodes, int32_t* p_nodes, int32_t* n_rows, int32_t* n_jobs,
                            int32_t* lvl_max, int32_t* e_cap, int32_t* err_flag, int64_t* tot_nodes_alg,
-                           int64_t* tot_oriented) {
+                           int64_t* tot_oriented, const int32_t* perm) {
   if (L == 0) return S3GRL_OK;
   hipLaunchKernelGGL(count1_kernel, dim3((unsigned)((L + kCount1Waves - 1) / kCount1Waves)),
                      dim3(64 * kCount1Waves), 0, ctx->stream, g->indptr, g->indices, g->fwd_deg,
                      (int)g->num_nodes, links, L, plus, K, partner, mirror_of, n_nodes, p_nodes, n_rows,
                      n_jobs, lvl_max, e_cap, err_flag, reinterpret_cast<unsigned long long*>(tot_nodes_alg),
-                     reinterpret_cast<unsigned long long*>(tot_oriented));
+                     reinterpret_cast<unsigned long long*>(tot_oriented), perm);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -1911,7 +1945,8 @@ s3grl_status launch_count1(s3grl_context* ctx, const s3grl_graph* g, const int64
 s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_cap, int K,
                              const int32_t* n_nodes, const int32_t* p_nodes,
                              const int32_t* lvl_max, int64_t L, int32_t* class_count,
-                             int32_t* class_list, bool allow_hash, const int32_t* e_cap, int stash_slot) {
+                             int32_t* class_list, bool allow_hash, const int32_t* e_cap, int stash_slot,
+                             const int32_t* perm) {
   if (L == 0) return S3GRL_OK;
   ClassBounds cb = class_bounds(g->num_nodes, cn_cap, K);
   const bool dm = allow_hash && stash_slot > 0 && dm_mode_for(g);
@@ -1926,7 +1961,7 @@ s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_ca
                      class_bounds_full(cn_cap, K),
                      getenv("S3GRL_FORCE_BM_HBM") ? 0 : (1 << 30),   // test hook: bit matrices in HBM
                      dm ? std::min(stash_slot + 2, 65535) : 0, dm ? dm_class_mask_for(g, cn_cap, K) : 0,
-                     class_count, class_list);
+                     class_count, class_list, perm);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }

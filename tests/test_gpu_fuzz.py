@@ -85,6 +85,8 @@ def test_random_configuration(eng, monkeypatch, case):
         monkeypatch.setenv("S3GRL_SPLIT_SEG_SHIFT", "5")
     if case % 9 == 5:
         monkeypatch.setenv("S3GRL_FORCE_EXT_BITMAPS", "1")             # bitmaps in HBM slices (graphs beyond the LDS limit)
+    if case % 2 == 1:
+        monkeypatch.setenv("S3GRL_HUB_ORDER", "1")                     # big-graph processing order (by hub endpoint)
     G = eng.graph(A)
     f = eng.features(X, ["auto", "dense", "packed"][case % 3])
     res = eng.precompute(G, f, eng.links(links.T), mode="pos_plus" if plus else "pos", num_hops=hops, sign_k=K)

@@ -1188,6 +1188,46 @@ def test_bitmaps_in_hbm_change_nothing(eng, monkeypatch, name, hops, mode):
     G.close()
 
 
+@pytest.mark.parametrize("feat", ["dense", "packed"])
+@pytest.mark.parametrize("name,hops,mode", [("usair", 1, "pos"), ("usair", 2, "pos_plus"), ("cora", 3, "pos"),
+                                            ("rand300", 2, "pos_plus")])
+def test_hub_processing_order_changes_no_bit(eng, monkeypatch, name, hops, mode, feat):
+    """On big graphs a plan works on its links in the order of their higher-degree endpoint
+    (s3grl_relabel.hip launch_link_order: the sizing pass, the class lists of the link kernels, the
+    gather's job order) so that neighbouring workgroups read the same hub rows.  Only the order of the
+    WORK changes: every output — rows, row nodes, node lists, statistics — is bit for bit the
+    list-order plan's.  S3GRL_HUB_ORDER forces either road on a small fixture; split jobs included."""
+    import torch
+
+    g = load_extract(name)
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = np.random.default_rng(8).standard_normal((n, 70))
+    links = np.concatenate([g["links"], g["links"][:6, ::-1]])
+    G = eng.graph(A)
+    f = eng.features(X, feat)
+    L = eng.links(links.T)
+    for split in (False, True):
+        if split:
+            monkeypatch.setenv("S3GRL_SPLIT_T", "32")
+            monkeypatch.setenv("S3GRL_SPLIT_SEG_SHIFT", "4")
+        out = []
+        for hub in ("0", "1"):
+            monkeypatch.setenv("S3GRL_HUB_ORDER", hub)
+            plan = eng.plan(G, L, mode=mode, num_hops=hops, sign_k=3, full_stats=not split)
+            exp = [t.clone() for t in plan.export_subgraphs()]
+            st = dict(plan.stats)
+            st.pop("workspace_bytes", None)
+            out.append((exp, st, plan.run(f).clone(), plan.row_ptr().clone(), plan.row_nodes().clone()))
+            plan.close()
+        (ea, sa, ra, pa, na), (eb, sb, rb, pb, nb) = out
+        assert all(torch.equal(x, y) for x, y in zip(ea, eb))
+        assert sa == sb and torch.equal(pa, pb) and torch.equal(na, nb)
+        assert torch.equal(ra, rb)
+    f.close()
+    G.close()
+
+
 @pytest.mark.parametrize("mode", ["pos", "pos_plus"])
 def test_half_million_nodes_two_hops_vs_c(eng, mode):
     """A 500 000-node power-law graph, two hops: beyond the LDS bitmap limit.  The sizing pass keeps
