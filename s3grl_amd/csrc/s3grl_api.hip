@@ -371,6 +371,8 @@ s3grl_status s3grl_graph_create(s3grl_context* ctx, int64_t num_nodes, const int
       g->r_fwd_indices = t.fwd_indices;
       g->r_fwd_deg = t.fwd_deg;
     }
+    // and the neighbourhoods of its hubs, shared by all their links (s3grl_hub.hip)
+    if (st == S3GRL_OK && g->r_fwd_indptr) st = build_hub_cache(ctx, g);
   }
   if (st != S3GRL_OK) {
     s3grl_graph_destroy(g);
@@ -435,6 +437,7 @@ s3grl_status s3grl_graph_destroy(s3grl_graph* g) {
   g->ctx->arena.release(g->out_indices);
   g->ctx->arena.release(g->in_indptr);
   g->ctx->arena.release(g->in_indices);
+  release_hub_cache(g);
   delete g;
   return S3GRL_OK;
 }
@@ -669,6 +672,7 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
     S3GRL_TRY(launch_translate_links(ctx, g, plan->links, L, lr));
     links_walk = lr;
   }
+  if (!relabel) g_walk.hub = HubCache{};   // the cache is the degree-ordered graph's
   plan->relabelled = relabel;
   // Big graph, long list: the links are worked on in the order of their higher-degree endpoint
   // (launch_link_order) — sizing pass, link kernels (through the class lists) and gather.  Small graphs
@@ -681,12 +685,14 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
     S3GRL_TRY(launch_link_order(ctx, links_walk, L, g->num_nodes, g_walk.indptr, perm));
   }
   int32_t* e_cap = nullptr;
+  int64_t* x_cap = nullptr;   // one-hop plans: (LDS need << 32 | bound of the edges outside the hub's cache), -1: no hub
   if (onehop) {
     S3GRL_TRY(arena_alloc(ctx, (size_t)L, &e_cap, own));
     plan->e_cap = e_cap;
+    if (g_walk.hub.nh > 0 && !(cfg->flags & S3GRL_FLAG_COUNT_ONLY)) S3GRL_TRY(arena_alloc(ctx, (size_t)L, &x_cap, tr));
     S3GRL_TRY(launch_count1(ctx, &g_walk, links_walk, L, plus ? 1 : 0, K, partner, mirror_of, plan->n_nodes, p_nodes,
                             n_rows, n_jobs, lvl_max, e_cap, reinterpret_cast<int32_t*>(ds), st + 3 * kStatRow,
-                            st + 4 * kStatRow, perm));
+                            st + 4 * kStatRow, perm, x_cap));
   } else {
     S3GRL_TRY(launch_count(ctx, &g_walk, links_walk, L, cfg->num_hops, plus ? 1 : 0, K, ws,
                            partner, mirror_of,
@@ -700,7 +706,7 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   // PoS has no common-neighbour rows: the LDS classes are known without a round trip
   if (!plus)
     S3GRL_TRY(launch_classify(ctx, g, 1, K, plan->n_nodes, p_nodes, lvl_max, L, class_count, class_list,
-                              !sampling && !g->directed, e_cap, stash ? slot : 0, perm));
+                              !sampling && !g->directed, e_cap, stash ? slot : 0, perm, x_cap));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs, ds, 48 * 8, hipMemcpyDeviceToHost, ctx->stream));   // scalars + class counts
   S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_stats + 3 * kStatRow, st + 3 * kStatRow, 2 * kStatRow * sizeof(int64_t),
                                hipMemcpyDeviceToHost, ctx->stream));
@@ -723,7 +729,7 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   const int cn_cap = ((int)std::max<int64_t>(max_R - 2, 0) + 1) * ((relabel && plus) ? 3 : 1);
   if (plus) {
     S3GRL_TRY(launch_classify(ctx, g, cn_cap, K, plan->n_nodes, p_nodes, lvl_max, L, class_count,
-                              class_list, !sampling && !g->directed, e_cap, stash ? slot : 0, perm));
+                              class_list, !sampling && !g->directed, e_cap, stash ? slot : 0, perm, x_cap));
     S3GRL_HIP_TRY(hipMemcpyAsync(hs + 32, ds + 32, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
     S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
@@ -733,7 +739,7 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   std::memcpy(class_count_host, hs + 32, sizeof(class_count_host));
   if (getenv("S3GRL_DEBUG")) {
     fprintf(stderr, "[s3grl] L=%lld max_n=%lld classes:", (long long)L, (long long)max_n);
-    for (int c = 0; c < 21; ++c) fprintf(stderr, " %d", class_count_host[c]);
+    for (int c = 0; c < num_class_lists(); ++c) fprintf(stderr, " %d", class_count_host[c]);
     fprintf(stderr, "\n");
   }
   if (cfg->flags & S3GRL_FLAG_COUNT_ONLY) {   // sizing pass: sizes and offsets only
@@ -812,7 +818,8 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
                          plan->row_ptr, plan->job_off, coef_off, mirror_of, plan->c_ids,
                          plan->c_coef, plan->jobs, plan->job_z, plan->job_lim, plan->row_nodes, plan->lvl, st,
                          st + kStatRow, st + 2 * kStatRow, smp, stash, slot, e_cap, max_n,
-                         relabel ? g->old_of_new : nullptr, relabel ? g->new_of_old : nullptr, split_t, seg_shift));
+                         relabel ? g->old_of_new : nullptr, relabel ? g->new_of_old : nullptr, split_t, seg_shift,
+                         x_cap));
   if (split_t > 0) {   // pieces per job and their total (read with the statistics below)
     int32_t* pcnt;
     S3GRL_TRY(arena_alloc(ctx, (size_t)njobs, &pcnt, tr));
@@ -853,6 +860,11 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
                       "deg %lld  ops<K %lld  last op %lld  tail %lld\n",
               (long long)hs[16], (long long)hs[17], (long long)hs[18], (long long)hs[19],
               (long long)hs[20], (long long)hs[21]);
+      if (x_cap)
+        fprintf(stderr, "[s3grl] link_hub_kernel phase cycles (same slots): nodes %lld  ids+rows %lld  walk %lld  "
+                        "small csr %lld  passes %lld  tail %lld\n",
+                (long long)hs[16], (long long)hs[17], (long long)hs[18], (long long)hs[19], (long long)hs[20],
+                (long long)hs[21]);
       S3GRL_HIP_TRY(hipMemcpy(hs + 24, ds + 24, 8 * 8, hipMemcpyDeviceToHost));
       fprintf(stderr, "[s3grl] link_full_kernel, big class: merge %lld  hash+ids %lld  probes %lld  "
                       "csr+sort %lld  passes %lld   links %lld, columns in HBM for %lld\n",

@@ -1,0 +1,902 @@
+// Hub neighbourhoods: one-hop plans on big power-law graphs (reference utils.py:57-80 with num_hops = 1,
+// tuned_SIGN.py:153-175).
+//
+// A one-hop subgraph is S = {src, dst} ∪ N(src) ∪ N(dst).  When one endpoint is a hub h (thousands of
+// neighbours) nearly all of S is N(h) — and N(h), with every edge inside it, is the same for EVERY link
+// that has h as an endpoint (a split of a power-law graph holds hundreds of links per hub).
+// link_full_kernel (s3grl_onehop.inl) rediscovers that neighbourhood link by link: ~30 000 probes of the
+// oriented rows, a CSR build and a sort per row for a 3 000-node subgraph.  Here:
+//
+//   build_hub_cache   once per graph: for every node h with deg >= kHubMinDegree (no self-loop) the induced
+//                     adjacency of N(h) as a CSR whose columns are POSITIONS in h's sorted row (uint16),
+//                     rows ascending.  The edges h—x are implicit.
+//   link_hub_kernel   per link (h, o): local ids 0 = h, 1..c = N(h) in row order, then the nodes only o
+//                     brings (o itself when it is no neighbour of h, N(o) \ N(h)).  Only THOSE nodes' rows
+//                     are walked (Σ deg over N(o) \ N(h): a few thousand neighbour tests against the staged
+//                     row of h); the edges found are a small CSR next to the cached one, and every operator
+//                     is a pull over cache + star + small CSR.  The masked edge src—dst is the star edge
+//                     h—o: left out of o's row, of h's sum and of both degrees.
+//
+// Which links: count1_kernel decides per link — from the graph and the link alone (never from the rest
+// of the list: a link gives the same bits in a sharded and in an unsharded run) — hub = the endpoint of
+// higher (degree, then lower id), in the cache, Σ degree over N(other) <= kHubVolMax, LDS need within a
+// CU; classify_kernel then sorts them into kHubClasses LDS classes.  Everything else stays on
+// link_full_kernel.  Same rows and coefficients as there up to the summation order (cache entries in
+// row order, the star edge, then the found edges ascending — a fixed order).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+#include "s3grl_device.hpp"
+
+namespace s3grl {
+namespace {
+
+// Rows of a pull by their length (cached + found entries; the star edge comes on top).  Half of a hub's
+// neighbours have no edge inside the neighbourhood at all and nine in ten at most a handful: one LANE per
+// row up to kHubTinyRow entries, four lanes up to kHubLongRow, a whole wavefront beyond (at most
+// kHubLongCap rows per link, further ones stay with their four lanes).  The kernel is bound by
+// instruction issue: four lanes for every row cost 3.5x the instructions of this split.
+constexpr int kHubTinyRow = 4;
+constexpr int kHubLongRow = 48;
+constexpr int kHubLongCap = 128;
+constexpr int kHubShWords = 72;   // 40 of scan / counter words, 32 of row 0's partial sums
+#ifndef S3GRL_HUB_G
+#define S3GRL_HUB_G 4
+#endif
+
+__device__ __forceinline__ int lds_lower_bound(const int32_t* a, int n, int x) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// ---- the cache ---------------------------------------------------------------------------------------
+// eight lanes per node: Σ degree over the row, self-loop test, hub flag
+__global__ void hub_mark_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int64_t N,
+                                int min_deg, int32_t* __restrict__ flag, int32_t* __restrict__ voln) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t u = gid >> 3;
+  const int g = (int)(gid & 7);
+  if (u >= N) return;
+  const int b = indptr[u], e = indptr[u + 1];
+  long long sum = 0;
+  int loop = 0;
+  for (int k = b + g; k < e; k += 8) {
+    const int v = indices[k];
+    sum += indptr[v + 1] - indptr[v];
+    loop |= v == (int)u ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) {
+    sum += __shfl_xor(sum, o);
+    loop |= __shfl_xor(loop, o);
+  }
+  if (g == 0) {
+    voln[u] = (int32_t)min(sum, (long long)0x7fffffff);
+    const int d = e - b;
+    flag[u] = (d >= min_deg && d <= 65535 && !loop) ? 1 : 0;
+  }
+}
+
+__global__ void hub_list_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ flag,
+                                const int64_t* __restrict__ off, int64_t N, int32_t* __restrict__ slot,
+                                int32_t* __restrict__ hubs, int32_t* __restrict__ rows) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= N) return;
+  if (flag[u]) {
+    const int k = (int)off[u];
+    slot[u] = k;
+    hubs[k] = (int32_t)u;
+    rows[k] = indptr[u + 1] - indptr[u] + 1;   // one offset entry per neighbour + the end
+  } else {
+    slot[u] = -1;
+  }
+}
+
+// one wavefront per cached row (hub k, position p): N(v) ∩ N(h) for v = the p-th neighbour of h, as positions
+// in h's row.  FILL = false counts, FILL = true writes (ascending: the lanes walk N(v) in order).
+template <bool FILL>
+__global__ __launch_bounds__(256) void hub_rows_kernel(const int32_t* __restrict__ indptr,
+                                                       const int32_t* __restrict__ indices,
+                                                       const int32_t* __restrict__ hubs,
+                                                       const int64_t* __restrict__ row_base, int nh, int64_t rows_total,
+                                                       int32_t* __restrict__ cnt, const int64_t* __restrict__ abs_off,
+                                                       uint16_t* __restrict__ hcols) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows_total) return;
+  int lo = 0, hi = nh;   // the hub whose rows hold r: last k with row_base[k] <= r
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (row_base[mid] <= r) lo = mid; else hi = mid;
+  }
+  const int k = lo;
+  const int p = (int)(r - row_base[k]);
+  const int h = hubs[k];
+  const int32_t* __restrict__ H = indices + indptr[h];
+  const int c = indptr[h + 1] - indptr[h];
+  if (p >= c) {   // the end entry of the hub
+    if (!FILL && lane == 0) cnt[r] = 0;
+    return;
+  }
+  const int v = H[p];
+  const int32_t* __restrict__ row = indices + indptr[v];
+  const int len = indptr[v + 1] - indptr[v];
+  int total = 0;
+  for (int e0 = 0; e0 < len; e0 += 64) {
+    const int e = e0 + lane;
+    int pos = -1;
+    if (e < len) {
+      const int y = row[e];
+      int a = 0, b = c;
+      while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (H[mid] < y) a = mid + 1; else b = mid;
+      }
+      if (a < c && H[a] == y) pos = a;
+    }
+    const unsigned long long m = __ballot(pos >= 0);
+    if (FILL && pos >= 0) hcols[abs_off[r] + total + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)pos;
+    total += __popcll(m);
+  }
+  if (!FILL && lane == 0) cnt[r] = total;
+}
+
+// offsets of a hub's rows relative to its first column; first column of every hub
+__global__ void hub_offsets_kernel(const int64_t* __restrict__ row_base, int nh, int64_t rows_total,
+                                   const int64_t* __restrict__ abs_off, int32_t* __restrict__ hoff,
+                                   int64_t* __restrict__ col_base) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r <= nh) col_base[r] = abs_off[r < nh ? row_base[r] : rows_total];
+  if (r >= rows_total) return;
+  int lo = 0, hi = nh;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (row_base[mid] <= r) lo = mid; else hi = mid;
+  }
+  hoff[r] = (int32_t)(abs_off[r] - abs_off[row_base[lo]]);
+}
+
+// ---- the per-link kernel -----------------------------------------------------------------------------
+// LDS (dynamic): cn[cn_cap] cnpos[cn_cap] zbuf[4K] sh[40] longrows[kHubLongCap] dinv[n] offx[n+1] | region |
+// colsx[2·xcap] (uint16).  region = the state arrays cur[n], nxs[n] (float2) of the passes; before them it
+// holds the node list nl[n-1] (local ids 1..n-1: N(h) staged, then the other endpoint's nodes) and the list
+// of found edges, then the scatter cursors and the per-wave sort bitmaps.
+template <int T, int K>
+__global__ __launch_bounds__(T) void link_hub_kernel(const HubLinkArgs a, const int32_t* __restrict__ class_list,
+                                                     int count) {
+  extern __shared__ uint32_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int G = S3GRL_HUB_G;   // lanes per row of a pull
+  if ((int)blockIdx.x >= count) return;
+  const int32_t* __restrict__ indptr = a.indptr;
+  const int32_t* __restrict__ indices = a.indices;
+  auto ext = [&](int v) -> int { return a.old_of_new ? a.old_of_new[v] : v; };
+  unsigned long long t_prev = a.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+#define S3GRL_HSTAMP(idx)                                                \
+  if (a.dbg) {                                                           \
+    __syncthreads();                                                     \
+    const unsigned long long t_now = __builtin_amdgcn_s_memtime();       \
+    if (threadIdx.x == 0) atomicAdd(&a.dbg[idx], t_now - t_prev);        \
+    t_prev = t_now;                                                      \
+  }
+  const int l = class_list[blockIdx.x];
+  const int64_t noff = a.node_off[l];
+  const int n = (int)(a.node_off[l + 1] - noff);
+  const int xcap = (int)(a.x_cap[l] & 0xffffffffll);   // (classified here: the entry is >= 0)
+  const int xcap_e = (xcap + 1) & ~1;
+  const int mirror = a.mirror_of ? a.mirror_of[l] : -1;
+  const int64_t mrp = mirror >= 0 ? a.row_ptr[mirror] : -1;
+  const int cn_cap = a.cn_cap;
+  const int src = (int)a.links[2 * (int64_t)l], dst = (int)a.links[2 * (int64_t)l + 1];
+  const int cs = indptr[src + 1] - indptr[src], cd = indptr[dst + 1] - indptr[dst];
+  const bool src_hub = cs > cd || (cs == cd && src < dst);   // the rule of count1_kernel
+  const int h = src_hub ? src : dst, o = src_hub ? dst : src;
+  const int c = src_hub ? cs : cd, co = src_hub ? cd : cs;
+  const int32_t* __restrict__ Hrow = indices + indptr[h];
+  const int32_t* __restrict__ Orow = indices + indptr[o];
+  const int hk = a.hub.slot[h];
+  const int32_t* __restrict__ hoff_g = a.hub.hoff + a.hub.row_base[hk];
+  const uint16_t* __restrict__ hcols_g = a.hub.hcols + a.hub.col_base[hk];
+  const int64_t hub_entries = a.hub.col_base[hk + 1] - a.hub.col_base[hk];
+  // the hub's cached rows are staged in LDS (every pass walks all of them: from HBM / L2 each trip of a
+  // pass would be two dependent loads); hubs of more than 65 535 cached entries stay where they are
+  const bool staged = hub_stage_bytes(c, hub_entries) > 0;
+
+  int32_t* cn = reinterpret_cast<int32_t*>(smem);
+  int32_t* cnpos = cn + cn_cap;
+  float* zbuf = reinterpret_cast<float*>(cnpos + cn_cap);          // [2][K][2]
+  int* sh = reinterpret_cast<int*>(zbuf + 4 * K);                  // [kHubShWords]
+  float* red = reinterpret_cast<float*>(sh + 40);                      // [2 * T / 64]
+  uint16_t* longrows = reinterpret_cast<uint16_t*>(sh + kHubShWords);   // [kHubLongCap]
+  float* dinv = reinterpret_cast<float*>(sh + kHubShWords + kHubLongCap / 2);
+  int32_t* offx = reinterpret_cast<int32_t*>(dinv + n);            // [n + 1]
+  uint32_t* region = reinterpret_cast<uint32_t*>(offx + n + 1 + ((n + 1) & 1));
+  const int region_words = max(4 * n, n + xcap_e);
+  uint16_t* colsx = reinterpret_cast<uint16_t*>(region + region_words);   // [2 * xcap]
+  uint16_t* hoff_l = colsx + 2 * xcap_e;                                  // [c + 1] (staged)
+  uint16_t* hcols_l = hoff_l + (staged ? ((c + 2) & ~1) : 0);             // [hub_entries]
+  uint16_t* tier = hcols_l + (staged ? (((int)hub_entries + 1) & ~1) : 0);   // [n]: tiny rows from the front, four-lane rows from the back
+  auto hoff = [&](int t) -> int { return staged ? (int)hoff_l[t] : hoff_g[t]; };
+  auto hcols = [&](int k) -> int { return staged ? (int)hcols_l[k] : (int)hcols_g[k]; };
+  float2* cur = reinterpret_cast<float2*>(region);
+  float2* nxs = cur + n;
+  int32_t* nl = reinterpret_cast<int32_t*>(region);                // [n - 1]
+  uint32_t* elist = region + n;                                    // [xcap]
+  int32_t* cursor = reinterpret_cast<int32_t*>(region);            // [n] (nl is dead by then)
+
+  // ---- the nodes: N(h) staged, then what only the other endpoint brings ---------------------------------
+  for (int e = tid; e < c; e += T) nl[e] = Hrow[e];
+  if (staged) {
+    for (int e = tid; e <= c; e += T) hoff_l[e] = (uint16_t)hoff_g[e];
+    for (int e = tid; e < (int)hub_entries; e += T) hcols_l[e] = hcols_g[e];
+  }
+  if (tid == 0) {
+    sh[29] = 0;   // long rows registered
+    sh[30] = 0;   // edges found
+  }
+  __syncthreads();
+  const int pos_o = lds_lower_bound(nl, c, o);
+  const bool o_in_h = pos_o < c && nl[pos_o] == o;
+  const int lo = o_in_h ? 1 + pos_o : c + 1;      // local id of the other endpoint
+  const int qbase = c + (o_in_h ? 0 : 1);         // list position of the first node of N(o) \ N(h)
+  const int tn = n - 1 - qbase;                   // how many of those the sizing pass counted
+  if (!o_in_h && tid == 0 && c < n - 1) nl[c] = o;
+  {
+    // ordered compaction of row(o): the new nodes (neither h, o nor in N(h)) and — PoS Plus — the common
+    // neighbours (in N(h); o itself when it carries a self-loop: tuned_SIGN.py:233 on the masked matrix)
+    const int per = (co + T - 1) / T;
+    const int e0 = min(tid * per, co), e1 = min(e0 + per, co);
+    int packed = 0;
+    for (int e = e0; e < e1; ++e) {
+      const int x = Orow[e];
+      const int p = lds_lower_bound(nl, c, x);
+      const bool in_h = p < c && nl[p] == x;
+      packed += (!in_h && x != h && x != o) ? 1 : 0;
+      packed += (a.plus && (in_h || x == o)) ? (1 << 16) : 0;
+    }
+    int total;
+    int run = block_excl_scan<T>(packed, sh, total);
+    for (int e = e0; e < e1; ++e) {
+      const int x = Orow[e];
+      const int p = lds_lower_bound(nl, c, x);
+      const bool in_h = p < c && nl[p] == x;
+      if (!in_h && x != h && x != o) {
+        const int pos = qbase + (run & 0xffff);
+        if (pos < n - 1) nl[pos] = x;
+        run += 1;
+      }
+      if (a.plus && (in_h || x == o)) {
+        if ((run >> 16) < cn_cap) cn[run >> 16] = x;
+        run += 1 << 16;
+      }
+    }
+  }
+  __syncthreads();
+  S3GRL_HSTAMP(0)
+  const int32_t* Tl = nl + qbase;
+  // output position of a local id: the two endpoints first (hop 0 of the exported lists), h before o
+  auto opos = [&](int t) -> int { return t == 0 ? 0 : (t == lo ? 1 : (t < lo ? t + 1 : t)); };
+  long long vol_local = tid == 0 ? (long long)a.hub.voln[h] + c : 0ll;
+  for (int t = tid; t < n; t += T) {
+    const int v = t == 0 ? h : nl[t - 1];
+    a.c_ids[noff + opos(t)] = ext(v);
+    if (t > c) vol_local += indptr[v + 1] - indptr[v];
+  }
+  const int64_t rp = a.row_ptr[l];
+  const int R = (int)(a.row_ptr[l + 1] - rp);
+  if (a.plus && tid < 64) {
+    const int cc = R - 2;
+    if (a.old_of_new && cc > 1) {   // rows in ascending order of the caller's ids (see link_kernel)
+      int* key = cn + cc;
+      int* srt = cn + 2 * cc;
+      for (int i = tid; i < cc; i += 64) key[i] = a.old_of_new[cn[i]];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      for (int i = tid; i < cc; i += 64) {
+        const int kk = key[i];
+        int r = 0;
+        for (int j = 0; j < cc; ++j) r += key[j] < kk ? 1 : 0;
+        srt[r] = cn[i];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      for (int i = tid; i < cc; i += 64) cn[i] = srt[i];
+    }
+  }
+  if (tid == 0)
+    for (int dd = 0; dd < kMaxLevels; ++dd) a.lvl[(int64_t)l * kMaxLevels + dd] = dd == 0 ? 2 : n;
+  __syncthreads();
+  for (int r = tid; r < R; r += T) {
+    const int node = r == 0 ? src : (r == 1 ? dst : cn[r - 2]);
+    a.row_nodes[rp + r] = ext(node);
+    if (mirror >= 0) a.row_nodes[mrp + r] = ext(r == 0 ? dst : (r == 1 ? src : cn[r - 2]));
+    if (r >= 2) cnpos[r - 2] = node == o ? lo : 1 + lds_lower_bound(nl, c, node);
+  }
+  const int pos_src = src_hub ? 0 : lo, pos_dst = src_hub ? lo : 0;
+  S3GRL_HSTAMP(1)
+
+  // ---- the edges the cache does not hold: rows of the other endpoint's nodes (utils.py:76-80) ----------
+  // The rows are walked FLAT — entry e of their concatenation by thread e mod T — because they are rows of
+  // the graph, not oriented rows: one neighbour of o that is itself a hub would pin four lanes for
+  // hundreds of trips.  qoff (in dinv's space) = running offsets of the walked rows, qstart (in offx's) =
+  // where each row starts in `indices`.
+  const int qn = n - 1 - c;                      // walked rows: list positions c .. n-2, local ids c+1 .. n-1
+  int* qoff = reinterpret_cast<int*>(dinv);      // [qn + 1]
+  int* qstart = offx;                            // [qn]
+  {
+    const int per = (qn + T - 1) / T;
+    const int r0 = min(tid * per, qn), r1 = min(r0 + per, qn);
+    int mine = 0;
+    for (int r = r0; r < r1; ++r) {
+      const int v = nl[c + r];
+      mine += indptr[v + 1] - indptr[v];
+    }
+    int total;
+    int run = block_excl_scan<T>(mine, sh, total);
+    for (int r = r0; r < r1; ++r) {
+      const int v = nl[c + r];
+      const int b = indptr[v];
+      qoff[r] = run;
+      qstart[r] = b;
+      run += indptr[v + 1] - b;
+    }
+    if (tid == 0) qoff[qn] = total;
+  }
+  __syncthreads();
+  const int walk_total = qoff[qn];
+  for (int e0 = 0; e0 < walk_total; e0 += T) {
+    const int e = e0 + tid;
+    const bool valid = e < walk_total;
+    int i = 0, j = -1;
+    if (valid) {
+      int ra = 0, rb = qn;   // the row holding entry e: last r with qoff[r] <= e
+      while (rb - ra > 1) {
+        const int mid = (ra + rb) >> 1;
+        if (qoff[mid] <= e) ra = mid; else rb = mid;
+      }
+      const int u = indices[qstart[ra] + (e - qoff[ra])];
+      i = c + 1 + ra;
+      const int p = lds_lower_bound(nl, c, u);
+      if (p < c && nl[p] == u) {
+        j = 1 + p;
+      } else if (!o_in_h && u == o) {
+        j = c + 1;
+      } else {
+        const int p2 = lds_lower_bound(Tl, tn, u);
+        if (p2 < tn && Tl[p2] == u) j = qbase + 1 + p2;
+      }
+    }
+    // an edge between two of the walked rows shows up from both: kept from the lower one
+    const bool found = valid && j >= 0 && (j <= c || j >= i);
+    const unsigned long long fm = __ballot(found);
+    int base = 0;
+    if (fm) {
+      const int leader = __ffsll((long long)fm) - 1;
+      if (lane == leader) base = atomicAdd(&sh[30], __popcll(fm));
+      base = __shfl(base, leader);
+    }
+    if (found) {
+      const int k = base + __popcll(fm & ((1ull << lane) - 1ull));
+      if (k < xcap) elist[k] = ((uint32_t)i << 16) | (uint32_t)j;
+    }
+  }
+  __syncthreads();   // nl, qoff, qstart dead from here
+  S3GRL_HSTAMP(2)
+  const int found_edges = min(sh[30], xcap);
+  for (int t = tid; t <= n; t += T) offx[t] = 0;
+  __syncthreads();
+  for (int k = tid; k < found_edges; k += T) {   // degrees of the small CSR
+    const uint32_t w = elist[k];
+    const int i = (int)(w >> 16), j = (int)(w & 0xffffu);
+    atomicAdd(&offx[i], 1);
+    if (i != j) atomicAdd(&offx[j], 1);
+  }
+  __syncthreads();
+
+  // ---- degrees, D^-1/2 (inf -> 0), the small CSR ---------------------------------------------------------
+  long long edges_local = 0;
+  {
+    const int per = (n + T - 1) / T;
+    const int t0 = min(tid * per, n), t1 = min(t0 + per, n);
+    // the rows' tiers in the pulls, in ascending row order (the lanes of a wavefront then write
+    // neighbouring coefficients): tiny rows from the front of `tier`, four-lane rows from its back; row 0
+    // — h, the sum over its whole row — is summed by the whole workgroup
+    auto tier_of = [&](int t, int len) -> int { return t == 0 ? -1 : (len <= kHubTinyRow ? 0 : (len <= kHubLongRow ? 1 : 2)); };
+    int mine = 0, packed = 0;
+    for (int t = t0; t < t1; ++t) {
+      const int dgx = offx[t];
+      const int cached = (t >= 1 && t <= c) ? hoff(t) - hoff(t - 1) : 0;
+      const int tr = tier_of(t, dgx + cached);
+      mine += dgx;
+      packed += tr == 0 ? 1 : (tr >= 1 ? (1 << 16) : 0);   // (long rows beyond the cap join the four-lane ones)
+    }
+    int total, ptotal;
+    int run = block_excl_scan<T>(mine, sh, total);
+    int prun = block_excl_scan<T>(packed, sh, ptotal);
+    if (tid == 0) {
+      sh[33] = ptotal & 0xffff;
+      sh[34] = ptotal >> 16;
+    }
+    for (int t = t0; t < t1; ++t) {
+      const int dgx = offx[t];
+      const int cached = (t >= 1 && t <= c) ? hoff(t) - hoff(t - 1) : 0;
+      const int star = t == 0 ? c - (o_in_h ? 1 : 0) : ((t <= c && t != lo) ? 1 : 0);
+      const int dg = dgx + cached + star;
+      edges_local += dg;
+      const int tr = tier_of(t, dgx + cached);
+      if (tr == 0) {
+        tier[prun & 0xffff] = (uint16_t)t;
+        prun += 1;
+      } else if (tr >= 1) {
+        // a slot in the four-lane list either way; long rows that get a wavefront leave a hole marked 0
+        int q = kHubLongCap;
+        if (tr == 2) q = atomicAdd(&sh[29], 1);
+        if (q < kHubLongCap) longrows[q] = (uint16_t)t;
+        tier[n - 1 - (prun >> 16)] = q < kHubLongCap ? (uint16_t)0 : (uint16_t)t;
+        prun += 1 << 16;
+      }
+      dinv[t] = dg > 0 ? 1.0f / sqrtf((float)dg) : 0.0f;
+      offx[t] = run;
+      cursor[t] = run;
+      run += dgx;
+    }
+    if (tid == 0) offx[n] = total;
+  }
+  __syncthreads();
+  for (int k = tid; k < found_edges; k += T) {
+    const uint32_t w = elist[k];
+    const int i = (int)(w >> 16), j = (int)(w & 0xffffu);
+    colsx[atomicAdd(&cursor[i], 1)] = (uint16_t)j;
+    if (i != j) colsx[atomicAdd(&cursor[j], 1)] = (uint16_t)i;
+  }
+  {
+    // every row ascending (a fixed summation order).  Nearly all rows of the small CSR are empty or hold
+    // one entry: the rows that need sorting are collected first (2..16 entries: by rank, four per
+    // wavefront; longer ones one per wavefront: by rank up to 64 entries, through a per-wave bitmap of the
+    // n local ids beyond).  Lists in the region behind the cursors / bitmaps (dead edge list).
+    const int WB = (n + 31) >> 5;
+    uint32_t* wbm = region + wv * WB;
+    uint32_t* list_a = region + 2 * n;   // [n]
+    uint32_t* list_b = region + 3 * n;   // [n]
+    if (tid == 0) {
+      sh[31] = 0;
+      sh[32] = 0;
+    }
+    __syncthreads();   // (also: the scatter is complete, cursor dead)
+    for (int r = tid; r < n; r += T) {
+      const int len = offx[r + 1] - offx[r];
+      if (len > 16) list_b[atomicAdd(&sh[32], 1)] = (uint32_t)r;
+      else if (len > 1) list_a[atomicAdd(&sh[31], 1)] = (uint32_t)r;
+    }
+    __syncthreads();
+    const int na = sh[31], nb = sh[32];
+    const int sub = lane >> 4, sl = lane & 15;
+    for (int q0 = wv * 4; q0 < na; q0 += (T / 64) * 4) {
+      const bool mine = q0 + sub < na;
+      const int r = (int)list_a[min(q0 + sub, na - 1)];
+      const int b = offx[r], len = offx[r + 1] - b;
+      const int x = mine && sl < len ? (int)colsx[b + sl] : 0x7fffffff;
+      int rank = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) rank += __shfl(x, (lane & 48) + k) < x ? 1 : 0;
+      if (mine && sl < len) colsx[b + rank] = (uint16_t)x;
+    }
+    for (int q = wv; q < nb; q += T / 64) {
+      const int r = (int)list_b[q];
+      const int b = offx[r], len = offx[r + 1] - b;
+      if (len <= 64) {
+        const int x = lane < len ? (int)colsx[b + lane] : 0x7fffffff;
+        int rank = 0;
+        for (int k = 0; k < len; ++k) rank += __shfl(x, k) < x ? 1 : 0;
+        if (lane < len) colsx[b + rank] = (uint16_t)x;
+      } else {
+        for (int w = lane; w < WB; w += 64) wbm[w] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < len; k += 64) {
+          const int cc = colsx[b + k];
+          atomicOr(&wbm[cc >> 5], 1u << (cc & 31));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        int base = b;
+        for (int w0 = 0; w0 < WB; w0 += 64) {
+          uint32_t word = w0 + lane < WB ? wbm[w0 + lane] : 0u;
+          const int cnt = __popc(word);
+          int inc = cnt;
+#pragma unroll
+          for (int oo = 1; oo < 64; oo <<= 1) {
+            const int t = __shfl_up(inc, oo);
+            if (lane >= oo) inc += t;
+          }
+          int k = base + inc - cnt;
+          while (word) {
+            const int bit = __ffs(word) - 1;
+            word &= word - 1;
+            colsx[k++] = (uint16_t)((w0 + lane) * 32 + bit);
+          }
+          base += __shfl(inc, 63);
+        }
+      }
+    }
+  }
+  __syncthreads();   // the region becomes the state arrays
+  S3GRL_HSTAMP(3)
+  const int nlong = min(sh[29], kHubLongCap), ntiny = sh[33], nmid = sh[34];
+
+  // ---- per row pair: K pulls over cache + star + small CSR -----------------------------------------------
+  const int npairs = (R + 1) / 2;
+  for (int pr = 0; pr < npairs; ++pr) {
+    const int64_t jid = a.job_off[l] + pr;
+    const int64_t coff = a.coef_off ? a.coef_off[jid] : noff;
+    const int node_a = pr == 0 ? src : cn[2 * pr - 2];
+    const int node_b = pr == 0 ? dst : (2 * pr + 1 < R ? cn[2 * pr - 1] : -1);
+    const int la = pr == 0 ? pos_src : cnpos[2 * pr - 2];
+    const int lb = pr == 0 ? pos_dst : (node_b >= 0 ? cnpos[2 * pr - 1] : -1);
+    for (int w = tid; w < n; w += T)
+      cur[w] = make_float2(w == la ? dinv[w] : 0.f, w == lb ? dinv[w] : 0.f);
+    if (tid < 4 * K) zbuf[tid] = 0.f;
+    __syncthreads();
+    float2* s_in = cur;
+    float2* s_out = nxs;
+    float2* coef = reinterpret_cast<float2*>(a.c_coef) + coff * K;   // [K][n] float2
+    const bool split = a.split_t > 0 && n > a.split_t;               // coefficients piece by piece (link_kernel)
+    auto cidx_split = [&](int i, int t) -> int64_t {
+      const int s0 = (t >> a.seg_shift) << a.seg_shift;
+      const int len = min(1 << a.seg_shift, n - s0);
+      return (int64_t)s0 * K + (int64_t)i * len + (t - s0);
+    };
+#pragma unroll 1
+    for (int i = 0; i < K; ++i) {
+      const int g = tid & (G - 1);
+      float2* coef_i = coef + (int64_t)i * n;   // (unsplit lists: operator-major)
+      auto commit = [&](int t, float ax, float ay) {
+        const float dw = dinv[t];
+        const float rx = dw * ax, ry = dw * ay;
+        s_out[t] = make_float2(dw * rx, dw * ry);
+        const int op = opos(t);
+        if (!split) coef_i[op] = make_float2(rx, ry);
+        else coef[cidx_split(i, op)] = make_float2(rx, ry);
+        // label column of operator i+1: r[src] + r[dst]  (tuned_SIGN.py:177-185)
+        if (t == pos_src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
+        if (t == pos_dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
+      };
+      {   // row 0: all of h's row but the masked edge, in slices of the workgroup (fixed reduction tree)
+        float ax = 0.f, ay = 0.f;
+        for (int p = tid; p < c; p += T) {
+          if (1 + p != lo) {
+            const float2 sv = s_in[1 + p];
+            ax += sv.x;
+            ay += sv.y;
+          }
+        }
+#pragma unroll
+        for (int oo = 32; oo > 0; oo >>= 1) {
+          ax += __shfl_xor(ax, oo);
+          ay += __shfl_xor(ay, oo);
+        }
+        if (lane == 0) {
+          red[2 * wv] = ax;
+          red[2 * wv + 1] = ay;
+        }
+      }
+      for (int q = tid; q < ntiny; q += T) {   // one lane per tiny row: star, cached, found
+        const int t = tier[q];
+        float ax = 0.f, ay = 0.f;
+        if (t <= c) {
+          if (t != lo) {
+            const float2 sv = s_in[0];
+            ax = sv.x;
+            ay = sv.y;
+          }
+          const int k1 = hoff(t);
+          for (int k = hoff(t - 1); k < k1; ++k) {
+            const float2 sv = s_in[1 + hcols(k)];
+            ax += sv.x;
+            ay += sv.y;
+          }
+        }
+        const int k1 = offx[t + 1];
+        for (int k = offx[t]; k < k1; ++k) {
+          const float2 sv = s_in[colsx[k]];
+          ax += sv.x;
+          ay += sv.y;
+        }
+        commit(t, ax, ay);
+      }
+      for (int base = 0; base < nmid; base += T / G) {   // G lanes per row
+        const int q = base + tid / G;
+        const int t = tier[n - 1 - min(q, nmid - 1)];
+        const bool mine = q < nmid && t != 0;   // (0: a long row, summed by a wavefront below)
+        float ax = 0.f, ay = 0.f;
+        if (mine) {
+          if (t <= c) {
+            const int k1 = hoff(t);
+            for (int k = hoff(t - 1) + g; k < k1; k += G) {
+              const float2 sv = s_in[1 + hcols(k)];
+              ax += sv.x;
+              ay += sv.y;
+            }
+            if (g == 0 && t != lo) {
+              const float2 sv = s_in[0];
+              ax += sv.x;
+              ay += sv.y;
+            }
+          }
+          const int k1 = offx[t + 1];
+          for (int k = offx[t] + g; k < k1; k += G) {
+            const float2 sv = s_in[colsx[k]];
+            ax += sv.x;
+            ay += sv.y;
+          }
+        }
+#pragma unroll
+        for (int oo = G / 2; oo > 0; oo >>= 1) {
+          ax += __shfl_xor(ax, oo);
+          ay += __shfl_xor(ay, oo);
+        }
+        if (mine && g == 0) commit(t, ax, ay);
+      }
+      for (int q = wv; q < nlong; q += T / 64) {   // one wavefront per long row
+        const int t = longrows[q];
+        float ax = 0.f, ay = 0.f;
+        {
+          if (t <= c) {
+            const int k1 = hoff(t);
+            for (int k = hoff(t - 1) + lane; k < k1; k += 64) {
+              const float2 sv = s_in[1 + hcols(k)];
+              ax += sv.x;
+              ay += sv.y;
+            }
+            if (lane == 0 && t != lo) {
+              const float2 sv = s_in[0];
+              ax += sv.x;
+              ay += sv.y;
+            }
+          }
+          const int k1 = offx[t + 1];
+          for (int k = offx[t] + lane; k < k1; k += 64) {
+            const float2 sv = s_in[colsx[k]];
+            ax += sv.x;
+            ay += sv.y;
+          }
+        }
+#pragma unroll
+        for (int oo = 32; oo > 0; oo >>= 1) {
+          ax += __shfl_xor(ax, oo);
+          ay += __shfl_xor(ay, oo);
+        }
+        if (lane == 0) commit(t, ax, ay);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        float ax = 0.f, ay = 0.f;
+        for (int w = 0; w < T / 64; ++w) {
+          ax += red[2 * w];
+          ay += red[2 * w + 1];
+        }
+        commit(0, ax, ay);
+      }
+      __syncthreads();
+      float2* tmp2 = s_in;
+      s_in = s_out;
+      s_out = tmp2;
+    }
+    if (tid < 2 * K) {
+      const int i = tid >> 1, r = tid & 1;
+      a.job_z[(jid * K + i) * 2 + r] = zbuf[(0 * K + i) * 2 + r] + zbuf[(1 * K + i) * 2 + r];
+    }
+    if (tid < K) a.job_lim[jid * K + tid] = n;   // one hop: every operator reaches the whole list
+    if (tid == 0) {
+      Job j;
+      j.coef_off = coff * K;
+      j.ids_off = noff;
+      j.out_row = rp + 2 * pr;
+      j.link = l;
+      j.support = n;
+      j.node_a = ext(node_a);
+      j.node_b = node_b >= 0 ? ext(node_b) : -1;
+      j.z_a = (node_a == src || node_a == dst) ? 1 : 0;
+      j.z_b = (node_b == src || node_b == dst) ? 1 : 0;
+      j.mirror_row = mirror >= 0 ? mrp + 2 * pr : -1;
+      j.mirror_swap = pr == 0 ? 1 : 0;
+      j.split = split ? 1 : 0;
+      a.jobs[jid] = j;
+      atomicAdd(stat_slot(a.tot_support), (unsigned long long)n * (mirror >= 0 ? 2ull : 1ull));
+    }
+    __syncthreads();
+  }
+  S3GRL_HSTAMP(4)
+  // totals: Σ induced entries, Σ degrees in the graph (64-bit block sums through LDS)
+  {
+    long long* red = reinterpret_cast<long long*>(region);   // state arrays are dead
+#pragma unroll
+    for (int oo = 32; oo > 0; oo >>= 1) {
+      edges_local += __shfl_xor(edges_local, oo);
+      vol_local += __shfl_xor(vol_local, oo);
+    }
+    if (lane == 0) {
+      red[2 * wv] = edges_local;
+      red[2 * wv + 1] = vol_local;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      long long e = 0, v = 0;
+      for (int w = 0; w < T / 64; ++w) {
+        e += red[2 * w];
+        v += red[2 * w + 1];
+      }
+      atomicAdd(stat_slot(a.tot_edges), (unsigned long long)e * (mirror >= 0 ? 2ull : 1ull));
+      atomicAdd(stat_slot(a.tot_vol), (unsigned long long)v * (mirror >= 0 ? 2ull : 1ull));
+    }
+  }
+  S3GRL_HSTAMP(5)
+#undef S3GRL_HSTAMP
+}
+
+template <int T, int K>
+s3grl_status launch_hub_t(const HubLinkArgs& a, int cls, const int32_t* class_list, int count, hipStream_t stream) {
+  const size_t lds = (size_t)4 * hub_fixed_words(a.cn_cap, K) + (size_t)hub_class_bound(cls, a.cn_cap, K);
+  auto kern = link_hub_kernel<T, K>;
+  S3GRL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(T), lds, stream, a, class_list, count);
+  S3GRL_HIP_TRY(hipGetLastError());
+  return S3GRL_OK;
+}
+
+template <int K>
+s3grl_status launch_hub_k(const HubLinkArgs& a, int cls, const int32_t* class_list, int count, hipStream_t stream) {
+  int t = cls == 0 ? 128 : (cls == 1 ? 256 : (cls == 2 ? 512 : 1024));
+  {
+    char name[32];   // tuning hook
+    snprintf(name, sizeof(name), "S3GRL_TH_CLASS%d", cls);
+    if (const char* e = getenv(name)) t = atoi(e);
+  }
+  if (t <= 128) return launch_hub_t<128, K>(a, cls, class_list, count, stream);
+  if (t <= 256) return launch_hub_t<256, K>(a, cls, class_list, count, stream);
+  if (t <= 512) return launch_hub_t<512, K>(a, cls, class_list, count, stream);
+  return launch_hub_t<1024, K>(a, cls, class_list, count, stream);
+}
+
+}  // namespace
+
+int hub_fixed_words(int cn_cap, int K) { return 2 * cn_cap + 4 * K + kHubShWords + kHubLongCap / 2; }
+
+int hub_class_bound(int cls, int cn_cap, int K) {
+  static const int nominal[kHubClasses] = {20480, 40960, 81920, 163840};
+  const int avail = 163840 - 4 * hub_fixed_words(cn_cap, K);
+  return std::min(nominal[cls] - (cls < kHubClasses - 1 ? 4 * hub_fixed_words(cn_cap, K) : 0), avail);
+}
+
+s3grl_status launch_hub_class(s3grl_context* ctx, const HubLinkArgs& a, int K, int cls, const int32_t* class_list,
+                              int count, hipStream_t stream) {
+  (void)ctx;
+  if (count <= 0) return S3GRL_OK;
+  switch (K) {
+    case 1: return launch_hub_k<1>(a, cls, class_list, count, stream);
+    case 2: return launch_hub_k<2>(a, cls, class_list, count, stream);
+    case 3: return launch_hub_k<3>(a, cls, class_list, count, stream);
+    case 4: return launch_hub_k<4>(a, cls, class_list, count, stream);
+    case 5: return launch_hub_k<5>(a, cls, class_list, count, stream);
+    case 6: return launch_hub_k<6>(a, cls, class_list, count, stream);
+    case 7: return launch_hub_k<7>(a, cls, class_list, count, stream);
+    case 8: return launch_hub_k<8>(a, cls, class_list, count, stream);
+    default: return S3GRL_ERR_INVALID_ARGUMENT;
+  }
+}
+
+void release_hub_cache(s3grl_graph* g) {
+  HubCache& hc = g->hub;
+  g->ctx->arena.release(hc.slot);
+  g->ctx->arena.release(hc.voln);
+  g->ctx->arena.release(hc.row_base);
+  g->ctx->arena.release(hc.col_base);
+  g->ctx->arena.release(hc.hoff);
+  g->ctx->arena.release(hc.hcols);
+  hc = HubCache{};
+}
+
+// The cache of the degree-ordered graph (the one one-hop plans walk).  Nothing is built — and every link
+// stays on link_full_kernel — when the graph has no node of kHubMinDegree neighbours, or when the induced
+// neighbourhoods would take more than 1 GiB (dense hubs: their links are no cheaper this way).
+s3grl_status build_hub_cache(s3grl_context* ctx, s3grl_graph* g) {
+  if (!g->r_indptr || getenv("S3GRL_NO_HUB_CACHE")) return S3GRL_OK;
+  int min_deg = kHubMinDegree;
+  if (const char* e = getenv("S3GRL_HUB_MIN_DEG")) min_deg = std::max(2, atoi(e));   // test / tuning hook
+  if (g->max_degree < min_deg) return S3GRL_OK;
+  const int64_t N = g->num_nodes;
+  const int32_t* indptr = g->r_indptr;
+  const int32_t* indices = g->r_indices;
+  HubCache hc;
+  Transient tmp{ctx, {}};
+  auto talloc = [&](size_t bytes, void** p) -> s3grl_status {
+    S3GRL_TRY(ctx->arena.alloc(std::max<size_t>(bytes, 16), p));
+    tmp.ptrs.push_back(*p);
+    return S3GRL_OK;
+  };
+  void *flag_v, *off_v, *ws_v, *q;
+  S3GRL_TRY(talloc((size_t)N * 4, &flag_v));
+  S3GRL_TRY(talloc((size_t)(N + 1) * 8, &off_v));
+  S3GRL_TRY(talloc((size_t)scan_workspace_elems(N) * 8, &ws_v));
+  int32_t* flag = static_cast<int32_t*>(flag_v);
+  int64_t* off = static_cast<int64_t*>(off_v);
+  S3GRL_TRY(ctx->arena.alloc((size_t)N * 4, &q));
+  hc.slot = static_cast<int32_t*>(q);
+  S3GRL_TRY(ctx->arena.alloc((size_t)N * 4, &q));
+  hc.voln = static_cast<int32_t*>(q);
+  g->hub = hc;   // (released with the graph from here on, also on an error below)
+  hipLaunchKernelGGL(hub_mark_kernel, dim3((unsigned)((N * 8 + 255) / 256)), dim3(256), 0, ctx->stream, indptr,
+                     indices, N, min_deg, flag, hc.voln);
+  S3GRL_HIP_TRY(hipGetLastError());
+  S3GRL_TRY(launch_scan_i32_to_i64(ctx, flag, N, off, static_cast<int64_t*>(ws_v)));
+  S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_scalars, off + N, 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const int64_t nh = ctx->h_scalars[0];
+  if (nh == 0 || nh >= (int64_t)1 << 24) {
+    S3GRL_HIP_TRY(hipMemsetAsync(hc.slot, 0xff, (size_t)N * 4, ctx->stream));
+    S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return S3GRL_OK;
+  }
+  void *hubs_v, *rows_v, *ws2_v;
+  S3GRL_TRY(talloc((size_t)nh * 4, &hubs_v));
+  S3GRL_TRY(talloc((size_t)nh * 4, &rows_v));
+  S3GRL_TRY(talloc((size_t)scan_workspace_elems(nh) * 8, &ws2_v));
+  hipLaunchKernelGGL(hub_list_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, indptr, flag, off,
+                     N, hc.slot, static_cast<int32_t*>(hubs_v), static_cast<int32_t*>(rows_v));
+  S3GRL_HIP_TRY(hipGetLastError());
+  S3GRL_TRY(ctx->arena.alloc((size_t)(nh + 1) * 8, &q));
+  g->hub.row_base = hc.row_base = static_cast<int64_t*>(q);
+  S3GRL_TRY(ctx->arena.alloc((size_t)(nh + 1) * 8, &q));
+  g->hub.col_base = hc.col_base = static_cast<int64_t*>(q);
+  S3GRL_TRY(launch_scan_i32_to_i64(ctx, static_cast<int32_t*>(rows_v), nh, hc.row_base, static_cast<int64_t*>(ws2_v)));
+  S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_scalars, hc.row_base + nh, 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const int64_t rows_total = ctx->h_scalars[0];
+  void *cnt_v, *abs_v, *ws3_v;
+  S3GRL_TRY(talloc((size_t)rows_total * 4, &cnt_v));
+  S3GRL_TRY(talloc((size_t)(rows_total + 1) * 8, &abs_v));
+  S3GRL_TRY(talloc((size_t)scan_workspace_elems(rows_total) * 8, &ws3_v));
+  const unsigned rgrid = (unsigned)((rows_total + 3) / 4);
+  hipLaunchKernelGGL(hub_rows_kernel<false>, dim3(rgrid), dim3(256), 0, ctx->stream, indptr, indices,
+                     static_cast<const int32_t*>(hubs_v), hc.row_base, (int)nh, rows_total,
+                     static_cast<int32_t*>(cnt_v), static_cast<const int64_t*>(nullptr),
+                     static_cast<uint16_t*>(nullptr));
+  S3GRL_HIP_TRY(hipGetLastError());
+  int64_t* abs_off = static_cast<int64_t*>(abs_v);
+  S3GRL_TRY(launch_scan_i32_to_i64(ctx, static_cast<int32_t*>(cnt_v), rows_total, abs_off,
+                                   static_cast<int64_t*>(ws3_v)));
+  S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_scalars, abs_off + rows_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const int64_t entries = ctx->h_scalars[0];
+  if (entries * 2 > ((int64_t)1 << 30)) {   // dense hubs: not worth a cache (see above)
+    S3GRL_HIP_TRY(hipMemsetAsync(hc.slot, 0xff, (size_t)N * 4, ctx->stream));
+    S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return S3GRL_OK;
+  }
+  S3GRL_TRY(ctx->arena.alloc((size_t)rows_total * 4, &q));
+  g->hub.hoff = hc.hoff = static_cast<int32_t*>(q);
+  S3GRL_TRY(ctx->arena.alloc((size_t)std::max<int64_t>(entries, 8) * 2, &q));
+  g->hub.hcols = hc.hcols = static_cast<uint16_t*>(q);
+  hipLaunchKernelGGL(hub_offsets_kernel, dim3((unsigned)((rows_total + 255) / 256)), dim3(256), 0, ctx->stream,
+                     hc.row_base, (int)nh, rows_total, abs_off, hc.hoff, hc.col_base);
+  hipLaunchKernelGGL(hub_rows_kernel<true>, dim3(rgrid), dim3(256), 0, ctx->stream, indptr, indices,
+                     static_cast<const int32_t*>(hubs_v), hc.row_base, (int)nh, rows_total,
+                     static_cast<int32_t*>(nullptr), abs_off, hc.hcols);
+  S3GRL_HIP_TRY(hipGetLastError());
+  S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));   // tmp is released on return
+  g->hub.nh = (int32_t)nh;
+  if (getenv("S3GRL_DEBUG"))
+    fprintf(stderr, "[s3grl] hub cache: %lld hubs (deg >= %d), %lld rows, %lld entries\n", (long long)nh, min_deg,
+            (long long)rows_total, (long long)entries);
+  return S3GRL_OK;
+}
+
+}  // namespace s3grl

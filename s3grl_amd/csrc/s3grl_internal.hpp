@@ -153,8 +153,27 @@ struct s3grl_context {
   s3grl_plan* stats_owner = nullptr;
 };
 
+// Hub neighbourhoods (s3grl_hub.hip), built once per graph for one-hop plans on big graphs: for every
+// node h of at least kHubMinDegree neighbours (no self-loop, at most 65 535 neighbours) the induced
+// adjacency of N(h) as a CSR of positions in h's sorted row.  A link with such an endpoint shares all of
+// it with every other link of that hub: link_hub_kernel only finds the edges of the OTHER endpoint's
+// neighbours and pulls over the cached rows.
+struct HubCache {
+  int32_t nh = 0;
+  int32_t* slot = nullptr;       // [N] hub number of a node, -1 for the others
+  int32_t* voln = nullptr;       // [N] Σ degree over a node's stored neighbours
+  int64_t* row_base = nullptr;   // [nh + 1] first entry of hub k in hoff (deg(h) + 1 entries per hub)
+  int64_t* col_base = nullptr;   // [nh + 1] first entry of hub k in hcols
+  int32_t* hoff = nullptr;       // row offsets, relative to col_base[k]
+  uint16_t* hcols = nullptr;     // positions in the hub's row, ascending inside a row
+};
+constexpr int kHubMinDegree = 256;
+constexpr int kHubClasses = 4;           // LDS classes of link_hub_kernel: 128 / 256 / 512 / 1024 threads
+constexpr int64_t kHubVolMax = 65536;    // Σ degree over the other endpoint's neighbourhood: beyond, the old path
+
 struct s3grl_graph {
   s3grl_context* ctx = nullptr;
+  HubCache hub;                // of the degree-ordered graph (r_indptr / r_indices)
   int64_t num_nodes = 0;
   int64_t nnz = 0;
   int32_t max_degree = 0;      // decides whether the hub-row path of the row walker is armed
@@ -293,6 +312,43 @@ s3grl_status launch_translate_links(s3grl_context* ctx, const s3grl_graph* g, co
 // plan on a big graph works on its links (locality; outputs stay in the caller's order)
 s3grl_status launch_link_order(s3grl_context* ctx, const int64_t* links, int64_t L, int64_t N,
                                const int32_t* indptr, int32_t* perm);
+// hub.hip
+s3grl_status build_hub_cache(s3grl_context* ctx, s3grl_graph* g);
+void release_hub_cache(s3grl_graph* g);
+// LDS bytes of link_hub_kernel beyond its fixed part (n nodes, at most xcap edges outside the hub's cache)
+__host__ __device__ inline int64_t hub_lds_need(int64_t n, int64_t xcap) {
+  const int64_t state = 16 * n, build = 4 * n + 4 * xcap;
+  return 8 * n + 16 + (state > build ? state : build) + 4 * ((xcap + 1) & ~(int64_t)1) + 2 * ((n + 1) & ~(int64_t)1);
+}
+// ... and of the hub's cached rows staged next to them (offsets and columns as uint16; a hub of more than
+// 65 535 cached entries is read from HBM instead)
+__host__ __device__ inline int64_t hub_stage_bytes(int64_t c, int64_t entries) {
+  return entries <= 65535 ? 2 * ((c + 2) & ~(int64_t)1) + 2 * ((entries + 1) & ~(int64_t)1) : 0;
+}
+int hub_fixed_words(int cn_cap, int K);
+int hub_class_bound(int cls, int cn_cap, int K);   // LDS bytes (beyond the fixed part) of hub class 0..kHubClasses-1
+struct HubLinkArgs {
+  const int32_t *indptr, *indices;
+  HubCache hub;
+  const int64_t* links;
+  int plus, cn_cap;
+  const int64_t* x_cap;
+  const int64_t *node_off, *row_ptr, *job_off, *coef_off;
+  const int32_t* mirror_of;
+  int32_t* c_ids;
+  float* c_coef;
+  Job* jobs;
+  float* job_z;
+  int32_t* job_lim;
+  int64_t* row_nodes;
+  int32_t* lvl;
+  unsigned long long *tot_edges, *tot_support, *tot_vol;
+  const int32_t* old_of_new;
+  int split_t, seg_shift;
+  unsigned long long* dbg;   // diagnostic (S3GRL_DEBUG_STAMPS): cycles per phase, summed over workgroups
+};
+s3grl_status launch_hub_class(s3grl_context* ctx, const HubLinkArgs& a, int K, int cls, const int32_t* class_list,
+                              int count, hipStream_t stream);
 s3grl_status launch_sort_hops(s3grl_context* ctx, const s3grl_plan* p, int32_t* nodes);
 
 // structure.hip
@@ -344,7 +400,7 @@ s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_ca
                              const int32_t* n_nodes, const int32_t* p_nodes,
                              const int32_t* lvl_max, int64_t L, int32_t* class_count,
                              int32_t* class_list, bool allow_hash = true, const int32_t* e_cap = nullptr,
-                             int stash_slot = 0, const int32_t* perm = nullptr);
+                             int stash_slot = 0, const int32_t* perm = nullptr, const int64_t* x_cap = nullptr);
 // one-hop plans on big graphs (s3grl_onehop.inl): degree-oriented rows of the graph, and the
 // sizing pass that needs no bitmaps
 bool sparse_mode_for(const s3grl_graph* g);
@@ -354,7 +410,7 @@ s3grl_status launch_count1(s3grl_context* ctx, const s3grl_graph* g, const int64
                            int plus, int K, const int32_t* partner, const int32_t* mirror_of,
                            int32_t* n_nodes, int32_t* p_nodes, int32_t* n_rows, int32_t* n_jobs,
                            int32_t* lvl_max, int32_t* e_cap, int32_t* err_flag, int64_t* tot_nodes_alg,
-                           int64_t* tot_oriented, const int32_t* perm = nullptr);
+                           int64_t* tot_oriented, const int32_t* perm = nullptr, int64_t* x_cap = nullptr);
 s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                           const int32_t* class_list, const int32_t* class_count_host, int hops,
                           int plus, int cn_cap, int full_stats, int K, WalkSets ws, const int32_t* p_nodes,
@@ -366,7 +422,7 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           HopSampling smp = HopSampling{1.0, 0, 0}, const int32_t* stash = nullptr,
                           int slot = 0, const int32_t* e_cap = nullptr, int64_t max_nodes = 0,
                           const int32_t* old_of_new = nullptr, const int32_t* new_of_old = nullptr,
-                          int split_t = 0, int seg_shift = 0);
+                          int split_t = 0, int seg_shift = 0, const int64_t* x_cap = nullptr);
 // pieces of the split jobs: piece_off [njobs + 1] (device) and *total (device scalar) first, the
 // piece arrays once the host knows the total
 s3grl_status launch_split_count(s3grl_context* ctx, const Job* jobs, int64_t njobs, int seg_shift,

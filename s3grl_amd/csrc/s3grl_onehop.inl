@@ -91,7 +91,8 @@ __global__ __launch_bounds__(64 * kCount1Waves) void count1_kernel(
     int32_t* __restrict__ n_nodes, int32_t* __restrict__ p_nodes, int32_t* __restrict__ n_rows,
     int32_t* __restrict__ n_jobs, int32_t* __restrict__ lvl_max, int32_t* __restrict__ e_cap,
     int32_t* __restrict__ err_flag, unsigned long long* __restrict__ tot_nodes_alg,
-    unsigned long long* __restrict__ tot_oriented, const int32_t* __restrict__ perm) {
+    unsigned long long* __restrict__ tot_oriented, const int32_t* __restrict__ perm, const HubCache hub,
+    int64_t* __restrict__ x_cap) {
   const int lane = threadIdx.x & 63;
   const int64_t li = (int64_t)blockIdx.x * kCount1Waves + (threadIdx.x >> 6);
   if (li >= L) return;
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(64 * kCount1Waves) void count1_kernel(
       n_jobs[l] = 0;
       lvl_max[l] = 0;
       e_cap[l] = 0;
+      if (x_cap) x_cap[l] = -1;
     }
     return;
   }
@@ -166,6 +168,27 @@ __global__ __launch_bounds__(64 * kCount1Waves) void count1_kernel(
     n_jobs[l] = (R + 1) / 2;
     lvl_max[l] = max(2, n - 2);
     e_cap[l] = (int)min(2ll * fsum, (long long)0x3fffffff);
+    if (x_cap) {
+      // Can link_hub_kernel (s3grl_hub.hip) take this link?  Decided from the graph and the link alone.
+      // hub = the endpoint of higher degree (then lower id); the edges outside its cached neighbourhood
+      // are at most Σ degree over N(other) ∪ {other}, and at most the oriented entries of S less the
+      // hub's star and the cached edges (every induced edge sits in one oriented row of S).
+      long long xc = -1;
+      const bool s_hub = cs > cd || (cs == cd && s < d);
+      const int hb = s_hub ? s : d, ot = s_hub ? d : s;
+      const int hk = hub.slot[hb];
+      if (hk >= 0 && n <= 65535) {
+        const long long c_h = s_hub ? cs : cd, c_o = s_hub ? cd : cs;
+        const long long vb = (long long)hub.voln[ot] + c_o;
+        const long long eh = hub.col_base[hk + 1] - hub.col_base[hk];
+        const long long xb = min(vb, max(fsum - c_h - eh / 2, 0ll));
+        if (vb <= kHubVolMax) {
+          const long long need = min(hub_lds_need(n, xb) + hub_stage_bytes(c_h, eh), (long long)0x7fffffff);
+          xc = (need << 32) | xb;
+        }
+      }
+      x_cap[l] = xc;
+    }
     const unsigned long long mult = (mirror_of && mirror_of[l] >= 0) ? 2ull : 1ull;
     atomicAdd(stat_slot(tot_nodes_alg), mult * (unsigned long long)n);
     // oriented-row entries link_full_kernel will probe for this link (measurement: bench.py's

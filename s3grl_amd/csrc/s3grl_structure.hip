@@ -731,7 +731,9 @@ constexpr int kSparseBase = kNumClasses + 2;
 // kFullBig = the same with the bit matrix in an HBM slice (subgraphs of more than ~700 nodes)
 constexpr int kFullBase = kSparseBase + kNumClasses;
 constexpr int kFullBig = kFullBase + kNumClasses;
-constexpr int kNumLists = kFullBig + 1;
+// kHubBase.. = one-hop links with a cached hub neighbourhood, link_hub_kernel (s3grl_hub.hip) by LDS need
+constexpr int kHubBase = kFullBig + 1;
+constexpr int kNumLists = kHubBase + kHubClasses;
 
 __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
                                 const int32_t* __restrict__ p_nodes,
@@ -739,7 +741,8 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
                                 int sparse_mode, ClassBounds sbound, const int32_t* __restrict__ e_cap,
                                 ClassBounds fbound, int bm_limit, int dm_max_n, int dm_class_mask,
                                 int32_t* __restrict__ class_count, int32_t* __restrict__ class_list,
-                                const int32_t* __restrict__ perm) {
+                                const int32_t* __restrict__ perm, const int64_t* __restrict__ x_cap,
+                                ClassBounds hbound) {
   const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   // (perm: the class lists come out in the plan's processing order, up to the order of the atomics)
   const int64_t l = li < L ? (perm ? (int64_t)perm[li] : li) : L;
@@ -750,7 +753,16 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
   bool sparse = false;
   // one-hop plan (e_cap is only produced for those), every operator reaches all of S, local ids fit
   // 16 bits: link_full_kernel, by its LDS need with or without the bit matrix on chip
-  if (e_cap && n > 0 && p == n && n <= 65535) {
+  if (x_cap && n > 0 && p == n && x_cap[l] >= 0) {
+    const int64_t need_h = x_cap[l] >> 32;
+    if (need_h <= hbound.b[kHubClasses - 1]) {
+      sparse = true;
+#pragma unroll
+      for (int k = 0; k < kHubClasses; ++k) c += need_h > hbound.b[k] ? 1 : 0;
+      c += kHubBase;
+    }
+  }
+  if (!sparse && e_cap && n > 0 && p == n && n <= 65535) {
     const int ec = e_cap[l];
     const int need_a = full_lds_need(n, ec, true), need_b = full_lds_need(n, ec, false);
     if (need_a <= min(fbound.b[kNumClasses - 1], bm_limit)) {
@@ -1931,13 +1943,14 @@ s3grl_status launch_count1(s3grl_context* ctx, const s3grl_graph* g, const int64
                            int plus, int K, const int32_t* partner, const int32_t* mirror_of,
                            int32_t* n_nodes, int32_t* p_nodes, int32_t* n_rows, int32_t* n_jobs,
                            int32_t* lvl_max, int32_t* e_cap, int32_t* err_flag, int64_t* tot_nodes_alg,
-                           int64_t* tot_oriented, const int32_t* perm) {
+                           int64_t* tot_oriented, const int32_t* perm, int64_t* x_cap) {
   if (L == 0) return S3GRL_OK;
   hipLaunchKernelGGL(count1_kernel, dim3((unsigned)((L + kCount1Waves - 1) / kCount1Waves)),
                      dim3(64 * kCount1Waves), 0, ctx->stream, g->indptr, g->indices, g->fwd_deg,
                      (int)g->num_nodes, links, L, plus, K, partner, mirror_of, n_nodes, p_nodes, n_rows,
                      n_jobs, lvl_max, e_cap, err_flag, reinterpret_cast<unsigned long long*>(tot_nodes_alg),
-                     reinterpret_cast<unsigned long long*>(tot_oriented), perm);
+                     reinterpret_cast<unsigned long long*>(tot_oriented), perm, g->hub,
+                     (x_cap && g->hub.nh > 0) ? x_cap : nullptr);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -1946,7 +1959,7 @@ s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_ca
                              const int32_t* n_nodes, const int32_t* p_nodes,
                              const int32_t* lvl_max, int64_t L, int32_t* class_count,
                              int32_t* class_list, bool allow_hash, const int32_t* e_cap, int stash_slot,
-                             const int32_t* perm) {
+                             const int32_t* perm, const int64_t* x_cap) {
   if (L == 0) return S3GRL_OK;
   ClassBounds cb = class_bounds(g->num_nodes, cn_cap, K);
   const bool dm = allow_hash && stash_slot > 0 && dm_mode_for(g);
@@ -1955,13 +1968,16 @@ s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_ca
     // there is only the HBM-scratch class, with its bitmaps in the slice too
     for (int c = 0; c < kNumClasses; ++c) cb.b[c] = -1;   // every link "overflows" the LDS classes
   }
+  ClassBounds hb{};
+  static_assert(kHubClasses <= kNumClasses, "hub class bounds travel in a ClassBounds");
+  for (int c = 0; c < kHubClasses; ++c) hb.b[c] = hub_class_bound(c, cn_cap, K);
   hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream,
                      n_nodes, p_nodes, lvl_max, L, cb, dm ? 2 : ((allow_hash && sparse_mode_for(g)) ? 1 : 0),
                      dm ? class_bounds_dm(g->num_nodes, cn_cap, K) : class_bounds_sparse(cn_cap, K), e_cap,
                      class_bounds_full(cn_cap, K),
                      getenv("S3GRL_FORCE_BM_HBM") ? 0 : (1 << 30),   // test hook: bit matrices in HBM
                      dm ? std::min(stash_slot + 2, 65535) : 0, dm ? dm_class_mask_for(g, cn_cap, K) : 0,
-                     class_count, class_list, perm);
+                     class_count, class_list, perm, x_cap, hb);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -2005,6 +2021,7 @@ struct LinkArgs {
   int bm_ext_words;                         // HBM-scratch class: words of the bitmaps at the head of a slice (0: LDS)
   int gs_chunk;                             // ... and how many slices there are (the class runs in chunks)
   int64_t list_offset;                      // first entry of the class list a launch works on
+  const int64_t* x_cap;                     // one-hop plans: bound of the edges outside the hub's cache (-1: no hub)
 };
 
 // One-hop full-reach classes (link_full_kernel).  Small classes run one wavefront per link (no
@@ -2137,6 +2154,16 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
   if (class_count_host[kFullBig] > 0)
     S3GRL_TRY((launch_full_class<1024, K, true>(ctx, a, L, kFullBig, class_count_host[kFullBig], next_stream(),
                                                   a.bm_scratch, a.bm_stride_words, a.bm_grid)));
+  for (int c = kHubBase + kHubClasses - 1; c >= kHubBase; --c) {   // cached hub neighbourhoods (s3grl_hub.hip)
+    if (class_count_host[c] == 0) continue;
+    HubLinkArgs h{a.g->indptr, a.g->indices, a.g->hub, a.links, a.plus, a.cn_cap, a.x_cap, a.node_off, a.row_ptr,
+                  a.job_off, a.coef_off, a.mirror_of, a.c_ids, a.c_coef, a.jobs, a.job_z, a.job_lim, a.row_nodes,
+                  a.lvl, reinterpret_cast<unsigned long long*>(a.tot_edges),
+                  reinterpret_cast<unsigned long long*>(a.tot_support),
+                  reinterpret_cast<unsigned long long*>(a.tot_vol), a.old_of_new, a.split_t, a.seg_shift, a.dbg};
+    S3GRL_TRY(launch_hub_class(ctx, h, K, c - kHubBase, a.class_list + (int64_t)c * L, class_count_host[c],
+                               next_stream()));
+  }
   for (int c = kFullBig - 1; c >= kFullBase; --c) {
     const int count = class_count_host[c];
     if (count == 0) continue;
@@ -2233,7 +2260,7 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           int64_t* tot_edges, int64_t* tot_support, int64_t* tot_vol,
                           HopSampling smp, const int32_t* stash, int slot, const int32_t* e_cap,
                           int64_t max_nodes, const int32_t* old_of_new, const int32_t* new_of_old,
-                          int split_t, int seg_shift) {
+                          int split_t, int seg_shift, const int64_t* x_cap) {
   if (L == 0) return S3GRL_OK;
   // links too large for LDS keep their lists in HBM scratch: one 256-byte aligned slice each
   Transient scratch_owner{ctx, {}};
@@ -2263,7 +2290,8 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
              getenv("S3GRL_DEBUG_STAMPS") ? reinterpret_cast<unsigned long long*>(ctx->d_scalars + 16) : nullptr,
              smp, stash, slot, e_cap, nullptr, 0, 0, 0, old_of_new, new_of_old,
              (old_of_new && !getenv("S3GRL_NO_LEAF_WALK")) ? g->deg_le2_from : -1, split_t, seg_shift,
-             DirGraph{g->out_indptr, g->out_indices, g->in_indptr, g->in_indices}, bm_ext_words, gs_chunk, 0};
+             DirGraph{g->out_indptr, g->out_indices, g->in_indptr, g->in_indices}, bm_ext_words, gs_chunk, 0,
+             x_cap};
   // the class whose bit matrix does not fit LDS: one slice per resident workgroup of a persistent grid
   if (class_count_host[kFullBig] > 0) {
     // slice = list of found edges (uint32, at most ecap / 2) + CSR columns (uint16 x ecap) of the

@@ -85,6 +85,10 @@ def test_random_configuration(eng, monkeypatch, case):
         monkeypatch.setenv("S3GRL_SPLIT_SEG_SHIFT", "5")
     if case % 9 == 5:
         monkeypatch.setenv("S3GRL_FORCE_EXT_BITMAPS", "1")             # bitmaps in HBM slices (graphs beyond the LDS limit)
+    if hops == 1 and case % 2 == 0:
+        monkeypatch.setenv("S3GRL_FORCE_ONEHOP", "1")                  # row-intersection path + cached hub
+        monkeypatch.setenv("S3GRL_FORCE_HASH", "1")                    # neighbourhoods (s3grl_hub.hip) from degree 4
+        monkeypatch.setenv("S3GRL_HUB_MIN_DEG", "4")
     if case % 2 == 1:
         monkeypatch.setenv("S3GRL_HUB_ORDER", "1")                     # big-graph processing order (by hub endpoint)
     G = eng.graph(A)

@@ -25,25 +25,27 @@ def eng():
 
 def _plans(eng, monkeypatch, A, links, mode, K, bm_hbm=False):
     """(bitmap-flavour plan, one-hop-path plan) of the same one-hop request."""
-    for k in ("S3GRL_FORCE_ONEHOP", "S3GRL_FORCE_HASH", "S3GRL_FORCE_BM_HBM", "S3GRL_BIG_COLS_HBM"):
+    for k in ("S3GRL_FORCE_ONEHOP", "S3GRL_FORCE_HASH", "S3GRL_FORCE_BM_HBM", "S3GRL_BIG_COLS_HBM", "S3GRL_HUB_MIN_DEG"):
         monkeypatch.delenv(k, raising=False)
     G0 = eng.graph(A)
     p0 = eng.plan(G0, links, mode=mode, num_hops=1, sign_k=K, full_stats=True)
     monkeypatch.setenv("S3GRL_FORCE_ONEHOP", "1")
     monkeypatch.setenv("S3GRL_FORCE_HASH", "1")
-    if bm_hbm:                                 # the class of the biggest subgraphs (edge list + sort)
+    if bm_hbm == "hub":                        # cached hub neighbourhoods (s3grl_hub.hip): every node of 3+ neighbours
+        monkeypatch.setenv("S3GRL_HUB_MIN_DEG", "3")
+    elif bm_hbm:                               # the class of the biggest subgraphs (edge list + sort)
         monkeypatch.setenv("S3GRL_FORCE_BM_HBM", "1")
     if bm_hbm == "hbm":                        # ... with its CSR columns in the HBM slice
         monkeypatch.setenv("S3GRL_BIG_COLS_HBM", "1")
     G1 = eng.graph(A)                      # the oriented rows are built with the graph
     p1 = eng.plan(G1, links, mode=mode, num_hops=1, sign_k=K, full_stats=True)
-    for k in ("S3GRL_FORCE_ONEHOP", "S3GRL_FORCE_HASH", "S3GRL_FORCE_BM_HBM", "S3GRL_BIG_COLS_HBM"):
+    for k in ("S3GRL_FORCE_ONEHOP", "S3GRL_FORCE_HASH", "S3GRL_FORCE_BM_HBM", "S3GRL_BIG_COLS_HBM", "S3GRL_HUB_MIN_DEG"):
         monkeypatch.delenv(k, raising=False)
     return (G0, p0), (G1, p1)
 
 
 @pytest.mark.parametrize("name", EXTRACT_NAMES)
-@pytest.mark.parametrize("K,bm_hbm", [(1, False), (2, "hbm"), (3, "lds"), (5, False)])
+@pytest.mark.parametrize("K,bm_hbm", [(1, False), (2, "hbm"), (3, "lds"), (5, False), (2, "hub"), (3, "hub"), (5, "hub")])
 def test_onehop_path_equals_bitmap_flavour(eng, monkeypatch, name, K, bm_hbm):
     import torch
 
@@ -72,7 +74,7 @@ def test_onehop_path_equals_bitmap_flavour(eng, monkeypatch, name, K, bm_hbm):
 
 
 @pytest.mark.parametrize("name", ["usair", "rand300", "star_iso"])
-@pytest.mark.parametrize("bm_hbm", [False, "lds"])
+@pytest.mark.parametrize("bm_hbm", [False, "lds", "hub"])
 def test_onehop_path_degree_order_is_invisible(eng, monkeypatch, name, bm_hbm):
     """The one-hop path walks the graph's degree order too (csrc/s3grl_relabel.hip); with
     S3GRL_NO_RELABEL it walks the caller's order.  Same node lists, rows nodes and statistics."""
@@ -101,8 +103,9 @@ def test_onehop_path_degree_order_is_invisible(eng, monkeypatch, name, bm_hbm):
     assert rel_err(a[0].cpu().numpy(), b[0].cpu().numpy()) < 3e-6
 
 
+@pytest.mark.parametrize("flavour", [False, "hub"])
 @pytest.mark.parametrize("name", ["usair", "rand300", "probe5"])
-def test_onehop_path_node_sets_vs_reference_fixture(eng, monkeypatch, name):
+def test_onehop_path_node_sets_vs_reference_fixture(eng, monkeypatch, name, flavour):
     """Hop-1 node sets and CN rows against what the reference's own k_hop_subgraph produced."""
     g = load_extract(name)
     if 1 not in [int(h) for h in g["hops"]]:
@@ -110,7 +113,8 @@ def test_onehop_path_node_sets_vs_reference_fixture(eng, monkeypatch, name):
     n = int(g["num_nodes"])
     A = csr_from_undirected(n, g["edges"])
     links = eng.links(g["links"].T)
-    _, (G1, p1) = _plans(eng, monkeypatch, A, links, "pos_plus", 3)
+    (G0, p0), (G1, p1) = _plans(eng, monkeypatch, A, links, "pos_plus", 3, flavour)
+    p0.close(), G0.close()
     node_ptr, nodes, dists = (t.cpu().numpy() for t in p1.export_subgraphs())
     row_ptr, row_nodes = p1.row_ptr().cpu().numpy(), p1.row_nodes().cpu().numpy()
     for li, (s, d) in enumerate(g["links"]):
@@ -125,7 +129,7 @@ def test_onehop_path_node_sets_vs_reference_fixture(eng, monkeypatch, name):
 
 
 @pytest.mark.parametrize("mode", ["pos", "pos_plus"])
-@pytest.mark.parametrize("bm_hbm", [False, "lds", "hbm"])
+@pytest.mark.parametrize("bm_hbm", [False, "lds", "hbm", "hub"])
 def test_onehop_path_vs_oracle_with_self_loops_and_hubs(eng, monkeypatch, mode, bm_hbm):
     """A graph with self-loops at link endpoints and at common neighbours, a hub adjacent to
     everything, isolated endpoints, and links in both directions (folded) — against the oracle."""
