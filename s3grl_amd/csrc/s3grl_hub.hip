@@ -168,13 +168,19 @@ __global__ void hub_offsets_kernel(const int64_t* __restrict__ row_base, int nh,
 // colsx[2·xcap] (uint16).  region = the state arrays cur[n], nxs[n] (float2) of the passes; before them it
 // holds the node list nl[n-1] (local ids 1..n-1: N(h) staged, then the other endpoint's nodes) and the list
 // of found edges, then the scatter cursors and the per-wave sort bitmaps.
-template <int T, int K>
+// XG (the class of links whose BOUND of found edges does not fit LDS — the bound is loose, Σ degree over
+// the other endpoint's neighbourhood, the edges found are a few per cent of it): a persistent grid, the
+// list of found edges in this workgroup's HBM slice, the small CSR's columns on chip whenever the EXACT
+// count fits what the link leaves of the LDS, else in the slice too.
+template <int T, int K, bool XG>
 __global__ __launch_bounds__(T) void link_hub_kernel(const HubLinkArgs a, const int32_t* __restrict__ class_list,
-                                                     int count) {
+                                                     int count, int lds_bytes) {
   extern __shared__ uint32_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   constexpr int G = S3GRL_HUB_G;   // lanes per row of a pull
-  if ((int)blockIdx.x >= count) return;
+  int item = blockIdx.x;
+  if (item >= count) return;
+  do {   // (one link per workgroup; XG: a persistent grid over the class, one slice per workgroup)
   const int32_t* __restrict__ indptr = a.indptr;
   const int32_t* __restrict__ indices = a.indices;
   auto ext = [&](int v) -> int { return a.old_of_new ? a.old_of_new[v] : v; };
@@ -186,11 +192,11 @@ __global__ __launch_bounds__(T) void link_hub_kernel(const HubLinkArgs a, const 
     if (threadIdx.x == 0) atomicAdd(&a.dbg[idx], t_now - t_prev);        \
     t_prev = t_now;                                                      \
   }
-  const int l = class_list[blockIdx.x];
+  const int l = class_list[item];
   const int64_t noff = a.node_off[l];
   const int n = (int)(a.node_off[l + 1] - noff);
   const int xcap = (int)(a.x_cap[l] & 0xffffffffll);   // (classified here: the entry is >= 0)
-  const int xcap_e = (xcap + 1) & ~1;
+  const int xcap_e = XG ? 0 : ((xcap + 1) & ~1);   // found edges the LDS layout provides for
   const int mirror = a.mirror_of ? a.mirror_of[l] : -1;
   const int64_t mrp = mirror >= 0 ? a.row_ptr[mirror] : -1;
   const int cn_cap = a.cn_cap;
@@ -219,16 +225,30 @@ __global__ __launch_bounds__(T) void link_hub_kernel(const HubLinkArgs a, const 
   int32_t* offx = reinterpret_cast<int32_t*>(dinv + n);            // [n + 1]
   uint32_t* region = reinterpret_cast<uint32_t*>(offx + n + 1 + ((n + 1) & 1));
   const int region_words = max(4 * n, n + xcap_e);
-  uint16_t* colsx = reinterpret_cast<uint16_t*>(region + region_words);   // [2 * xcap]
-  uint16_t* hoff_l = colsx + 2 * xcap_e;                                  // [c + 1] (staged)
+  uint16_t* hoff_l = reinterpret_cast<uint16_t*>(region + region_words);  // [c + 1] (staged)
   uint16_t* hcols_l = hoff_l + (staged ? ((c + 2) & ~1) : 0);             // [hub_entries]
   uint16_t* tier = hcols_l + (staged ? (((int)hub_entries + 1) & ~1) : 0);   // [n]: tiny rows from the front, four-lane rows from the back
+  uint16_t* cols_l = tier + ((n + 1) & ~1);                                  // [2 * xcap] (XG: what is left)
+  uint32_t* slice = XG ? a.slices + (int64_t)blockIdx.x * a.slice_words : nullptr;
+  uint16_t* cols_g = XG ? reinterpret_cast<uint16_t*>(slice + a.slice_words / 2) : nullptr;
+  const int cols_cap = XG ? (lds_bytes - (int)(reinterpret_cast<char*>(cols_l) - reinterpret_cast<char*>(smem))) / 2 : 0;
+  bool cols_on_chip = true;
+  auto cx_ld = [&](int k) -> int {
+    if constexpr (XG) return cols_on_chip ? (int)cols_l[k] : (int)cols_g[k]; else return (int)cols_l[k];
+  };
+  auto cx_st = [&](int k, int v) {
+    if constexpr (XG) {
+      if (cols_on_chip) cols_l[k] = (uint16_t)v; else cols_g[k] = (uint16_t)v;
+    } else {
+      cols_l[k] = (uint16_t)v;
+    }
+  };
   auto hoff = [&](int t) -> int { return staged ? (int)hoff_l[t] : hoff_g[t]; };
   auto hcols = [&](int k) -> int { return staged ? (int)hcols_l[k] : (int)hcols_g[k]; };
   float2* cur = reinterpret_cast<float2*>(region);
   float2* nxs = cur + n;
   int32_t* nl = reinterpret_cast<int32_t*>(region);                // [n - 1]
-  uint32_t* elist = region + n;                                    // [xcap]
+  uint32_t* elist = XG ? slice : region + n;                       // [xcap]
   int32_t* cursor = reinterpret_cast<int32_t*>(region);            // [n] (nl is dead by then)
 
   // ---- the nodes: N(h) staged, then what only the other endpoint brings ---------------------------------
@@ -387,9 +407,11 @@ __global__ __launch_bounds__(T) void link_hub_kernel(const HubLinkArgs a, const 
       if (k < xcap) elist[k] = ((uint32_t)i << 16) | (uint32_t)j;
     }
   }
+  if constexpr (XG) __threadfence();   // the edge list is read back by other waves (through L2)
   __syncthreads();   // nl, qoff, qstart dead from here
   S3GRL_HSTAMP(2)
   const int found_edges = min(sh[30], xcap);
+  if constexpr (XG) cols_on_chip = 2 * found_edges <= cols_cap;
   for (int t = tid; t <= n; t += T) offx[t] = 0;
   __syncthreads();
   for (int k = tid; k < found_edges; k += T) {   // degrees of the small CSR
@@ -453,8 +475,11 @@ __global__ __launch_bounds__(T) void link_hub_kernel(const HubLinkArgs a, const 
   for (int k = tid; k < found_edges; k += T) {
     const uint32_t w = elist[k];
     const int i = (int)(w >> 16), j = (int)(w & 0xffffu);
-    colsx[atomicAdd(&cursor[i], 1)] = (uint16_t)j;
-    if (i != j) colsx[atomicAdd(&cursor[j], 1)] = (uint16_t)i;
+    cx_st(atomicAdd(&cursor[i], 1), j);
+    if (i != j) cx_st(atomicAdd(&cursor[j], 1), i);
+  }
+  if constexpr (XG) {
+    if (!cols_on_chip) __threadfence();
   }
   {
     // every row ascending (a fixed summation order).  Nearly all rows of the small CSR are empty or hold
@@ -482,26 +507,26 @@ __global__ __launch_bounds__(T) void link_hub_kernel(const HubLinkArgs a, const 
       const bool mine = q0 + sub < na;
       const int r = (int)list_a[min(q0 + sub, na - 1)];
       const int b = offx[r], len = offx[r + 1] - b;
-      const int x = mine && sl < len ? (int)colsx[b + sl] : 0x7fffffff;
+      const int x = mine && sl < len ? cx_ld(b + sl) : 0x7fffffff;
       int rank = 0;
 #pragma unroll
       for (int k = 0; k < 16; ++k) rank += __shfl(x, (lane & 48) + k) < x ? 1 : 0;
-      if (mine && sl < len) colsx[b + rank] = (uint16_t)x;
+      if (mine && sl < len) cx_st(b + rank, x);
     }
     for (int q = wv; q < nb; q += T / 64) {
       const int r = (int)list_b[q];
       const int b = offx[r], len = offx[r + 1] - b;
       if (len <= 64) {
-        const int x = lane < len ? (int)colsx[b + lane] : 0x7fffffff;
+        const int x = lane < len ? cx_ld(b + lane) : 0x7fffffff;
         int rank = 0;
         for (int k = 0; k < len; ++k) rank += __shfl(x, k) < x ? 1 : 0;
-        if (lane < len) colsx[b + rank] = (uint16_t)x;
+        if (lane < len) cx_st(b + rank, x);
       } else {
         for (int w = lane; w < WB; w += 64) wbm[w] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         for (int k = lane; k < len; k += 64) {
-          const int cc = colsx[b + k];
+          const int cc = cx_ld(b + k);
           atomicOr(&wbm[cc >> 5], 1u << (cc & 31));
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -520,12 +545,15 @@ __global__ __launch_bounds__(T) void link_hub_kernel(const HubLinkArgs a, const 
           while (word) {
             const int bit = __ffs(word) - 1;
             word &= word - 1;
-            colsx[k++] = (uint16_t)((w0 + lane) * 32 + bit);
+            cx_st(k++, (w0 + lane) * 32 + bit);
           }
           base += __shfl(inc, 63);
         }
       }
     }
+  }
+  if constexpr (XG) {
+    if (!cols_on_chip) __threadfence();
   }
   __syncthreads();   // the region becomes the state arrays
   S3GRL_HSTAMP(3)
@@ -568,6 +596,42 @@ __global__ __launch_bounds__(T) void link_hub_kernel(const HubLinkArgs a, const 
         if (t == pos_src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
         if (t == pos_dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
       };
+      if (i == 0) {
+        // Operator 1 of a pair is Â e_a | Â e_b: every entry has at most ONE term per row of the pair — the
+        // rows of a and b are spread instead of pulling over all of S (the same bits: a pull would add
+        // that term to zeros).
+        for (int t = tid; t < n; t += T) s_out[t] = make_float2(0.f, 0.f);
+        __syncthreads();
+        float* so = reinterpret_cast<float*>(s_out);
+        auto spread = [&](int lx, int comp) {
+          if (lx < 0) return;
+          const float v = dinv[lx];   // = s_in[lx], the only non-zero of this component
+          if (lx == 0) {
+            for (int p = tid; p < c; p += T)
+              if (1 + p != lo) so[2 * (1 + p) + comp] = v;
+            return;
+          }
+          if (lx <= c) {
+            const int k1 = hoff(lx);
+            for (int k = hoff(lx - 1) + tid; k < k1; k += T) so[2 * (1 + hcols(k)) + comp] = v;
+            if (tid == 0 && lx != lo) so[comp] = v;
+          }
+          const int k1 = offx[lx + 1];
+          for (int k = offx[lx] + tid; k < k1; k += T) so[2 * cx_ld(k) + comp] = v;
+        };
+        spread(la, 0);
+        spread(lb, 1);
+        __syncthreads();
+        for (int t = tid; t < n; t += T) {
+          const float2 one = s_out[t];
+          commit(t, one.x, one.y);
+        }
+        __syncthreads();
+        float2* tmp2 = s_in;
+        s_in = s_out;
+        s_out = tmp2;
+        continue;
+      }
       {   // row 0: all of h's row but the masked edge, in slices of the workgroup (fixed reduction tree)
         float ax = 0.f, ay = 0.f;
         for (int p = tid; p < c; p += T) {
@@ -605,7 +669,7 @@ __global__ __launch_bounds__(T) void link_hub_kernel(const HubLinkArgs a, const 
         }
         const int k1 = offx[t + 1];
         for (int k = offx[t]; k < k1; ++k) {
-          const float2 sv = s_in[colsx[k]];
+          const float2 sv = s_in[cx_ld(k)];
           ax += sv.x;
           ay += sv.y;
         }
@@ -632,7 +696,7 @@ __global__ __launch_bounds__(T) void link_hub_kernel(const HubLinkArgs a, const 
           }
           const int k1 = offx[t + 1];
           for (int k = offx[t] + g; k < k1; k += G) {
-            const float2 sv = s_in[colsx[k]];
+            const float2 sv = s_in[cx_ld(k)];
             ax += sv.x;
             ay += sv.y;
           }
@@ -663,7 +727,7 @@ __global__ __launch_bounds__(T) void link_hub_kernel(const HubLinkArgs a, const 
           }
           const int k1 = offx[t + 1];
           for (int k = offx[t] + lane; k < k1; k += 64) {
-            const float2 sv = s_in[colsx[k]];
+            const float2 sv = s_in[cx_ld(k)];
             ax += sv.x;
             ay += sv.y;
           }
@@ -738,16 +802,22 @@ __global__ __launch_bounds__(T) void link_hub_kernel(const HubLinkArgs a, const 
     }
   }
   S3GRL_HSTAMP(5)
+  if constexpr (XG) __syncthreads();   // LDS is reused by the next item of a persistent workgroup
+  item += gridDim.x;
+  } while (XG && item < count);
 #undef S3GRL_HSTAMP
 }
 
-template <int T, int K>
+template <int T, int K, bool XG>
 s3grl_status launch_hub_t(const HubLinkArgs& a, int cls, const int32_t* class_list, int count, hipStream_t stream) {
-  const size_t lds = (size_t)4 * hub_fixed_words(a.cn_cap, K) + (size_t)hub_class_bound(cls, a.cn_cap, K);
-  auto kern = link_hub_kernel<T, K>;
+  const size_t lds = (size_t)4 * hub_fixed_words(a.cn_cap, K) +
+                     (size_t)hub_class_bound(std::min(cls, kHubClasses - 1), a.cn_cap, K);
+  auto kern = link_hub_kernel<T, K, XG>;
   S3GRL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(T), lds, stream, a, class_list, count);
+  const int grid = XG ? std::min(count, a.slice_grid) : count;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(T), lds, stream, a, class_list, count,
+                     getenv("S3GRL_HUB_COLS_HBM") ? 0 : (int)lds);   // test hook: the columns in the slice too
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -755,15 +825,16 @@ s3grl_status launch_hub_t(const HubLinkArgs& a, int cls, const int32_t* class_li
 template <int K>
 s3grl_status launch_hub_k(const HubLinkArgs& a, int cls, const int32_t* class_list, int count, hipStream_t stream) {
   int t = cls == 0 ? 128 : (cls == 1 ? 256 : (cls == 2 ? 512 : 1024));
-  {
+  if (cls < kHubClasses) {
     char name[32];   // tuning hook
     snprintf(name, sizeof(name), "S3GRL_TH_CLASS%d", cls);
     if (const char* e = getenv(name)) t = atoi(e);
   }
-  if (t <= 128) return launch_hub_t<128, K>(a, cls, class_list, count, stream);
-  if (t <= 256) return launch_hub_t<256, K>(a, cls, class_list, count, stream);
-  if (t <= 512) return launch_hub_t<512, K>(a, cls, class_list, count, stream);
-  return launch_hub_t<1024, K>(a, cls, class_list, count, stream);
+  if (cls == kHubClasses) return launch_hub_t<1024, K, true>(a, cls, class_list, count, stream);
+  if (t <= 128) return launch_hub_t<128, K, false>(a, cls, class_list, count, stream);
+  if (t <= 256) return launch_hub_t<256, K, false>(a, cls, class_list, count, stream);
+  if (t <= 512) return launch_hub_t<512, K, false>(a, cls, class_list, count, stream);
+  return launch_hub_t<1024, K, false>(a, cls, class_list, count, stream);
 }
 
 }  // namespace

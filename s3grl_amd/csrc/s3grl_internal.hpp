@@ -168,7 +168,8 @@ struct HubCache {
   uint16_t* hcols = nullptr;     // positions in the hub's row, ascending inside a row
 };
 constexpr int kHubMinDegree = 256;
-constexpr int kHubClasses = 4;           // LDS classes of link_hub_kernel: 128 / 256 / 512 / 1024 threads
+constexpr int kHubClasses = 4;           // LDS classes of link_hub_kernel: 128 / 256 / 512 / 1024 threads; one more
+                                         // (index kHubClasses) keeps its list of found edges in HBM slices
 constexpr int64_t kHubVolMax = 65536;    // Σ degree over the other endpoint's neighbourhood: beyond, the old path
 
 struct s3grl_graph {
@@ -346,6 +347,9 @@ struct HubLinkArgs {
   const int32_t* old_of_new;
   int split_t, seg_shift;
   unsigned long long* dbg;   // diagnostic (S3GRL_DEBUG_STAMPS): cycles per phase, summed over workgroups
+  uint32_t* slices;          // class kHubClasses (found edges beyond LDS): one HBM slice per resident workgroup
+  int64_t slice_words;
+  int slice_grid;
 };
 s3grl_status launch_hub_class(s3grl_context* ctx, const HubLinkArgs& a, int K, int cls, const int32_t* class_list,
                               int count, hipStream_t stream);

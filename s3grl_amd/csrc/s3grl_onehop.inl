@@ -182,10 +182,7 @@ __global__ __launch_bounds__(64 * kCount1Waves) void count1_kernel(
         const long long vb = (long long)hub.voln[ot] + c_o;
         const long long eh = hub.col_base[hk + 1] - hub.col_base[hk];
         const long long xb = min(vb, max(fsum - c_h - eh / 2, 0ll));
-        if (vb <= kHubVolMax) {
-          const long long need = min(hub_lds_need(n, xb) + hub_stage_bytes(c_h, eh), (long long)0x7fffffff);
-          xc = (need << 32) | xb;
-        }
+        if (vb <= kHubVolMax) xc = (hub_stage_bytes(c_h, eh) << 32) | xb;   // (staged bytes of the cache, bound)
       }
       x_cap[l] = xc;
     }

@@ -733,7 +733,7 @@ constexpr int kFullBase = kSparseBase + kNumClasses;
 constexpr int kFullBig = kFullBase + kNumClasses;
 // kHubBase.. = one-hop links with a cached hub neighbourhood, link_hub_kernel (s3grl_hub.hip) by LDS need
 constexpr int kHubBase = kFullBig + 1;
-constexpr int kNumLists = kHubBase + kHubClasses;
+constexpr int kNumLists = kHubBase + kHubClasses + 1;   // (+ the class with its found edges in HBM slices)
 
 __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
                                 const int32_t* __restrict__ p_nodes,
@@ -754,12 +754,17 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
   // one-hop plan (e_cap is only produced for those), every operator reaches all of S, local ids fit
   // 16 bits: link_full_kernel, by its LDS need with or without the bit matrix on chip
   if (x_cap && n > 0 && p == n && x_cap[l] >= 0) {
-    const int64_t need_h = x_cap[l] >> 32;
-    if (need_h <= hbound.b[kHubClasses - 1]) {
+    const int64_t stage = x_cap[l] >> 32, xb = x_cap[l] & 0xffffffffll;
+    const int64_t need_h = hub_lds_need(n, xb) + stage;
+    if (!hbound.b[kHubClasses] && need_h <= hbound.b[kHubClasses - 1]) {   // (b[kHubClasses]: test hook)
       sparse = true;
 #pragma unroll
       for (int k = 0; k < kHubClasses; ++k) c += need_h > hbound.b[k] ? 1 : 0;
       c += kHubBase;
+    } else if (hub_lds_need(n, 0) + stage <= hbound.b[kHubClasses - 1]) {
+      sparse = true;
+      c = kHubBase + kHubClasses;
+      atomicMax(&class_count[29], (int)xb);   // sizes the HBM slices of that class
     }
   }
   if (!sparse && e_cap && n > 0 && p == n && n <= 65535) {
@@ -1970,7 +1975,9 @@ s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_ca
   }
   ClassBounds hb{};
   static_assert(kHubClasses <= kNumClasses, "hub class bounds travel in a ClassBounds");
+  static_assert(kHubClasses < kNumClasses, "one more entry for the test hook");
   for (int c = 0; c < kHubClasses; ++c) hb.b[c] = hub_class_bound(c, cn_cap, K);
+  hb.b[kHubClasses] = getenv("S3GRL_FORCE_HUB_SLICES") ? 1 : 0;   // test hook: found edges in HBM slices
   hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream,
                      n_nodes, p_nodes, lvl_max, L, cb, dm ? 2 : ((allow_hash && sparse_mode_for(g)) ? 1 : 0),
                      dm ? class_bounds_dm(g->num_nodes, cn_cap, K) : class_bounds_sparse(cn_cap, K), e_cap,
@@ -2022,6 +2029,9 @@ struct LinkArgs {
   int gs_chunk;                             // ... and how many slices there are (the class runs in chunks)
   int64_t list_offset;                      // first entry of the class list a launch works on
   const int64_t* x_cap;                     // one-hop plans: bound of the edges outside the hub's cache (-1: no hub)
+  uint32_t* hub_slices;                     // link_hub_kernel's overflow class: found-edge list + columns per workgroup
+  int64_t hub_slice_words;
+  int hub_slice_grid;
 };
 
 // One-hop full-reach classes (link_full_kernel).  Small classes run one wavefront per link (no
@@ -2154,13 +2164,14 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
   if (class_count_host[kFullBig] > 0)
     S3GRL_TRY((launch_full_class<1024, K, true>(ctx, a, L, kFullBig, class_count_host[kFullBig], next_stream(),
                                                   a.bm_scratch, a.bm_stride_words, a.bm_grid)));
-  for (int c = kHubBase + kHubClasses - 1; c >= kHubBase; --c) {   // cached hub neighbourhoods (s3grl_hub.hip)
+  for (int c = kHubBase + kHubClasses; c >= kHubBase; --c) {   // cached hub neighbourhoods (s3grl_hub.hip)
     if (class_count_host[c] == 0) continue;
     HubLinkArgs h{a.g->indptr, a.g->indices, a.g->hub, a.links, a.plus, a.cn_cap, a.x_cap, a.node_off, a.row_ptr,
                   a.job_off, a.coef_off, a.mirror_of, a.c_ids, a.c_coef, a.jobs, a.job_z, a.job_lim, a.row_nodes,
                   a.lvl, reinterpret_cast<unsigned long long*>(a.tot_edges),
                   reinterpret_cast<unsigned long long*>(a.tot_support),
-                  reinterpret_cast<unsigned long long*>(a.tot_vol), a.old_of_new, a.split_t, a.seg_shift, a.dbg};
+                  reinterpret_cast<unsigned long long*>(a.tot_vol), a.old_of_new, a.split_t, a.seg_shift, a.dbg,
+                  a.hub_slices, a.hub_slice_words, a.hub_slice_grid};
     S3GRL_TRY(launch_hub_class(ctx, h, K, c - kHubBase, a.class_list + (int64_t)c * L, class_count_host[c],
                                next_stream()));
   }
@@ -2291,7 +2302,16 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
              smp, stash, slot, e_cap, nullptr, 0, 0, 0, old_of_new, new_of_old,
              (old_of_new && !getenv("S3GRL_NO_LEAF_WALK")) ? g->deg_le2_from : -1, split_t, seg_shift,
              DirGraph{g->out_indptr, g->out_indices, g->in_indptr, g->in_indices}, bm_ext_words, gs_chunk, 0,
-             x_cap};
+             x_cap, nullptr, 0, 0};
+  if (class_count_host[kHubBase + kHubClasses] > 0) {   // list of found edges (uint32) + columns (2 x uint16) per slice
+    const int64_t xmax = ((int64_t)class_count_host[29] + 63) / 64 * 64;
+    a.hub_slice_words = 2 * xmax;
+    a.hub_slice_grid = (int)std::min<int64_t>(class_count_host[kHubBase + kHubClasses], 256);
+    void* q = nullptr;
+    S3GRL_TRY(ctx->arena.alloc((size_t)a.hub_slice_words * 4 * a.hub_slice_grid, &q));
+    scratch_owner.ptrs.push_back(q);
+    a.hub_slices = static_cast<uint32_t*>(q);
+  }
   // the class whose bit matrix does not fit LDS: one slice per resident workgroup of a persistent grid
   if (class_count_host[kFullBig] > 0) {
     // slice = list of found edges (uint32, at most ecap / 2) + CSR columns (uint16 x ecap) of the

@@ -25,27 +25,34 @@ def eng():
 
 def _plans(eng, monkeypatch, A, links, mode, K, bm_hbm=False):
     """(bitmap-flavour plan, one-hop-path plan) of the same one-hop request."""
-    for k in ("S3GRL_FORCE_ONEHOP", "S3GRL_FORCE_HASH", "S3GRL_FORCE_BM_HBM", "S3GRL_BIG_COLS_HBM", "S3GRL_HUB_MIN_DEG"):
+    for k in ("S3GRL_FORCE_ONEHOP", "S3GRL_FORCE_HASH", "S3GRL_FORCE_BM_HBM", "S3GRL_BIG_COLS_HBM", "S3GRL_HUB_MIN_DEG",
+              "S3GRL_FORCE_HUB_SLICES", "S3GRL_HUB_COLS_HBM"):
         monkeypatch.delenv(k, raising=False)
     G0 = eng.graph(A)
     p0 = eng.plan(G0, links, mode=mode, num_hops=1, sign_k=K, full_stats=True)
     monkeypatch.setenv("S3GRL_FORCE_ONEHOP", "1")
     monkeypatch.setenv("S3GRL_FORCE_HASH", "1")
-    if bm_hbm == "hub":                        # cached hub neighbourhoods (s3grl_hub.hip): every node of 3+ neighbours
+    if bm_hbm in ("hub", "hubx", "hubxx"):     # cached hub neighbourhoods (s3grl_hub.hip): every node of 3+ neighbours
         monkeypatch.setenv("S3GRL_HUB_MIN_DEG", "3")
+        if bm_hbm != "hub":                    # ... the class with its found edges in HBM slices
+            monkeypatch.setenv("S3GRL_FORCE_HUB_SLICES", "1")
+        if bm_hbm == "hubxx":                  # ... and the small CSR's columns there too
+            monkeypatch.setenv("S3GRL_HUB_COLS_HBM", "1")
     elif bm_hbm:                               # the class of the biggest subgraphs (edge list + sort)
         monkeypatch.setenv("S3GRL_FORCE_BM_HBM", "1")
     if bm_hbm == "hbm":                        # ... with its CSR columns in the HBM slice
         monkeypatch.setenv("S3GRL_BIG_COLS_HBM", "1")
     G1 = eng.graph(A)                      # the oriented rows are built with the graph
     p1 = eng.plan(G1, links, mode=mode, num_hops=1, sign_k=K, full_stats=True)
-    for k in ("S3GRL_FORCE_ONEHOP", "S3GRL_FORCE_HASH", "S3GRL_FORCE_BM_HBM", "S3GRL_BIG_COLS_HBM", "S3GRL_HUB_MIN_DEG"):
+    for k in ("S3GRL_FORCE_ONEHOP", "S3GRL_FORCE_HASH", "S3GRL_FORCE_BM_HBM", "S3GRL_BIG_COLS_HBM", "S3GRL_HUB_MIN_DEG",
+              "S3GRL_FORCE_HUB_SLICES", "S3GRL_HUB_COLS_HBM"):
         monkeypatch.delenv(k, raising=False)
     return (G0, p0), (G1, p1)
 
 
 @pytest.mark.parametrize("name", EXTRACT_NAMES)
-@pytest.mark.parametrize("K,bm_hbm", [(1, False), (2, "hbm"), (3, "lds"), (5, False), (2, "hub"), (3, "hub"), (5, "hub")])
+@pytest.mark.parametrize("K,bm_hbm", [(1, False), (2, "hbm"), (3, "lds"), (5, False), (2, "hub"), (3, "hub"), (5, "hub"),
+                                      (3, "hubx"), (2, "hubxx")])
 def test_onehop_path_equals_bitmap_flavour(eng, monkeypatch, name, K, bm_hbm):
     import torch
 
@@ -129,7 +136,7 @@ def test_onehop_path_node_sets_vs_reference_fixture(eng, monkeypatch, name, flav
 
 
 @pytest.mark.parametrize("mode", ["pos", "pos_plus"])
-@pytest.mark.parametrize("bm_hbm", [False, "lds", "hbm", "hub"])
+@pytest.mark.parametrize("bm_hbm", [False, "lds", "hbm", "hub", "hubx", "hubxx"])
 def test_onehop_path_vs_oracle_with_self_loops_and_hubs(eng, monkeypatch, mode, bm_hbm):
     """A graph with self-loops at link endpoints and at common neighbours, a hub adjacent to
     everything, isolated endpoints, and links in both directions (folded) — against the oracle."""
@@ -162,6 +169,10 @@ def test_onehop_path_vs_oracle_with_self_loops_and_hubs(eng, monkeypatch, mode, 
         monkeypatch.setenv("S3GRL_FORCE_BM_HBM", "1")
     if bm_hbm == "hbm":
         monkeypatch.setenv("S3GRL_BIG_COLS_HBM", "1")
+    if bm_hbm in ("hubx", "hubxx"):
+        monkeypatch.setenv("S3GRL_FORCE_HUB_SLICES", "1")
+    if bm_hbm == "hubxx":
+        monkeypatch.setenv("S3GRL_HUB_COLS_HBM", "1")
     pf = eng.plan(G1, eng.links(links), mode=mode, num_hops=1, sign_k=K)       # with folding
     for p in (p1, pf):
         rows = p.run(eng.features(X)).cpu().numpy()
@@ -214,3 +225,61 @@ def test_onehop_plans_have_no_node_limit(eng):
     assert p2.stats["max_nodes"] > 2
     p2.close()
     G.close()
+
+
+@pytest.mark.parametrize("mode", ["pos", "pos_plus"])
+def test_cached_hub_neighbourhoods_equal_the_per_link_road(eng, monkeypatch, mode):
+    """A power-law graph with real hubs (csrc/s3grl_hub.hip): links at hubs take link_hub_kernel — the
+    hub's induced neighbourhood from the per-graph cache, only the other endpoint's rows walked — and
+    must give what link_full_kernel gives with the cache switched off: node lists, row nodes and
+    statistics exactly, rows to fp32 round-off (another fixed summation order); both directions of a
+    link, folded and unfolded, bit for bit the same; hub-hub links and leaves included."""
+    import torch
+    from s3grl_amd import workloads
+
+    n, e = workloads.chung_lu(30000, 150000, seed=5)
+    A = workloads.csr_from_undirected(n, e)
+    deg = np.diff(A.indptr)
+    hubs = np.argsort(-deg)[:12]
+    assert deg[hubs[-1]] >= 64
+    rng = np.random.default_rng(2)
+    links = []
+    for h in hubs:
+        nb = A.indices[A.indptr[h]:A.indptr[h + 1]]
+        links += [(h, int(v)) for v in rng.choice(nb, 6, replace=False)]          # positive links at the hub
+        links += [(int(v), h) for v in rng.integers(0, n, 6) if v != h]           # negative ones, hub as dst
+    links += [(int(hubs[0]), int(hubs[1])), (int(hubs[2]), int(hubs[5]))]        # hub - hub
+    links = np.array(links)
+    links = np.concatenate([links, links[:10, ::-1]])                             # + reversed duplicates
+    X = rng.standard_normal((n, 24)).astype(np.float32)
+    out = []
+    monkeypatch.setenv("S3GRL_FORCE_ONEHOP", "1")
+    monkeypatch.setenv("S3GRL_FORCE_HASH", "1")
+    for cache in (False, True):
+        monkeypatch.setenv("S3GRL_HUB_MIN_DEG", "64")
+        if not cache:
+            monkeypatch.setenv("S3GRL_NO_HUB_CACHE", "1")
+        else:
+            monkeypatch.delenv("S3GRL_NO_HUB_CACHE", raising=False)
+        G = eng.graph(A)
+        f = eng.features(X)
+        L = eng.links(links.T)
+        p = eng.plan(G, L, mode=mode, num_hops=1, sign_k=3, full_stats=True)
+        rows = p.run(f).clone()
+        st = dict(p.stats)
+        st.pop("workspace_bytes")
+        exp = [t.clone() for t in p.export_subgraphs()]
+        pf = eng.plan(G, L, mode=mode, num_hops=1, sign_k=3)                      # folded
+        assert pf.stats["folded_links"] == 10
+        assert torch.equal(pf.run(f), rows)
+        out.append((rows, st, exp, p.row_ptr().clone(), p.row_nodes().clone()))
+        p.close(), pf.close(), f.close(), G.close()
+    (ra, sa, ea, pa, na), (rb, sb, eb, pb, nb_) = out
+    assert sa == sb and torch.equal(pa, pb) and torch.equal(na, nb_)
+    assert all(torch.equal(x, y) for x, y in zip(ea, eb))
+    assert not torch.equal(ra, rb)                        # (another summation order: the cache WAS used)
+    assert rel_err(rb.cpu().numpy(), ra.cpu().numpy()) < 3e-6
+    from oracle import c_oracle
+
+    ref, ptr, _, _ = c_oracle.pos_rows(links.T, 1, A, X, 3, plus=mode == "pos_plus")
+    assert rel_err(rb.cpu().numpy(), ref) < TOL
