@@ -128,10 +128,19 @@ def collect_pmc(args, kernel_family, per_step=False):
     if passes is None:
         return None
     merged, disp = passes
-    g = merged.get(kernel_family)
+    if isinstance(kernel_family, (list, tuple)):   # several kernels share the phase: their counters add up
+        fams = [f for f in kernel_family if f in merged]
+        g = {}
+        for f in fams:
+            for k, v in merged[f].items():
+                g[k] = g.get(k, 0.0) + v
+        launches = max(sum(disp.get(f, 0) for f in fams), 1)
+        kernel_family = " + ".join(fams)
+    else:
+        g = merged.get(kernel_family)
+        launches = max(disp.get(kernel_family, 1), 1)
     if not g or "FETCH_SIZE" not in g or "WRITE_SIZE" not in g:
         return None
-    launches = max(disp.get(kernel_family, 1), 1)
     n = 1 if per_step else launches
     rec = {"kernel": kernel_family, "dispatches": launches, "per": "step (sum over its launches)" if per_step else "launch",
            "FETCH_SIZE_KB": g["FETCH_SIZE"] / n, "WRITE_SIZE_KB": g["WRITE_SIZE"] / n,
@@ -149,7 +158,8 @@ def link_kernel_roofline(args, w, link_index, stats, phase_ms, K, F, collect):
     vol(S): the bytes they physically request are counted exactly from the plan."""
     ms = phase_ms["propagate"]
     onehop = stats.get("oriented_entries", 0) > 0
-    kname = "link_full_kernel" if onehop else "link_kernel"
+    hub_links = stats.get("hub_links", 0)
+    kname = ("link_full_kernel + link_hub_kernel" if hub_links else "link_full_kernel") if onehop else "link_kernel"
     n_ext, vol, sup, pairs = stats["extracted_nodes"], stats["total_volume"], stats["total_support"], stats["num_row_pairs"]
     folded = stats.get("folded_links", 0)
     L = link_index.shape[1]
@@ -159,9 +169,12 @@ def link_kernel_roofline(args, w, link_index, stats, phase_ms, K, F, collect):
     # support counts a folded link twice (algorithmic); the kernels write one list per extracted pair
     sup_ext = sup * (L - folded) / max(L, 1)
     if onehop:
-        reads = {"endpoint_rows": 4 * ends * (L - folded) / max(L, 1),        # the two CSR rows, staged in LDS
+        # links served from a cached hub neighbourhood (link_hub_kernel) report what they requested themselves
+        ends_full = max(ends * (L - folded) / max(L, 1) - stats.get("hub_endpoint_entries", 0), 0)
+        reads = {"endpoint_rows": 4 * ends_full,                             # the two CSR rows, staged in LDS
                  "oriented_rows": 4 * stats["oriented_entries"],             # probes of the masked adjacency
-                 "row_bounds": 16 * n_ext}                                   # indptr + fwd_indptr pairs per node
+                 "row_bounds": 16 * (n_ext - stats.get("hub_nodes", 0)),     # indptr + fwd_indptr pairs per node
+                 "hub_links": stats.get("hub_read_bytes", 0)}                # endpoint rows, walked rows, staged cache
     else:
         reads = {"csr_rows": 4 * vol * (1 + max(K - 1, 1)), "row_bounds": 8 * n_ext * K,
                  "node_lists": 4 * n_ext}
@@ -187,12 +200,13 @@ def link_kernel_roofline(args, w, link_index, stats, phase_ms, K, F, collect):
         "physical_bytes": physical, "physical_GBps": physical / sec / 1e9,
         "physical_reads": reads, "physical_writes": writes,
         "traffic": traffic, "traffic_source": traffic_source, "l2_hit_rate": l2_hit, "pmc": pmc,
-        "limiter": ("dependent-load latency: ~25 steps per link (rows -> rank merge -> hash -> oriented-row "
-                    "probes -> CSR of local ids -> K pulls), each a barrier-separated round trip to L2 or LDS; "
-                    "neither HBM (this fraction) nor VALU issue is saturated") if onehop else
+        "limiter": ("LDS issue of the K pulls (cached hub rows + found edges, a few entries per row) and of the "
+                    "neighbour tests of the walked rows (link_hub_kernel); dependent-load latency of the per-link "
+                    "chain rows -> rank merge -> hash -> oriented-row probes -> CSR -> K pulls (link_full_kernel): "
+                    "the classes' serial times add up to the phase, HBM (this fraction) is not the bound") if onehop else
                    "VALU issue of the row walk (76-86 % busy at under half of its lanes), DESIGN §2.1",
         "phase_ms": phase_ms,
-        "folded_links": folded, "mean_subgraph_nodes": stats["total_nodes"] / max(L, 1),
+        "folded_links": folded, "hub_links": hub_links, "mean_subgraph_nodes": stats["total_nodes"] / max(L, 1),
     }
 
 
@@ -678,7 +692,7 @@ def main():
             traffic, traffic_source, l2_hit = None, None, None
             if args.collect_pmc and world == 1:
                 # (the child runs ONE step: the sum over the family's dispatches is the launch of a step)
-                rec = collect_pmc(args, kname, per_step=True)
+                rec = collect_pmc(args, kname.split(" + ") if " + " in kname else kname, per_step=True)
                 if rec:
                     traffic, l2_hit = rec["hbm_bytes_per_launch"], rec.get("l2_hit_rate")
                     traffic_source = "collected by this run: child rocprofv3 --pmc passes of the same command"

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define S3GRL_ABI_VERSION 4
+#define S3GRL_ABI_VERSION 5
 
 typedef enum s3grl_status {
   S3GRL_OK = 0,
@@ -117,8 +117,15 @@ typedef struct s3grl_plan_stats {
                                totals above count them like any other link (algorithmic). */
   int64_t extracted_nodes;  /* Σ n over the links actually extracted */
   int64_t oriented_entries; /* one-hop plans on big graphs: Σ over the extracted links of the degree-oriented
-                               row entries of their subgraph's nodes (what link_full_kernel probes: the
+                               row entries of their subgraph's nodes, hub_links excepted (what link_full_kernel probes: the
                                physical counterpart of total_volume); 0 for other plans */
+  int64_t hub_links;        /* ... of which: links served from a cached hub neighbourhood (link_hub_kernel:
+                               the induced adjacency of a hub's neighbours is built once per graph and
+                               shared by all of the hub's links); their oriented rows are NOT probed */
+  int64_t hub_read_bytes;   /* bytes those links requested: the two endpoint rows, the rows of the nodes
+                               only the non-hub endpoint brings (bounds + entries), the cached rows staged */
+  int64_t hub_endpoint_entries; /* Σ deg(src) + deg(dst) over those links (their share of the endpoint rows) */
+  int64_t hub_nodes;        /* Σ n over those links (their share of extracted_nodes) */
 } s3grl_plan_stats;
 
 typedef struct s3grl_context s3grl_context; /* device, stream, workspace arena */

@@ -52,7 +52,7 @@ class NodeSets(C.Structure):
                 ("num_set_nodes", C.c_int64), ("per_link", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 FLAG_FULL_STATS, FLAG_NO_FOLD, FLAG_COUNT_ONLY = 1, 2, 4
 
 
@@ -60,7 +60,7 @@ class PlanStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "num_links", "total_rows", "total_nodes", "total_volume", "total_sub_edges",
         "total_support", "num_row_pairs", "max_nodes", "workspace_bytes", "folded_links",
-        "extracted_nodes", "oriented_entries")]
+        "extracted_nodes", "oriented_entries", "hub_links", "hub_read_bytes", "hub_endpoint_entries", "hub_nodes")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

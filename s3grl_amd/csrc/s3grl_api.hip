@@ -268,6 +268,11 @@ static s3grl_status resolve_plan_stats(s3grl_context* ctx) {
   p->stats.total_sub_edges = total(0);
   p->stats.total_support = total(1);
   p->stats.total_volume = total(2);
+  p->stats.oriented_entries = total(4);   // (link_hub_kernel takes its links' share back)
+  p->stats.hub_links = total(5);
+  p->stats.hub_read_bytes = total(6);
+  p->stats.hub_endpoint_entries = total(7);
+  p->stats.hub_nodes = total(8);
   p->stats_pending = false;
   if (ctx->profiling) {
     float ms = 0;
@@ -831,6 +836,8 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   S3GRL_TRY(record(ctx, 2));
   S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_stats, st, 3 * kStatRow * sizeof(int64_t), hipMemcpyDeviceToHost,
                                ctx->stream));
+  S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_stats + 4 * kStatRow, st + 4 * kStatRow, 5 * kStatRow * sizeof(int64_t),
+                               hipMemcpyDeviceToHost, ctx->stream));
   plan->stats.workspace_bytes = (int64_t)ctx->arena.bytes_held();
   // The totals (Σ edges / support / vol) are read back when somebody asks for them: no wait for the
   // link kernels here, so the gather can be queued right behind them.  Plans with split jobs need

@@ -799,6 +799,17 @@ __global__ __launch_bounds__(T) void link_hub_kernel(const HubLinkArgs a, const 
       }
       atomicAdd(stat_slot(a.tot_edges), (unsigned long long)e * (mirror >= 0 ? 2ull : 1ull));
       atomicAdd(stat_slot(a.tot_vol), (unsigned long long)v * (mirror >= 0 ? 2ull : 1ull));
+      // what this link requested (bench.py's physical-bytes figure): the two endpoint rows, the walked rows'
+      // bounds and entries, the staged cache, the ids of the degree order
+      atomicAdd(stat_slot(a.tot_hub_links), 1ull);
+      atomicAdd(stat_slot(a.tot_hub_ends), (unsigned long long)(c + co));
+      atomicAdd(stat_slot(a.tot_hub_nodes), (unsigned long long)n);
+      // (count1_kernel summed the oriented-row entries of EVERY link: this one's are not probed)
+      atomicAdd(stat_slot(a.tot_oriented), 0ull - (unsigned long long)(a.e_cap[l] / 2));
+      atomicAdd(stat_slot(a.tot_hub_bytes),
+                (unsigned long long)(4ll * c + 8ll * co + 16ll * qn + 4ll * walk_total +
+                                     (staged ? 2ll * (c + 1) + 2ll * hub_entries : 8ll * c + 2ll * (K - 1) * hub_entries) +
+                                     (a.old_of_new ? 4ll * n : 0ll)));
     }
   }
   S3GRL_HSTAMP(5)

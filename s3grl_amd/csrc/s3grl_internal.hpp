@@ -36,7 +36,8 @@ constexpr int kMaxNodesLds = 327680;   // 4 bitmaps of N bits must fit 160 KiB o
 constexpr int kMaxSignK = 8;
 constexpr int kStatShards = 64;        // see stat_slot() in s3grl_device.hpp
 constexpr int kStatStride = 16;        // int64 per shard: one 128-byte line
-constexpr int kStatRows = 5;           // Σ edges, Σ support, Σ vol, Σ n (algorithmic), Σ oriented-row entries
+constexpr int kStatRows = 9;           // Σ edges, Σ support, Σ vol, Σ n (algorithmic), Σ oriented-row entries,
+                                       // links of link_hub_kernel, bytes they read, Σ of their endpoint degrees, Σ of their n
 constexpr int kMaxLevels = 32;         // BFS levels tracked per link (num_hops <= 30)
 // link_kernel keeps a whole subgraph on-chip; links are binned by LDS need into classes
 constexpr int kNumClasses = 6;
@@ -343,7 +344,8 @@ struct HubLinkArgs {
   int32_t* job_lim;
   int64_t* row_nodes;
   int32_t* lvl;
-  unsigned long long *tot_edges, *tot_support, *tot_vol;
+  unsigned long long *tot_edges, *tot_support, *tot_vol, *tot_oriented, *tot_hub_links, *tot_hub_bytes, *tot_hub_ends, *tot_hub_nodes;
+  const int32_t* e_cap;      // 2 x the oriented-row entries of a link's subgraph (count1_kernel)
   const int32_t* old_of_new;
   int split_t, seg_shift;
   unsigned long long* dbg;   // diagnostic (S3GRL_DEBUG_STAMPS): cycles per phase, summed over workgroups

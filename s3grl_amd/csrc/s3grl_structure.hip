@@ -2170,7 +2170,13 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
                   a.job_off, a.coef_off, a.mirror_of, a.c_ids, a.c_coef, a.jobs, a.job_z, a.job_lim, a.row_nodes,
                   a.lvl, reinterpret_cast<unsigned long long*>(a.tot_edges),
                   reinterpret_cast<unsigned long long*>(a.tot_support),
-                  reinterpret_cast<unsigned long long*>(a.tot_vol), a.old_of_new, a.split_t, a.seg_shift, a.dbg,
+                  reinterpret_cast<unsigned long long*>(a.tot_vol),
+                  reinterpret_cast<unsigned long long*>(a.tot_vol) + 2 * (size_t)kStatShards * kStatStride,   // rows 4..8 of d_stats
+                  reinterpret_cast<unsigned long long*>(a.tot_vol) + 3 * (size_t)kStatShards * kStatStride,
+                  reinterpret_cast<unsigned long long*>(a.tot_vol) + 4 * (size_t)kStatShards * kStatStride,
+                  reinterpret_cast<unsigned long long*>(a.tot_vol) + 5 * (size_t)kStatShards * kStatStride,
+                  reinterpret_cast<unsigned long long*>(a.tot_vol) + 6 * (size_t)kStatShards * kStatStride,
+                  a.e_cap, a.old_of_new, a.split_t, a.seg_shift, a.dbg,
                   a.hub_slices, a.hub_slice_words, a.hub_slice_grid};
     S3GRL_TRY(launch_hub_class(ctx, h, K, c - kHubBase, a.class_list + (int64_t)c * L, class_count_host[c],
                                next_stream()));

@@ -70,7 +70,13 @@ def test_onehop_path_equals_bitmap_flavour(eng, monkeypatch, name, K, bm_hbm):
             assert torch.equal(a, b)                      # node lists, canonical order, hop distances
         s0, s1 = dict(p0.stats), dict(p1.stats)
         s0.pop("workspace_bytes"), s1.pop("workspace_bytes")
-        assert s0.pop("oriented_entries") == 0 and s1.pop("oriented_entries") > 0   # a one-hop-path figure
+        assert s0.pop("hub_links") == 0 and s0.pop("hub_read_bytes") == 0 and s0.pop("hub_endpoint_entries") == 0 and s0.pop("hub_nodes") == 0
+        hub_links = s1.pop("hub_links")
+        assert (hub_links > 0) == (s1.pop("hub_read_bytes") > 0) == (s1.pop("hub_endpoint_entries") > 0) == (s1.pop("hub_nodes") > 0)
+        # one-hop-path figures: rows probed by link_full_kernel, links served from a cached hub neighbourhood
+        assert s0.pop("oriented_entries") == 0 and s1.pop("oriented_entries") + hub_links > 0
+        if str(bm_hbm).startswith("hub") and K >= 2 and name in ("usair", "cora", "rand300"):
+            assert hub_links > 0                          # the cached neighbourhoods were used
         assert s0 == s1                                   # n, vol(S), induced edges, support: exact
         # two summation orders of the same fp32 sums (the multi-hop path walks the degree order)
         assert rel_err(r1.cpu().numpy(), r0.cpu().numpy()) < 3e-6
@@ -100,6 +106,7 @@ def test_onehop_path_degree_order_is_invisible(eng, monkeypatch, name, bm_hbm):
         st = dict(p1.stats)
         st.pop("workspace_bytes")
         st.pop("oriented_entries")        # ties of the (degree, id) orientation follow the id order walked
+        st.pop("hub_links"), st.pop("hub_read_bytes"), st.pop("hub_endpoint_entries"), st.pop("hub_nodes")   # (the cache belongs to the degree order)
         outs.append((p1.run(f).clone(), p1.row_ptr().clone(), p1.row_nodes().clone(),
                      [t.clone() for t in p1.export_subgraphs()], st))
         p0.close(), p1.close(), G0.close(), G1.close()
@@ -268,6 +275,8 @@ def test_cached_hub_neighbourhoods_equal_the_per_link_road(eng, monkeypatch, mod
         rows = p.run(f).clone()
         st = dict(p.stats)
         st.pop("workspace_bytes")
+        assert (st.pop("hub_links") > len(links) // 2) == cache and (st.pop("hub_read_bytes") > 0) == cache
+        st.pop("hub_endpoint_entries"), st.pop("oriented_entries"), st.pop("hub_nodes")
         exp = [t.clone() for t in p.export_subgraphs()]
         pf = eng.plan(G, L, mode=mode, num_hops=1, sign_k=3)                      # folded
         assert pf.stats["folded_links"] == 10
