@@ -183,7 +183,7 @@ def link_kernel_roofline(args, w, link_index, stats, phase_ms, K, F, collect):
     physical = sum(reads.values()) + sum(writes.values())
     traffic, traffic_source, l2_hit, pmc = None, None, None, None
     if collect:
-        rec = collect_pmc(args, kname, per_step=True)
+        rec = collect_pmc(args, kname.split(" + ") if " + " in kname else kname, per_step=True)
         if rec:
             traffic, l2_hit = rec["hbm_bytes_per_launch"], rec.get("l2_hit_rate")
             traffic_source = "collected by this run: child rocprofv3 --pmc passes of the same command, summed over the step's launches"

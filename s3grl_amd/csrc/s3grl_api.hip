@@ -118,8 +118,11 @@ __global__ void max_i32_kernel(const int32_t* __restrict__ in, int64_t n, int64_
   if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<long long*>(out), (long long)m);
 }
 
+constexpr float kHubCostSlope = 14.f;   // cost of a link at a cached hub per node of its subgraph (S3GRL_HUB_COST_SLOPE: fitting hook)
+
 __global__ void link_cost_kernel(const int32_t* __restrict__ n_nodes, const int32_t* __restrict__ e_cap,
-                                 const int64_t* __restrict__ row_ptr, int64_t L, float* __restrict__ cost) {
+                                 const int64_t* __restrict__ x_cap, const int64_t* __restrict__ row_ptr, int64_t L,
+                                 float hub_slope, float* __restrict__ cost) {
   const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= L) return;
   const int n = n_nodes[l];
@@ -132,8 +135,11 @@ __global__ void link_cost_kernel(const int32_t* __restrict__ n_nodes, const int3
   // every row pair beyond the first (PoS Plus: the common-neighbour rows) is another K passes over the
   // subgraph and another gather job over its list
   const float pairs = (float)((row_ptr[l + 1] - row_ptr[l] + 1) / 2);
-  cost[l] = e_cap ? (float)e_cap[l] + 150.f + (pairs - 1.f) * (float)n
-                  : pairs * (float)n + 400.f;
+  // one-hop plans on big graphs: a link served from a cached hub neighbourhood (link_hub_kernel) costs
+  // its pulls and its gather, both ~ n; the others the probes of their oriented rows
+  if (x_cap && x_cap[l] >= 0) cost[l] = hub_slope * (float)n + 1250.f + (pairs - 1.f) * (float)n;
+  else cost[l] = e_cap ? (float)e_cap[l] + 380.f + (pairs - 1.f) * (float)n
+                       : pairs * (float)n + 400.f;
 }
 
 // job_n[job_off[l] + p] = n_nodes[l]: every row pair of a link gets a list of the link's size
@@ -694,7 +700,10 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   if (onehop) {
     S3GRL_TRY(arena_alloc(ctx, (size_t)L, &e_cap, own));
     plan->e_cap = e_cap;
-    if (g_walk.hub.nh > 0 && !(cfg->flags & S3GRL_FLAG_COUNT_ONLY)) S3GRL_TRY(arena_alloc(ctx, (size_t)L, &x_cap, tr));
+    if (g_walk.hub.nh > 0) {
+      S3GRL_TRY(arena_alloc(ctx, (size_t)L, &x_cap, own));
+      plan->x_cap = x_cap;
+    }
     S3GRL_TRY(launch_count1(ctx, &g_walk, links_walk, L, plus ? 1 : 0, K, partner, mirror_of, plan->n_nodes, p_nodes,
                             n_rows, n_jobs, lvl_max, e_cap, reinterpret_cast<int32_t*>(ds), st + 3 * kStatRow,
                             st + 4 * kStatRow, perm, x_cap));
@@ -927,7 +936,8 @@ s3grl_status s3grl_plan_link_cost(const s3grl_plan* p, float* cost) {
   if (!p || (!cost && p->L)) return S3GRL_ERR_INVALID_ARGUMENT;
   if (p->L == 0) return S3GRL_OK;
   hipLaunchKernelGGL(link_cost_kernel, dim3((unsigned)((p->L + 255) / 256)), dim3(256), 0, p->ctx->stream,
-                     p->n_nodes, p->e_cap, p->row_ptr, p->L, cost);
+                     p->n_nodes, p->e_cap, p->x_cap, p->row_ptr, p->L,
+                     getenv("S3GRL_HUB_COST_SLOPE") ? (float)atof(getenv("S3GRL_HUB_COST_SLOPE")) : kHubCostSlope, cost);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }

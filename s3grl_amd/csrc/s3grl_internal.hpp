@@ -228,6 +228,8 @@ struct s3grl_plan {
   int64_t* job_off = nullptr;    // [L+1]
   int32_t* lvl = nullptr;        // [L, kMaxLevels] cumulative node count per BFS level
   int32_t* e_cap = nullptr;      // [L] bound of the induced entries (one-hop plans on big graphs), else null
+  int64_t* x_cap = nullptr;      // [L] ... and, on graphs with cached hub neighbourhoods: >= 0 for the links
+                                 // link_hub_kernel can take (staged cache bytes << 32 | bound of the found edges)
   bool relabelled = false;       // the kernels walked the graph's degree order (s3grl_relabel.hip)
   bool stats_pending = false;    // total_sub_edges / total_support / total_volume not read back yet
   bool hub_order = false;        // links worked on in hub order (launch_link_order); job_order follows it

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Fit of the one-hop link-cost model (include/s3grl.h, s3grl_plan_link_cost) on the collab-scale
+workload: links at a cached hub (cost = slope * n + c) and the others (cost = e_bound + c) are timed
+apart, in two buckets each (plan + run, best of 3), and (slope, c) solved per category.
+
+    S3GRL_HUB_COST_SLOPE=1000 python3 tools/cost_fit_onehop.py      (the slope only marks the hub links)"""
+import os
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+os.environ.setdefault("S3GRL_HUB_COST_SLOPE", "1000")
+import numpy as np
+import torch
+
+from s3grl_amd import workloads
+from s3grl_amd.engine import Engine
+
+w = workloads.make("collab_pos_k3")
+li, y = w.split.all_links()
+li = np.asarray(li)
+eng = Engine("cuda:0")
+g, x = eng.graph(w.A), eng.features(w.X)
+K, F = w.sign_k, w.X.shape[1]
+n = eng.subgraph_sizes(g, eng.links(li), num_hops=1).cpu().numpy().astype(np.float64)
+cost = eng.link_costs(g, eng.links(li), num_hops=1, mode="pos", fold_reversed=False).cpu().numpy().astype(np.float64)
+hub = cost >= 999.0 * n
+ecap = np.where(hub, 0.0, cost - 150.0)
+print(f"{hub.sum()} hub links (mean n {n[hub].mean():.0f}), {(~hub).sum()} others (mean n {n[~hub].mean():.1f}, mean e_bound {ecap[~hub].mean():.1f})")
+
+
+def run(sel):
+    links = li[:, sel]
+    lk = eng.links(links)
+    out = torch.empty((2 * links.shape[1], K + 1, F + 1), device=eng.device)
+    best = 1e9
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        p = eng.plan(g, lk, mode="pos", num_hops=1, sign_k=K)
+        p.run(x, out)
+        p.close()
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return best * 1e3
+
+
+rows = []
+for name, mask, var in (("hub", hub, n), ("other", ~hub, ecap)):
+    idx = np.flatnonzero(mask)
+    med = np.median(var[idx])
+    for half, sel in (("low", idx[var[idx] <= med]), ("high", idx[var[idx] > med])):
+        ms = run(sel)
+        rows.append((name, half, len(sel), var[sel].sum(), ms))
+        print(f"{name:5s} {half:4s}: {len(sel):7d} links, sum of size variable {var[sel].sum():.3e}, {ms:.3f} ms")
+for name in ("hub", "other"):
+    (_, _, c1, s1, t1), (_, _, c2, s2, t2) = [r for r in rows if r[0] == name]
+    A = np.array([[s1, c1], [s2, c2]])
+    a, b = np.linalg.solve(A, np.array([t1, t2]))
+    print(f"{name}: ms = {a:.3e} * size + {b:.3e} * links   ->  per link {b / a:.0f} size units of fixed cost")
+ref = [r for r in rows if r[0] == "other"]
