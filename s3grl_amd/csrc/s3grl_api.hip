@@ -685,12 +685,17 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   }
   if (!relabel) g_walk.hub = HubCache{};   // the cache is the degree-ordered graph's
   plan->relabelled = relabel;
-  // Big graph, long list: the links are worked on in the order of their higher-degree endpoint
-  // (launch_link_order) — sizing pass, link kernels (through the class lists) and gather.  Small graphs
-  // sit in the caches whatever the order and keep the longest-first gather order.
+  // Long lists are worked on in the order of their links' higher-degree endpoint (launch_link_order):
+  // the sizing pass and the link kernels (through the class lists) on any graph — PubMed's sizing pass
+  // 1.32 -> 1.24 ms, the sort included — and on big graphs the gather too; small graphs sit in the
+  // caches whatever the order and keep the longest-first gather order (PubMed: 7.07 vs 7.21 ms).
   int32_t* perm = nullptr;
-  bool hub_order = g->num_nodes > kHubOrderMinNodes && L >= kHubOrderMinLinks;
-  if (const char* e = getenv("S3GRL_HUB_ORDER")) hub_order = atoi(e) != 0;   // test hook
+  bool hub_order = L >= kHubOrderMinLinks;
+  bool hub_gather = hub_order && g->num_nodes > kHubOrderMinNodes;
+  if (const char* e = getenv("S3GRL_HUB_ORDER")) {   // test hook: 0 off, 1 on (gather too), 2 sizing pass + link kernels only
+    hub_order = atoi(e) != 0;
+    hub_gather = atoi(e) == 1;
+  }
   if (hub_order) {
     S3GRL_TRY(arena_alloc(ctx, (size_t)L, &perm, tr));
     S3GRL_TRY(launch_link_order(ctx, links_walk, L, g->num_nodes, g_walk.indptr, perm));
@@ -782,14 +787,14 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
     S3GRL_TRY(arena_alloc(ctx, (size_t)std::max<int64_t>(njobs, 1), &plan->job_order, own));
     int32_t* pc = nullptr;
     int64_t* po = nullptr;
-    if (perm) {
+    if (perm && hub_gather) {
       S3GRL_TRY(arena_alloc(ctx, (size_t)L, &pc, tr));
       S3GRL_TRY(arena_alloc(ctx, (size_t)(L + 1), &po, tr));
     }
-    S3GRL_TRY(launch_job_order(ctx, plan->n_nodes, n_jobs, plan->job_off, L, hist, plan->job_order, perm, pc, po,
-                               scan_ws));
+    S3GRL_TRY(launch_job_order(ctx, plan->n_nodes, n_jobs, plan->job_off, L, hist, plan->job_order,
+                               hub_gather ? perm : nullptr, pc, po, scan_ws));
   }
-  plan->hub_order = perm != nullptr;
+  plan->hub_order = perm != nullptr && hub_gather;
 
   // coefficient lists: one per row pair, sized by the link's node count
   const int64_t* coef_off = nullptr;          // PoS: one pair per link, list at node_off[link]

@@ -86,7 +86,8 @@ __global__ void hub_mark_kernel(const int32_t* __restrict__ indptr, const int32_
 
 __global__ void hub_list_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ flag,
                                 const int64_t* __restrict__ off, int64_t N, int32_t* __restrict__ slot,
-                                int32_t* __restrict__ hubs, int32_t* __restrict__ rows) {
+                                int32_t* __restrict__ hubs, int32_t* __restrict__ rows,
+                                const int32_t* __restrict__ voln, unsigned long long* __restrict__ work) {
   const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= N) return;
   if (flag[u]) {
@@ -94,6 +95,7 @@ __global__ void hub_list_kernel(const int32_t* __restrict__ indptr, const int32_
     slot[u] = k;
     hubs[k] = (int32_t)u;
     rows[k] = indptr[u + 1] - indptr[u] + 1;   // one offset entry per neighbour + the end
+    atomicAdd(work, (unsigned long long)voln[u]);   // neighbour tests the cache of this hub costs to build
   } else {
     slot[u] = -1;
   }
@@ -931,9 +933,12 @@ s3grl_status build_hub_cache(s3grl_context* ctx, s3grl_graph* g) {
   S3GRL_TRY(talloc((size_t)nh * 4, &hubs_v));
   S3GRL_TRY(talloc((size_t)nh * 4, &rows_v));
   S3GRL_TRY(talloc((size_t)scan_workspace_elems(nh) * 8, &ws2_v));
+  S3GRL_HIP_TRY(hipMemsetAsync(ctx->d_scalars, 0, 8, ctx->stream));
   hipLaunchKernelGGL(hub_list_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, indptr, flag, off,
-                     N, hc.slot, static_cast<int32_t*>(hubs_v), static_cast<int32_t*>(rows_v));
+                     N, hc.slot, static_cast<int32_t*>(hubs_v), static_cast<int32_t*>(rows_v), hc.voln,
+                     reinterpret_cast<unsigned long long*>(ctx->d_scalars));
   S3GRL_HIP_TRY(hipGetLastError());
+  S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_scalars + 1, ctx->d_scalars, 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_TRY(ctx->arena.alloc((size_t)(nh + 1) * 8, &q));
   g->hub.row_base = hc.row_base = static_cast<int64_t*>(q);
   S3GRL_TRY(ctx->arena.alloc((size_t)(nh + 1) * 8, &q));
@@ -942,6 +947,14 @@ s3grl_status build_hub_cache(s3grl_context* ctx, s3grl_graph* g) {
   S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_scalars, hc.row_base + nh, 8, hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
   const int64_t rows_total = ctx->h_scalars[0];
+  // Σ over the hubs of Σ degree over their neighbours = the neighbour tests of the build (twice: count,
+  // fill).  A graph whose hubs are not rare (mean degree in the hundreds) would spend seconds here, and
+  // its hub links are no cheaper from a cache of dense neighbourhoods: no cache beyond 2^30 tests.
+  if (ctx->h_scalars[1] > ((int64_t)1 << 30) && !getenv("S3GRL_HUB_MIN_DEG")) {
+    S3GRL_HIP_TRY(hipMemsetAsync(hc.slot, 0xff, (size_t)N * 4, ctx->stream));
+    S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return S3GRL_OK;
+  }
   void *cnt_v, *abs_v, *ws3_v;
   S3GRL_TRY(talloc((size_t)rows_total * 4, &cnt_v));
   S3GRL_TRY(talloc((size_t)(rows_total + 1) * 8, &abs_v));

@@ -292,3 +292,30 @@ def test_cached_hub_neighbourhoods_equal_the_per_link_road(eng, monkeypatch, mod
 
     ref, ptr, _, _ = c_oracle.pos_rows(links.T, 1, A, X, 3, plus=mode == "pos_plus")
     assert rel_err(rb.cpu().numpy(), ref) < TOL
+
+
+def test_no_hub_cache_on_a_graph_whose_hubs_are_not_rare(eng, monkeypatch):
+    """Mean degree in the hundreds: every node would be a "hub", the cache of all those dense
+    neighbourhoods would cost more than 2^30 neighbour tests to build — it is skipped and every link
+    stays on link_full_kernel (hub_links == 0), results against the C restatement."""
+    from oracle import c_oracle
+    from s3grl_amd import workloads
+
+    rng = np.random.default_rng(4)
+    n, m = 8000, 1_700_000
+    e = rng.integers(0, n, size=(m, 2))
+    e = e[e[:, 0] != e[:, 1]]
+    A = workloads.csr_from_undirected(n, np.unique(np.sort(e, axis=1), axis=0))
+    assert np.diff(A.indptr).min() >= 256
+    links = rng.integers(0, n, size=(12, 2))
+    links = links[links[:, 0] != links[:, 1]]
+    X = rng.standard_normal((n, 8)).astype(np.float32)
+    monkeypatch.setenv("S3GRL_FORCE_ONEHOP", "1")
+    monkeypatch.setenv("S3GRL_FORCE_HASH", "1")
+    G = eng.graph(A)
+    p = eng.plan(G, eng.links(links.T), mode="pos", num_hops=1, sign_k=2)
+    rows = p.run(eng.features(X)).cpu().numpy()
+    assert p.stats["hub_links"] == 0 and p.stats["oriented_entries"] > 0
+    ref, ptr, _, _ = c_oracle.pos_rows(links.T, 1, A, X, 2)
+    assert rel_err(rows, ref) < TOL
+    p.close(), G.close()
