@@ -947,6 +947,17 @@ s3grl_status s3grl_plan_link_cost(const s3grl_plan* p, float* cost) {
   return S3GRL_OK;
 }
 
+// measurement hook (tools/xcd_locality_probe.py; not in include/s3grl.h): replaces the order in which the
+// gather takes the plan's jobs
+s3grl_status s3grl_debug_set_job_order(s3grl_plan* p, const int32_t* order, int64_t n) {
+  if (!p || !order || n != p->njobs) return S3GRL_ERR_INVALID_ARGUMENT;
+  S3GRL_HIP_TRY(hipMemcpyAsync(p->job_order, order, (size_t)n * 4, hipMemcpyDeviceToDevice, p->ctx->stream));
+  if (p->npieces)
+    S3GRL_HIP_TRY(hipMemcpyAsync(p->g_order + p->npieces, order, (size_t)n * 4, hipMemcpyDeviceToDevice,
+                                 p->ctx->stream));
+  return S3GRL_OK;
+}
+
 s3grl_status s3grl_plan_row_ptr(const s3grl_plan* p, int64_t* row_ptr) {
   if (!p || !row_ptr) return S3GRL_ERR_INVALID_ARGUMENT;
   S3GRL_HIP_TRY(hipMemcpyAsync(row_ptr, p->row_ptr, (size_t)(p->L + 1) * 8, hipMemcpyDeviceToDevice,
