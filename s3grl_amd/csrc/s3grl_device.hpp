@@ -95,8 +95,19 @@ constexpr int kHubFactor = 8;
 // the hub path (one extra barrier per walk) is armed only for graphs that have real hubs:
 // PubMed (max degree 171) runs 5 % faster without it, a power-law graph 20 % faster with it
 constexpr int kHubArmDegree = 256;
-constexpr int kHubCap = 255;     // deferred hub rows per call; further ones are walked in place
-constexpr int kHubWords = kHubCap + 1;   // {count, row positions...}
+// Deferred hub rows are marked in a bitmap over the list positions of the walk — EVERY hub row is summed by
+// a wavefront, whatever order the lanes reach it in (a list of the first 255 to arrive made the lane
+// assignment of the 256th — and its sum's last bit — depend on the order of an atomic: 36 links of the
+// collab-scale list).  kHubWords words cover kHubWords * 32 rows; longer walks go chunk by chunk.
+constexpr int kHubWords = 256;
+constexpr int kHubChunk = kHubWords * 32;
+
+// all-zero before the first walk of a kernel (walk_rows leaves it that way); called by every thread
+template <int T>
+__device__ __forceinline__ void hub_rows_clear(int* hub) {
+  if (hub)
+    for (int t = threadIdx.x; t < kHubWords; t += T) hub[t] = 0;
+}
 
 template <int T, int G, int UN, typename Visit, typename Commit>
 __device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
@@ -106,6 +117,10 @@ __device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
   const int tid = threadIdx.x;
   const int g = tid & (G - 1);
   constexpr int RPI = T / G;  // rows per wave-iteration slice
+  const int r_begin = r0, r_end = r1;
+  for (int chunk0 = r_begin; chunk0 < r_end; chunk0 += hub ? kHubChunk : max(r_end - r_begin, 1)) {
+  r0 = chunk0;
+  r1 = hub ? min(chunk0 + kHubChunk, r_end) : r_end;
   for (int base = r0; base < r1; base += UN * RPI) {
     // all loads of a stage are unconditional (clamped to a valid location, results selected
     // afterwards): predicated loads make hipcc wait after each one
@@ -126,13 +141,8 @@ __device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
     for (int u = 0; u < UN; ++u) {
       bool ok = t[u] < r1;
       if (hub && ok && be[u].y - be[u].x > kHubFactor * G) {   // uniform over the row's G lanes
-        int slot = kHubCap;
-        if (g == 0) slot = atomicAdd(&hub[0], 1);
-        slot = __shfl(slot, (tid & 63) & ~(G - 1));
-        if (slot < kHubCap) {
-          if (g == 0) hub[1 + slot] = t[u];
-          ok = false;
-        }
+        if (g == 0) atomicOr(reinterpret_cast<uint32_t*>(hub) + ((t[u] - r0) >> 5), 1u << ((t[u] - r0) & 31));
+        ok = false;
       }
       c0[u] = ok ? be[u].x + g : 0;
       e1[u] = ok ? be[u].y : 0;
@@ -222,10 +232,13 @@ __device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
   // maximum degree is below the hub threshold) skips the phase and its barriers.
   if (!hub) return;
   __syncthreads();
-  const int nh = min(hub[0], kHubCap);
   const int lane = tid & 63;
-  for (int h = tid >> 6; h < nh; h += T / 64) {
-    const int tt = hub[1 + h];
+  const int hub_words = (r1 - r0 + 31) >> 5;
+  for (int hw = tid >> 6; hw < hub_words; hw += T / 64) {
+   uint32_t hub_bits = reinterpret_cast<const uint32_t*>(hub)[hw];   // (uniform over the wavefront)
+   while (hub_bits) {
+    const int tt = r0 + hw * 32 + __ffs(hub_bits) - 1;
+    hub_bits &= hub_bits - 1;
     const int v = list[tt];
     const int e1 = indptr[v + 1];
     RowAcc acc{0.f, 0.f, 0, tt};
@@ -243,10 +256,12 @@ __device__ __forceinline__ void walk_rows(int r0, int r1, const int32_t* list,
       acc.n += __shfl_xor(acc.n, o);
     }
     if (lane == 0) commit(acc, tt, v);
+   }
   }
   __syncthreads();
-  if (tid == 0) hub[0] = 0;
+  for (int hw = tid; hw < hub_words; hw += T) hub[hw] = 0;
   __syncthreads();
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -387,8 +402,8 @@ __device__ __forceinline__ int bfs_list(const int32_t* __restrict__ indptr,
     list[0] = min(src, dst);
     list[1] = max(src, dst);
     lvl_end[0] = 2;
-    if (hub) hub[0] = 0;
   }
+  hub_rows_clear<T>(hub);
   __syncthreads();
   int n = 2, nlev = 1;  // levels 0..nlev-1 are complete
   if (walks) hops = 1;  // ScaLed: "level 1" = what the cached random walks of src and dst visited
@@ -519,8 +534,8 @@ __device__ __forceinline__ int bfs_hash(const int32_t* __restrict__ indptr,
     list[1] = b;
     lvl_end[0] = 2;
     *cnt = 2;
-    if (hub) hub[0] = 0;
   }
+  hub_rows_clear<T>(hub);
   __syncthreads();
   int n = 2, nlev = 1;
   if (walks) hops = 1;

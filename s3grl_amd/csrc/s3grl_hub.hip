@@ -441,12 +441,21 @@ __global__ __launch_bounds__(T) void link_hub_kernel(const HubLinkArgs a, const 
       mine += dgx;
       packed += tr == 0 ? 1 : (tr >= 1 ? (1 << 16) : 0);   // (long rows beyond the cap join the four-lane ones)
     }
-    int total, ptotal;
+    int nlong_mine = 0;
+    for (int t = t0; t < t1; ++t) {
+      const int cached = (t >= 1 && t <= c) ? hoff(t) - hoff(t - 1) : 0;
+      nlong_mine += tier_of(t, offx[t] + cached) == 2 ? 1 : 0;
+    }
+    int total, ptotal, ltotal;
     int run = block_excl_scan<T>(mine, sh, total);
     int prun = block_excl_scan<T>(packed, sh, ptotal);
+    // long rows in row order: the first kHubLongCap get a wavefront (not "the first to arrive": which
+    // rows do decides the last bit of their sums)
+    int lrun = block_excl_scan<T>(nlong_mine, sh, ltotal);
     if (tid == 0) {
       sh[33] = ptotal & 0xffff;
       sh[34] = ptotal >> 16;
+      sh[29] = ltotal;
     }
     for (int t = t0; t < t1; ++t) {
       const int dgx = offx[t];
@@ -461,7 +470,7 @@ __global__ __launch_bounds__(T) void link_hub_kernel(const HubLinkArgs a, const 
       } else if (tr >= 1) {
         // a slot in the four-lane list either way; long rows that get a wavefront leave a hole marked 0
         int q = kHubLongCap;
-        if (tr == 2) q = atomicAdd(&sh[29], 1);
+        if (tr == 2) q = lrun++;
         if (q < kHubLongCap) longrows[q] = (uint16_t)t;
         tier[n - 1 - (prun >> 16)] = q < kHubLongCap ? (uint16_t)0 : (uint16_t)t;
         prun += 1 << 16;

@@ -551,17 +551,28 @@ __global__ __launch_bounds__(T) void link_full_kernel(
     // it to more): four lanes would stride such a row for hundreds of trips while the rest of the
     // workgroup waits at the barrier of the pass.  They are registered here (sign bit of their
     // D^-1/2 as the per-row flag) and summed by a whole wavefront each, after the short rows.
-    for (int t = tid; t < n; t += T) {
-      if (off[t + 1] - off[t] > kLongRow) {
-        const int q = atomicAdd(&sh[29], 1);
-        if (q < kLongCap) {
-          longrows[q] = (uint16_t)t;
-          dinv[t] = -dinv[t];
+    // (the first kLongCap of them in row order — a block scan, not the order of an atomic: which rows
+    // get a wavefront decides the last bit of their sums)
+    int nlong;
+    {
+      const int per = (n + T - 1) / T;
+      const int t0 = min(tid * per, n), t1 = min(t0 + per, n);
+      int mine = 0;
+      for (int t = t0; t < t1; ++t) mine += off[t + 1] - off[t] > kLongRow ? 1 : 0;
+      int total;
+      int q = block_excl_scan<T>(mine, sh, total);
+      for (int t = t0; t < t1; ++t) {
+        if (off[t + 1] - off[t] > kLongRow) {
+          if (q < kLongCap) {
+            longrows[q] = (uint16_t)t;
+            dinv[t] = -dinv[t];
+          }
+          ++q;
         }
       }
+      nlong = min(total, kLongCap);
     }
     __syncthreads();
-    const int nlong = min(sh[29], kLongCap);
 
     // ---- per row pair: K pulls over the CSR ------------------------------------------------------
     const int npairs = (R + 1) / 2;

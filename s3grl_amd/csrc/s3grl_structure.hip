@@ -160,8 +160,8 @@ __global__ __launch_bounds__(kCountBlock) void count_kernel(
     }
     list[0] = src;
     list[1] = dst;
-    if (hub) hub[0] = 0;
   }
+  hub_rows_clear<kCountBlock>(hub);
   __syncthreads();
   // The frontier is a node list (G lanes per node: no serial row walks) as long as the levels
   // below `hops` fit kCountList entries; beyond that it degrades to a bitmap walked one thread
@@ -967,8 +967,8 @@ __global__ __launch_bounds__(T) void link_kernel(
     if (tid == 0) {
       list[0] = min(src, dst);
       list[1] = max(src, dst);
-      if (hub) hub[0] = 0;
     }
+    hub_rows_clear<T>(hub);
     __syncthreads();
     for (int t = tid; t < n_alloc; t += T) {
       const int v = t < 2 ? list[t] : st[t - 2];

@@ -1228,6 +1228,42 @@ def test_hub_processing_order_changes_no_bit(eng, monkeypatch, name, hops, mode,
     G.close()
 
 
+def test_many_hub_rows_are_summed_the_same_way_in_every_plan(eng):
+    """Rows of more than 8·G stored neighbours are summed by a wavefront each (walk_rows).  They used to
+    be collected in a list of 255 — which rows got a slot, and with it the last bit of the others' sums,
+    depended on the order of an atomic once a subgraph held more (36 links of the collab-scale list
+    differed between two plans of the same list).  Now every such row is marked in a bitmap.  Two-hop
+    subgraphs around the hubs of a power-law graph (hundreds of hub rows each): the same bits from two
+    plans, from a plan of a part of the list, and — one-hop, the long rows of link_full_kernel — too."""
+    import torch
+    from oracle import c_oracle
+    from s3grl_amd import workloads
+
+    n, e = workloads.chung_lu(30000, 150000, seed=5)
+    A = workloads.csr_from_undirected(n, e)
+    deg = np.diff(A.indptr)
+    hubs = np.argsort(-deg)[:10]
+    assert deg[hubs[0]] > 256 and (deg > 64).sum() > 300
+    rng = np.random.default_rng(1)
+    links = np.array([(int(a), int(b)) for i, a in enumerate(hubs) for b in hubs[i + 1:i + 4]] +
+                     [(int(h), int(v)) for h in hubs for v in rng.integers(0, n, 3) if v != h])
+    X = rng.standard_normal((n, 16)).astype(np.float32)
+    G = eng.graph(A)
+    f = eng.features(X)
+    for hops in (2, 1):
+        outs = []
+        for sel in (slice(None), slice(None), slice(0, len(links) // 2)):
+            p = eng.plan(G, eng.links(links[sel].T), mode="pos", num_hops=hops, sign_k=3)
+            outs.append(p.run(f).clone())
+            big = p.stats["max_nodes"]
+            p.close()
+        assert torch.equal(outs[0], outs[1])
+        assert torch.equal(outs[0][:outs[2].shape[0]], outs[2])
+        ref, _, _, _ = c_oracle.pos_rows(links.T, hops, A, X, 3)
+        assert rel_err(outs[0].cpu().numpy(), ref) < TOL, (hops, big)
+    f.close(), G.close()
+
+
 @pytest.mark.parametrize("mode", ["pos", "pos_plus"])
 def test_half_million_nodes_two_hops_vs_c(eng, mode):
     """A 500 000-node power-law graph, two hops: beyond the LDS bitmap limit.  The sizing pass keeps
