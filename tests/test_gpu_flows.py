@@ -333,3 +333,33 @@ def test_link_costs_and_sizes_from_the_sizing_pass():
         p.run(eng.features(np.ones((n, 4), dtype=np.float32)))
     p.close()
     eng.close()
+
+
+def test_pos_call_computed_and_copied_piece_by_piece(monkeypatch):
+    """Long PoS lists through the drop-in operator are computed in pieces whose rows travel to the host
+    while the next piece is computed (tuned_SIGN._pos_pipelined): the same tensor, bit for bit, as the
+    whole-list call — reversed duplicates cut apart by a piece boundary included."""
+    import torch
+    from s3grl_amd import tuned_SIGN, workloads
+    from s3grl_amd.tuned_SIGN import OptimizedSignOperations as ops
+
+    w = workloads.make("cora_posplus_k3")
+    A = w.A
+    n = A.shape[0]
+    rng = np.random.default_rng(0)
+    pos = np.stack(A.nonzero())                                    # both directions of every edge
+    neg = rng.integers(0, n, size=(2, 40000 - pos.shape[1] % 40000))
+    neg = neg[:, neg[0] != neg[1]]
+    li = torch.from_numpy(np.concatenate([pos, neg], 1)[:, :40000].astype(np.int64))
+    assert li.shape[1] >= tuned_SIGN._PIPE_MIN_LINKS
+    X = torch.from_numpy(np.ascontiguousarray(w.X[:, :24], dtype=np.float32))
+    kw = {"sign_k": 3, "k_node_set_strategy": "intersection"}
+    outs = []
+    for pieces in ("1", "4", "3"):
+        monkeypatch.setenv("S3GRL_D2H_PIECES", pieces)
+        lst = ops.get_PoS_prepped_ds(li, 2, A, 1.0, None, False, None, X, 1, kw, None)
+        rows, ptr, _ = lst.collate()
+        assert rows.device.type == "cpu" and rows.shape[0] == 2 * li.shape[1]
+        outs.append(rows.clone())
+    tuned_SIGN.clear_cache()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
