@@ -37,8 +37,8 @@ namespace {
 // Rows of a pull by their length (cached + found entries; the star edge comes on top).  Half of a hub's
 // neighbours have no edge inside the neighbourhood at all and nine in ten at most a handful: one LANE per
 // row up to kHubTinyRow entries, four lanes up to kHubLongRow, a whole wavefront beyond (at most
-// kHubLongCap rows per link, further ones stay with their four lanes).  The kernel is bound by
-// instruction issue: four lanes for every row cost 3.5x the instructions of this split.
+// kHubLongCap rows per link — the first in row order — further ones stay with their four lanes).  (Row
+// counts per tier travel through one block scan packed 16 + 16 bits: a link here has a few thousand rows.)
 constexpr int kHubTinyRow = 4;
 constexpr int kHubLongRow = 48;
 constexpr int kHubLongCap = 128;
@@ -166,10 +166,11 @@ __global__ void hub_offsets_kernel(const int64_t* __restrict__ row_base, int nh,
 }
 
 // ---- the per-link kernel -----------------------------------------------------------------------------
-// LDS (dynamic): cn[cn_cap] cnpos[cn_cap] zbuf[4K] sh[40] longrows[kHubLongCap] dinv[n] offx[n+1] | region |
-// colsx[2·xcap] (uint16).  region = the state arrays cur[n], nxs[n] (float2) of the passes; before them it
+// LDS (dynamic): cn[cn_cap] cnpos[cn_cap] zbuf[4K] sh[72] longrows[kHubLongCap] dinv[n] offx[n+1] | region |
+// the hub's cached rows (offsets, columns: uint16) | tier[n] | cols[2·xcap] (uint16), hub_lds_need() +
+// hub_stage_bytes().  region = the state arrays cur[n], nxs[n] (float2) of the passes; before them it
 // holds the node list nl[n-1] (local ids 1..n-1: N(h) staged, then the other endpoint's nodes) and the list
-// of found edges, then the scatter cursors and the per-wave sort bitmaps.
+// of found edges, then the scatter cursors, the lists of rows to sort and the per-wave sort bitmaps.
 // XG (the class of links whose BOUND of found edges does not fit LDS — the bound is loose, Σ degree over
 // the other endpoint's neighbourhood, the edges found are a few per cent of it): a persistent grid, the
 // list of found edges in this workgroup's HBM slice, the small CSR's columns on chip whenever the EXACT
