@@ -427,6 +427,9 @@ def main():
     ap.add_argument("--exchange-operator0", action="store_true",
                     help="N > 1: all-gather whole rows (operator 0 = X[node] included) instead of letting every rank "
                          "fill operator 0 from its own copy of X (comparison)")
+    ap.add_argument("--exchange-mirrors", action="store_true",
+                    help="N > 1: all-gather the rows of reversed duplicates too instead of rebuilding them on every "
+                         "rank from their primaries' rows (comparison)")
     ap.add_argument("--no-allgather", action="store_true",
                     help="N > 1: every rank keeps its shard (data-parallel consumer); no collective")
     ap.add_argument("--verify", action="store_true",
@@ -546,7 +549,8 @@ def main():
                     compute, li_dev, rank=rank, world_size=world, gather=gather,
                     rows_per_link=2, chunks=args.chunks if gather else 1, row_shape=(K + 1, F + 1),
                     device=eng.device, timers=timers, reuse_buffers=True, shards=shards,
-                    local_operator0=None if args.exchange_operator0 else fill_operator0)
+                    local_operator0=None if args.exchange_operator0 else fill_operator0,
+                    mirror_rows=not args.exchange_mirrors and not args.contiguous_shards)
         else:
             def compute_ragged(shard):
                 res = eng.precompute(g, x, eng.links(shard), mode=w.mode, num_hops=w.num_hops, sign_k=K)
@@ -559,6 +563,10 @@ def main():
                                                    gather=gather, shards=shards)
         b = shards.bounds
         shard_info = {"bounds": b, "links_per_rank": [b[r + 1] - b[r] for r in range(world)]}
+        if fixed_rows and gather and not args.exchange_mirrors and not args.contiguous_shards:
+            sent = [sum(nr) for nr in shards.transport(args.chunks, eng.device)[3]]
+            shard_info["links_sent_per_rank"] = sent
+            shard_info["links_not_sent"] = L - sum(sent)
 
     def step():
         if world > 1:
@@ -629,7 +637,7 @@ def main():
     # collective costs when nothing overlaps it
     allgather_alone = None
     if world > 1 and fixed_rows and not args.no_allgather and backend == "nccl":
-        rmax = 2 * max(shard_info["links_per_rank"])
+        rmax = 2 * max(shard_info.get("links_sent_per_rank") or shard_info["links_per_rank"])   # rows that travel
         kx = K + 1 if args.exchange_operator0 else K          # operators that travel
         buf = torch.empty((world * rmax, kx, F + 1), dtype=torch.float32, device=eng.device)
         torch.cuda.synchronize()
@@ -675,9 +683,14 @@ def main():
                               ("%d padded all_gather_into_tensor per step (pieces of a shard are gathered on "
                                "RCCL's stream while the next piece is computed) + scatter into list order" % args.chunks +
                                ("" if args.exchange_operator0 else
-                                "; operators 1..K travel, operator 0 (= [1 | X[node]]) is filled by every rank itself")
+                                "; operators 1..K travel, operator 0 (= [1 | X[node]]) is filled by every rank itself") +
+                               ("" if args.exchange_mirrors or args.contiguous_shards else
+                                "; a link that follows its reverse in a rank's piece does not travel: its rows are the "
+                                "primary's in swapped order, rebuilt on every rank (%d of %d links)"
+                                % (shard_info.get("links_not_sent", 0), L))
                                if fixed_rows else "sizes + one padded all_gather_into_tensor + compaction"),
                 "backend": backend, "links_per_rank": shard_info["links_per_rank"],
+                "links_sent_per_rank": shard_info.get("links_sent_per_rank"),
                 "per_rank": per_rank,
                 "compute_ms_per_rank": comp,
                 "imbalance_max_over_mean": max(comp) / (sum(comp) / len(comp)) if sum(comp) > 0 else None,

@@ -48,8 +48,8 @@ def shard_assignment(link_index, world_size, cost=None, pair_aware=True):
     still folds the reversed duplicate into its primary there (the reference's train positives hold
     both directions of every train edge: 23 % of PubMed's list is served for free on one GPU, and
     contiguous ranges of the permuted list split most of those pairs across ranks).  Pairs are
-    taken in order of first appearance and cut into `world_size` runs of equal total cost, so the
-    assignment follows the list order as far as the pairs allow.  Without pair_aware: contiguous
+    taken in order of first appearance and cut into `world_size` runs of equal total cost — the pairs
+    present in both directions and the others separately, a rank taking one run of each.  Without pair_aware: contiguous
     ranges (`shard_bounds`), order = identity."""
     li = np.asarray(torch.as_tensor(link_index).cpu())
     L = int(li.shape[1])
@@ -60,11 +60,20 @@ def shard_assignment(link_index, world_size, cost=None, pair_aware=True):
     _, first, inv = np.unique(key, return_index=True, return_inverse=True)
     c = np.ones(L) if cost is None else np.asarray(cost, dtype=np.float64)
     gcost = np.bincount(inv, weights=c, minlength=len(first))
-    gorder = np.argsort(first, kind="stable")                  # pairs by first appearance
-    gb = shard_bounds(len(gorder), world_size, gcost[gorder])  # runs of pairs of equal total cost
-    rank_of_group = np.empty(len(gorder), dtype=np.int64)
-    for r in range(world_size):
-        rank_of_group[gorder[gb[r]:gb[r + 1]]] = r
+    # Pairs present in BOTH directions and the others are cut apart, each kind into `world_size` runs of
+    # equal cost, and rank r takes run r of either kind: every rank then holds the same share of reversed
+    # duplicates — of what the mirror-free exchange (`mirror_rows`) does not put on the wire.  A padded
+    # all-gather moves world_size x the LARGEST contribution: with the pairs simply in list order the ranks
+    # that hold the negatives (no reversed duplicates) set that size for everybody.
+    fwd = np.bincount(inv, weights=(li[0] <= li[1]).astype(np.float64), minlength=len(first))
+    both_dirs = (fwd > 0) & (fwd < np.bincount(inv, minlength=len(first)))
+    rank_of_group = np.empty(len(first), dtype=np.int64)
+    for kind in (True, False):
+        members = np.flatnonzero(both_dirs == kind)
+        gorder = members[np.argsort(first[members], kind="stable")]   # pairs by first appearance
+        gb = shard_bounds(len(gorder), world_size, gcost[gorder])      # runs of pairs of equal total cost
+        for r in range(world_size):
+            rank_of_group[gorder[gb[r]:gb[r + 1]]] = r
     rank_of_link = rank_of_group[inv]
     # inside a rank: pair by pair (first appearance), the two directions next to each other — a rank's
     # list is cut into pieces for the pipelined all-gather, and a cut must not separate partners
@@ -88,6 +97,57 @@ class ShardPlan:
         dev = li.device if device is None else torch.device(device)
         self.links = li.to(dev)[:, self.order.to(dev)].contiguous()
         self.order_dev = self.order.to(dev)
+        # a link that is the reverse of the one right before it in a rank's list (pair-aware shards put the
+        # two directions of a pair next to each other, the first of the list first): its two rows are the
+        # other's in swapped order, so they need not travel (see `_fixed(..., mirror_rows=True)`)
+        sl = np.asarray(self.links.cpu())
+        rev = np.zeros(self.num_links, dtype=bool)
+        if pair_aware and self.num_links > 1:
+            rev[1:] = (sl[0, 1:] == sl[1, :-1]) & (sl[1, 1:] == sl[0, :-1]) & (sl[0, 1:] != sl[1, 1:])
+            for r in range(world_size):                     # never across a rank boundary
+                if 0 < self.bounds[r] < self.num_links:
+                    rev[self.bounds[r]] = False
+            # (a, b), (b, a), (a, b): the third is the reverse of a mirror, not of a primary — it travels
+            run = rev.copy()
+            run[1:] &= rev[:-1]
+            while run.any():
+                rev[np.flatnonzero(run & ~np.roll(run, 1))] = False
+                run = rev.copy()
+                run[1:] &= rev[:-1]
+        self.reverse_of_previous = rev
+        self._transport = {}
+
+    def transport(self, chunks, device):
+        """Per piece c (of `chunks` per rank) and rank r, for the mirror-free exchange of `_fixed`:
+        `pb[r]` piece bounds, `prim[r][c]` positions inside the piece of the links that travel,
+        `mir[r][c]` = (positions inside the piece of the links that do not, index of their primary among
+        the piece's travelling links) — device tensors, made once."""
+        key = (int(chunks), str(device))
+        t = self._transport.get(key)
+        if t is not None:
+            return t
+        world = len(self.bounds) - 1
+        pb = [chunk_bounds(self.bounds[r], self.bounds[r + 1], chunks, self.cost) for r in range(world)]
+        prim, mir, nprim = [], [], []
+        for r in range(world):
+            pr, mr, nr = [], [], []
+            for c in range(chunks):
+                p0, p1 = pb[r][c], pb[r][c + 1]
+                m = self.reverse_of_previous[p0:p1].copy()
+                if len(m):
+                    m[0] = False                           # its primary sits in the piece before: it travels
+                keep = np.flatnonzero(~m)
+                slot_of = np.cumsum(~m) - 1                # travelling links before-or-at every position
+                mpos = np.flatnonzero(m)
+                pr.append(torch.from_numpy(keep).to(device))
+                mr.append((torch.from_numpy(mpos).to(device), torch.from_numpy(slot_of[mpos]).to(device)))
+                nr.append(len(keep))
+            prim.append(pr)
+            mir.append(mr)
+            nprim.append(nr)
+        t = (pb, prim, mir, nprim)
+        self._transport[key] = t
+        return t
 
 
 def link_cost(A, link_index):
@@ -156,7 +216,7 @@ def _all_gather(out, inp, group, async_op=False):
 def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, group=None, gather=True,
                        rows_per_link=None, chunks=1, row_shape=None, dtype=torch.float32,
                        device=None, timers=None, collective_at_world1=False, reuse_buffers=False,
-                       pair_aware=False, shards=None, local_operator0=None):
+                       pair_aware=False, shards=None, local_operator0=None, mirror_rows=False):
     """Shard `link_index` ([2, L]) over the ranks and (when `gather`) reassemble the whole result
     on every rank.
 
@@ -173,8 +233,12 @@ def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, grou
     flavour): a callable `fill(final [L, rows_per_link, *row_shape])` that writes operator 0 of every
     link (`[:, :, 0, :]` = [z | X[node]], which every rank can form from the replicated X and the
     link list) — the ranks then exchange operators 1..K only: 1 / (K+1) fewer bytes on the wire, and
-    at 8 ranks the step is bound by the wire.  `timers` (dict, optional) receives host-side
-    timestamps.
+    at 8 ranks the step is bound by the wire.  `mirror_rows` (fixed flavour, pair-aware `shards`,
+    rows_per_link = 2): the caller vouches that the rows of a link (d, s) are the rows of (s, d) in
+    swapped order, bit for bit (PoS and SoP: the engine itself serves a reversed duplicate that way) —
+    a link that follows its reverse in a rank's piece then does not travel: every rank rebuilds it from
+    the primary it received (PubMed's list: 23 % of the links).  `timers` (dict, optional) receives
+    host-side timestamps.
     `collective_at_world1`: run the pieces / in-place all-gather / compaction path even on a
     one-rank group (a test hook: it is how the collective code meets real RCCL on a one-GPU box).
     `reuse_buffers` (fixed flavour): the returned `rows` live in a process-wide buffer that the NEXT
@@ -201,7 +265,9 @@ def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, grou
     if rows_per_link is not None:
         rows, row_ptr, _ = _fixed(compute, li, b, rank, world_size, cost, group, gather, int(rows_per_link),
                                   max(int(chunks), 1), tuple(row_shape), dtype, device, timers,
-                                  collective_at_world1, bool(reuse_buffers), order_t, local_operator0)
+                                  collective_at_world1, bool(reuse_buffers), order_t, local_operator0,
+                                  shards if (mirror_rows and shards is not None and not shards.identity
+                                             and int(rows_per_link) == 2) else None)
         return rows, row_ptr, where
     rows, row_ptr = compute(li[:, lo:hi])
     if not gather or world_size == 1:
@@ -279,10 +345,11 @@ def _result(key, shape, dtype, device, reuse):
 
 
 def _fixed(compute, li, b, rank, world, cost, group, gather, rpl, chunks, row_shape, dtype, device,
-           timers, collective_at_world1=False, reuse=False, order=None, local_op0=None):
+           timers, collective_at_world1=False, reuse=False, order=None, local_op0=None, mirrors=None):
     """`li` is the list grouped by rank (rank r owns columns b[r]:b[r+1]); `order` (device-resident
     positions in the caller's list, or None = identity) says where every column belongs;
-    `local_op0`: see `sharded_precompute(local_operator0=…)`."""
+    `local_op0`: see `sharded_precompute(local_operator0=…)`; `mirrors`: the ShardPlan when reversed
+    duplicates are rebuilt from their primaries instead of exchanged (`mirror_rows=True`)."""
     L = int(li.shape[1])
     lo, hi = b[rank], b[rank + 1]
     row_ptr = torch.arange(0, rpl * L + 1, rpl, dtype=torch.int64, device=device)
@@ -293,11 +360,15 @@ def _fixed(compute, li, b, rank, world, cost, group, gather, rpl, chunks, row_sh
         compute(li[:, lo:hi], rows)
         return rows, row_ptr[lo:hi + 1] - rpl * lo, (lo, hi)
     # piece c of rank r = links [pb[r][c], pb[r][c+1]); every rank derives every rank's bounds
-    pb = [chunk_bounds(b[r], b[r + 1], chunks, cost) for r in range(world)]
+    if mirrors is not None:
+        pb, prim, mir, nprim = mirrors.transport(chunks, device)
+    else:
+        pb = [chunk_bounds(b[r], b[r + 1], chunks, cost) for r in range(world)]
+        nprim = [[pb[r][c + 1] - pb[r][c] for c in range(chunks)] for r in range(world)]
     final = _result(("final", rank), (rpl * L,) + row_shape, dtype, device, reuse)
     works = [None] * chunks
     slots = [None] * chunks
-    pmaxes = [rpl * max(pb[r][c + 1] - pb[r][c] for r in range(world)) for c in range(chunks)]
+    pmaxes = [rpl * max(nprim[r][c] for r in range(world)) for c in range(chunks)]
     cap = max(max(pmaxes), 1)
     # what travels: whole rows, or operators 1..K when every rank fills operator 0 itself
     xshape = row_shape if local_op0 is None else (row_shape[0] - 1,) + row_shape[1:]
@@ -313,6 +384,15 @@ def _fixed(compute, li, b, rank, world, cost, group, gather, rpl, chunks, row_sh
             n = rpl * (p1 - p0)
             if not n:
                 continue
+            if mirrors is not None:      # what travelled goes to its list position; the reversed duplicates
+                npr = nprim[r][c]        # are their primaries' rows in swapped order
+                got = slot[r, :rpl * npr].view((npr, rpl) + xshape)
+                pos = order[p0:p1]
+                final_links_x.index_copy_(0, pos[prim[r][c]], got)
+                mpos, mslot = mir[r][c]
+                if mpos.numel():
+                    final_links_x.index_copy_(0, pos[mpos], got.index_select(0, mslot).flip(1))
+                continue
             if order is None:
                 final_x[rpl * p0: rpl * p0 + n].copy_(slot[r, :n], non_blocking=True)
             else:      # scatter by list position: 2 rows x K(+1) x (1+F) floats per link
@@ -327,7 +407,15 @@ def _fixed(compute, li, b, rank, world, cost, group, gather, rpl, chunks, row_sh
         p0, p1 = pb[rank][c], pb[rank][c + 1]
         if p1 > p0:
             n = rpl * (p1 - p0)
-            if local_op0 is None:
+            if mirrors is not None:      # whole piece computed (the engine folds the duplicates), primaries packed
+                full = _Buffers.get(("fullm", rank), (rpl * max(pb[rank][k + 1] - pb[rank][k] for k in range(chunks)),) +
+                                    row_shape, dtype, device)
+                compute(li[:, p0:p1], full[:n])
+                sent = full[:n].view((p1 - p0, rpl) + row_shape).index_select(0, prim[rank][c])
+                npr = nprim[rank][c]
+                slot[rank, :rpl * npr].view((npr, rpl) + xshape).copy_(
+                    sent if local_op0 is None else sent[:, :, 1:], non_blocking=True)
+            elif local_op0 is None:
                 compute(li[:, p0:p1], slot[rank, :n])
             else:      # the engine writes whole rows: pack operators 1..K into the slot
                 full = _Buffers.get(("full", rank), (cap,) + row_shape, dtype, device)

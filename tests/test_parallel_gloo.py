@@ -134,6 +134,32 @@ def _worker_fixed(rank, world, port, chunks, q):
                                                    cost=parallel.link_cost(A, both), **kwargs)
         ok = ok and np.array_equal(rows_x.numpy(), full_both)
     calls.clear()
+    # reversed duplicates rebuilt from their primaries instead of exchanged (mirror_rows): a compute whose
+    # rows of (d, s) ARE the rows of (s, d) in swapped order, like the engine's; lists with (a,b),(b,a),(a,b)
+    # runs and duplicates of one direction; with and without the local operator 0
+    def rows_sym(p):
+        p = np.asarray(p)
+        sd = np.stack([p[0] * 1000.0 + p[1], p[1] * 1000.0 + p[0]], 1)
+        return (sd[:, :, None, None] + 0.5 * np.arange(3)[None, None, :, None] +
+                0.25 * np.arange(7)[None, None, None, :]).reshape(-1, 3, 7)
+
+    def compute_sym(piece, out):
+        out.copy_(torch.from_numpy(rows_sym(piece.numpy() if torch.is_tensor(piece) else piece)))
+
+    tri = np.concatenate([both, both[::-1, :20], both[:, :6], both[::-1, 3:9]], axis=1)
+    tri = np.ascontiguousarray(tri[:, np.random.default_rng(5).permutation(tri.shape[1])])
+    plan_t = parallel.ShardPlan(tri, world, None, pair_aware=True)
+    full_tri = rows_sym(tri)
+    sent = sum(sum(nr) for nr in plan_t.transport(chunks, "cpu")[3])
+    ok = ok and 0 < tri.shape[1] - sent <= int(plan_t.reverse_of_previous.sum())   # (a piece boundary may part a pair)
+
+    def fill0_t(fl):
+        fl[:, :, 0, :] = torch.from_numpy(full_tri).view(tri.shape[1], 2, 3, 7)[:, :, 0, :]
+
+    for f0 in (None, fill0_t):
+        rows_m, _, _ = parallel.sharded_precompute(compute_sym, tri, shards=plan_t, mirror_rows=True,
+                                                   local_operator0=f0, **kwargs)
+        ok = ok and np.array_equal(rows_m.numpy(), full_tri)
     # gather=False hands back the local shard only
     rows_l, ptr_l, _ = parallel.sharded_precompute(
         compute, links, rank=rank, world_size=world, cost=parallel.link_cost(A, links),
