@@ -235,6 +235,28 @@ def test_sharded_precompute_with_the_engine_world1_nccl(mode, chunks):
                 collective_at_world1=True)
             torch.cuda.synchronize()
             assert torch.equal(rows_c, whole) and ptr_c.tolist() == list(range(0, 2 * links.shape[1] + 1, 2))
+        # reversed duplicates rebuilt from their primaries instead of exchanged (mirror_rows), with the real
+        # engine: its rows of (d, s) are the rows of (s, d) swapped bit for bit — PoS and SoP alike
+        if mode in ("pos", "sop"):
+            both = np.concatenate([links, links[::-1, :15], links[:, :4]], axis=1)
+            both = np.ascontiguousarray(both[:, np.random.default_rng(3).permutation(both.shape[1])])
+            whole_b = torch.empty((2 * both.shape[1], K + 1, 7), dtype=torch.float32, device=eng.device)
+            compute(torch.from_numpy(both), whole_b)
+            sp = parallel.ShardPlan(torch.from_numpy(both), 1, None, pair_aware=True, device=eng.device)
+            assert sp.reverse_of_previous.sum() >= 15
+            x_dev, li_dev = xd.tensor, torch.from_numpy(both).to(eng.device)
+
+            def fill0(fl):
+                fl[:, :, 0, 0] = 1.0
+                fl[:, 0, 0, 1:] = x_dev[li_dev[0]]
+                fl[:, 1, 0, 1:] = x_dev[li_dev[1]]
+
+            for f0 in (None, fill0) if mode == "pos" else (None,):
+                rows_m, _, _ = parallel.sharded_precompute(
+                    compute, li_dev, rank=0, world_size=1, rows_per_link=2, chunks=chunks, row_shape=(K + 1, 7),
+                    device=eng.device, collective_at_world1=True, shards=sp, mirror_rows=True, local_operator0=f0)
+                torch.cuda.synchronize()
+                assert torch.equal(rows_m, whole_b)
         probe = whole[:8].clone()
         out = torch.empty_like(probe)
         dist.all_gather_into_tensor(out, probe)
