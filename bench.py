@@ -419,9 +419,9 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the counter passes (quick runs)")
     ap.add_argument("--max-links", type=int, default=0, help="truncate the link list (debug)")
     ap.add_argument("--chunks", type=int, default=0,
-                    help="N > 1: pieces per rank (all-gather of piece c overlaps the compute of c+1); 0 = 2 pieces "
-                         "up to 2 ranks, 4 beyond (the exchange, not the compute, bounds the step there: the sooner "
-                         "the first piece is on the wire the better, at ~0.1 ms of launches and one sync per piece)")
+                    help="N > 1: pieces per rank (all-gather of piece c overlaps the compute of c+1); 0 = pieces of about "
+                         "8 000 links, between 2 and 8 (the exchange, not the compute, bounds the step: the sooner the "
+                         "first piece is on the wire the better, at ~0.15 ms of launches and one sync per piece)")
     ap.add_argument("--contiguous-shards", action="store_true",
                     help="N > 1: contiguous ranges of the list instead of pair-aware shards (comparison)")
     ap.add_argument("--exchange-operator0", action="store_true",
@@ -436,8 +436,6 @@ def main():
                     help="N > 1: check the reassembled tensor bit for bit against an unsharded run")
     args = ap.parse_args()
     args.collect_pmc = args.collect_pmc or not args.no_pmc   # single-GPU runs only (checked where it is used)
-    if args.chunks <= 0:
-        args.chunks = 2 if int(os.environ.get("WORLD_SIZE", args.gpus)) <= 2 else 4
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
@@ -527,6 +525,8 @@ def main():
         # assignment keeps the two directions of a pair on one rank (parallel.shard_assignment)
         cost = parallel.measured_cost(eng, g, link_index, w.num_hops, mode=w.mode) if w.mode != "sop" \
             else parallel.sop_cost(eng, g, w.A, link_index)
+        if args.chunks <= 0:
+            args.chunks = min(8, max(2, int(round(L / world / 8000.0))))
         li_dev = torch.as_tensor(link_index).to(eng.device)
         shards = parallel.ShardPlan(li_dev, world, cost, pair_aware=not args.contiguous_shards, device=eng.device)
         gather = not args.no_allgather
