@@ -12,14 +12,21 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
 ATOL = 1e-10
+TERMS_ULPS = 0.2    # with TOL: 2e-6 of the sum of the absolute terms (~32 ulps of fp32)
 
 
-def rel_err(got, ref):
+def rel_err(got, ref, terms=None):
     ref = np.asarray(ref, dtype=np.float64)
     got = np.asarray(got, dtype=np.float64)
     if not ref.size:
         return 0.0
     scale = np.maximum(np.abs(ref), np.abs(ref).max(axis=-1, keepdims=True))
+    if terms is not None:
+        # signed features: an element (with F = 3 a whole row) can cancel to ~0 while its terms are O(1); fp32
+        # leaves round-off of the TERMS there, in the engine as in the reference's own fp32 arithmetic.
+        # `terms` = the same rows computed on |X| = the sum of the absolute terms; a few ulps of it are allowed
+        # (1 case in 400 of the directed sweep needs it: |Δ| = 3.8e-9 on an element of 6.1e-5).
+        scale = np.maximum(scale, TERMS_ULPS * np.abs(terms))
     return float(np.max(np.clip(np.abs(got - ref) - ATOL, 0, None) / np.maximum(scale, 1e-30)))
 
 
@@ -98,6 +105,8 @@ def test_random_configuration(eng, monkeypatch, case):
     np.testing.assert_array_equal(res.row_ptr.cpu().numpy(), ptr)
     np.testing.assert_array_equal(res.row_nodes.cpu().numpy(), nodes)
     err = rel_err(res.rows.cpu().numpy(), ref)
+    if err >= TOL:      # cancellation of signed features?  judge against the sum of the absolute terms
+        err = rel_err(res.rows.cpu().numpy(), ref, c_oracle.pos_rows(links.T, hops, A, np.abs(X), K, plus=plus)[0])
     assert err < TOL, (case, kind, n, hops, K, plus, F, density, err)
     f.close()
     G.close()
@@ -148,6 +157,10 @@ def test_random_directed_configuration(eng, monkeypatch, case):
                                          directed=True, A_csc=A_csc, **okw), K)
     np.testing.assert_array_equal(res.row_ptr.cpu().numpy(), ptr)
     err = rel_err(res.rows.cpu().numpy(), ref)
+    if err >= TOL:      # cancellation of signed features?  judge against the sum of the absolute terms
+        terms, _, _ = oracle.collate_rows(fn(links.T, hops, A, np.abs(X).astype(np.float64), 1, kw, dtype=np.float64,
+                                             directed=True, A_csc=A_csc, **okw), K)
+        err = rel_err(res.rows.cpu().numpy(), ref, terms)
     assert err < TOL, (case, kind, n, hops, K, plus, F, err)
     G.close()
 
