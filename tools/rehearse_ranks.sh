@@ -1,6 +1,7 @@
 # N ranks sharing ONE GPU over gloo, launched the way the driver launches a multi-GPU run
 # (python -m torch.distributed.run ... bench.py --gpus N), with --verify: the sharded result must be
 # bit-equal to the unsharded one.  GPU box:  gpurun -- 'bash tools/rehearse_ranks.sh r03s 2 pubmed_pos_k3'
+# At most 5 ranks on a gpurun box: the launcher counts towards its limit of 6 processes per GPU.
 set -o pipefail
 cd $GRAFT_REPO_ROOT; TAG=$1; N=${2:-2}; shift 2
 O=gpurun_out/$TAG; mkdir -p $O
