@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64 * kCount1Waves) void count1_kernel(
 // (BMG, the class of the biggest subgraphs: no matrix; cols and the list of found edges in a
 // per-workgroup HBM slice, four per-wave sort bitmaps of WB words behind off[])
 template <int T, int K, bool BMG>
-__global__ __launch_bounds__(T) void link_full_kernel(
+__global__ __launch_bounds__(T, (T <= 256 ? 8 : 1)) void link_full_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
     const int32_t* __restrict__ fwd_indptr, const int32_t* __restrict__ fwd_indices,
     const int64_t* __restrict__ links, const int32_t* __restrict__ class_list, int count, int plus,

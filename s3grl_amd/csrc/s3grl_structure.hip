@@ -850,8 +850,11 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
 // (utils.py:60-63); the operator is D^-1/2 A D^-1/2 of the directed induced matrix with D = OUT-degrees
 // (row counts, tuned_SIGN.py:158-161), so r_i = r_{i-1} A_hat pulls over a node's PREDECESSORS (dg.in_*)
 // and the degrees are counted over its successors (dg.out_*), for every node of S (p == n).
+#ifndef S3GRL_LINK_MINW
+#define S3GRL_LINK_MINW(T) 1
+#endif
 template <int T, int K, int G, bool GS, bool HS, bool DM = false, bool DIRECTED = false>
-__global__ __launch_bounds__(T) void link_kernel(
+__global__ __launch_bounds__(T, S3GRL_LINK_MINW(T)) void link_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int W,
     const int64_t* __restrict__ links, const int32_t* __restrict__ class_list, int hops, int plus,
     int cn_cap, int full_stats, int hubs, const WalkSets ws,
