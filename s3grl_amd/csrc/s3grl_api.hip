@@ -449,6 +449,7 @@ s3grl_status s3grl_graph_destroy(s3grl_graph* g) {
   g->ctx->arena.release(g->in_indptr);
   g->ctx->arena.release(g->in_indices);
   release_hub_cache(g);
+  release_ball_cache(g);
   delete g;
   return S3GRL_OK;
 }
@@ -713,10 +714,22 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
                             n_rows, n_jobs, lvl_max, e_cap, reinterpret_cast<int32_t*>(ds), st + 3 * kStatRow,
                             st + 4 * kStatRow, perm, x_cap));
   } else {
-    S3GRL_TRY(launch_count(ctx, &g_walk, links_walk, L, cfg->num_hops, plus ? 1 : 0, K, ws,
-                           partner, mirror_of,
-                           plan->n_nodes, p_nodes, n_rows, n_jobs, lvl_max,
-                           reinterpret_cast<int32_t*>(ds), st + 3 * kStatRow, smp, stash, slot, plan->lvl, perm));
+    // plain plans on graphs whose node balls fit: the sizing pass is bitmap arithmetic on the cached balls
+    // of the two endpoints (s3grl_balls.hip) instead of a BFS per link
+    bool balls = false;
+    if (relabel && !walks && !sampling)
+      S3GRL_TRY(ensure_ball_cache(ctx, const_cast<s3grl_graph*>(g), cfg->num_hops, &balls));
+    if (balls) {
+      g_walk.balls = g->balls;
+      S3GRL_TRY(launch_count_balls(ctx, &g_walk, links_walk, L, cfg->num_hops, plus ? 1 : 0, K, partner, mirror_of,
+                                   plan->n_nodes, p_nodes, n_rows, n_jobs, lvl_max, reinterpret_cast<int32_t*>(ds),
+                                   st + 3 * kStatRow, stash, slot, plan->lvl, perm));
+    } else {
+      S3GRL_TRY(launch_count(ctx, &g_walk, links_walk, L, cfg->num_hops, plus ? 1 : 0, K, ws,
+                             partner, mirror_of,
+                             plan->n_nodes, p_nodes, n_rows, n_jobs, lvl_max,
+                             reinterpret_cast<int32_t*>(ds), st + 3 * kStatRow, smp, stash, slot, plan->lvl, perm));
+    }
   }
   if (fold) S3GRL_TRY(launch_mirror_rows(ctx, partner, L, n_rows));
   // offsets of nodes / rows / row pairs, their maxima (ds[1], ds[5]) and totals (ds[9..11]) in one go

@@ -173,9 +173,19 @@ constexpr int kHubClasses = 4;           // LDS classes of link_hub_kernel: 128 
                                          // (index kHubClasses) keeps its list of found edges in HBM slices
 constexpr int64_t kHubVolMax = 65536;    // Σ degree over the other endpoint's neighbourhood: beyond, the old path
 
+// BFS balls of every node of the degree-ordered graph as N-bit bitmaps (s3grl_balls.hip): level d - 1 of
+// `bits` holds ball_d(x) = the nodes within d hops of x, x included, for all x — built on first use, level by
+// level, for the plans whose sizing pass is bitmap arithmetic on them
+struct BallCache {
+  int hops = 0;                 // levels built
+  int64_t level_stride = 0;     // words per level = N * ceil(N / 32)
+  uint32_t* bits = nullptr;     // [hops][N][ceil(N / 32)]
+};
+
 struct s3grl_graph {
   s3grl_context* ctx = nullptr;
   HubCache hub;                // of the degree-ordered graph (r_indptr / r_indices)
+  BallCache balls;             // of the degree-ordered graph
   int64_t num_nodes = 0;
   int64_t nnz = 0;
   int32_t max_degree = 0;      // decides whether the hub-row path of the row walker is armed
@@ -316,6 +326,14 @@ s3grl_status launch_translate_links(s3grl_context* ctx, const s3grl_graph* g, co
 // plan on a big graph works on its links (locality; outputs stay in the caller's order)
 s3grl_status launch_link_order(s3grl_context* ctx, const int64_t* links, int64_t L, int64_t N,
                                const int32_t* indptr, int32_t* perm);
+// balls.hip
+s3grl_status ensure_ball_cache(s3grl_context* ctx, s3grl_graph* g, int hops, bool* usable);
+void release_ball_cache(s3grl_graph* g);
+s3grl_status launch_count_balls(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L, int hops,
+                                int plus, int K, const int32_t* partner, const int32_t* mirror_of, int32_t* n_nodes,
+                                int32_t* p_nodes, int32_t* n_rows, int32_t* n_jobs, int32_t* lvl_max,
+                                int32_t* err_flag, int64_t* tot_nodes_alg, int32_t* stash, int slot,
+                                int32_t* lvl_stash, const int32_t* perm);
 // hub.hip
 s3grl_status build_hub_cache(s3grl_context* ctx, s3grl_graph* g);
 void release_hub_cache(s3grl_graph* g);

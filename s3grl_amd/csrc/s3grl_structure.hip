@@ -21,44 +21,6 @@
 namespace s3grl {
 namespace {
 
-// PoS Plus row selection, reference tuned_SIGN.py:233 evaluated on the MASKED sub-CSR whose
-// `.indices` still hold the explicit zeros of the masking:
-//   N'(0) = (N_G(src) ∩ S) \ {dst} ∪ {dst-as-explicit-zero};  N'(1) likewise;  CN = N'(0) ∩ N'(1).
-// For x ∉ {src,dst}: x ∈ N(src) ∩ N(dst) ∩ S.  src itself is selected iff src has a self-loop,
-// dst iff dst has one.  One wave walks row(src) (ascending) and emits global ids in ascending
-// order into out[] (may be null: count only).  Returns |CN|.
-template <typename Member>
-__device__ __forceinline__ int common_neighbours(const int32_t* __restrict__ indptr,
-                                                 const int32_t* __restrict__ indices,
-                                                 Member in_s, int src, int dst, int32_t* out) {
-  const int lane = lane_id();
-  const int32_t* row_s = indices + indptr[src];
-  const int32_t* row_d = indices + indptr[dst];
-  const int cs = indptr[src + 1] - indptr[src], cd = indptr[dst + 1] - indptr[dst];
-  const bool loop_d = sorted_contains(row_d, cd, dst);
-  int total = 0, lt_dst = 0;
-  for (int c0 = 0; c0 < cs; c0 += 64) {
-    const int c = c0 + lane;
-    int x = -1;
-    bool sel = false;
-    if (c < cs) {
-      x = row_s[c];
-      sel = x != dst && in_s(x) && (x == src || sorted_contains(row_d, cd, x));
-    }
-    const unsigned long long bal = __ballot(sel);
-    const unsigned long long below = __ballot(sel && x < dst);
-    if (sel && out)
-      out[total + __popcll(bal & ((1ull << lane) - 1ull)) + ((loop_d && dst < x) ? 1 : 0)] = x;
-    total += __popcll(bal);
-    lt_dst += __popcll(below);
-  }
-  if (loop_d) {
-    if (lane == 0 && out) out[lt_dst] = dst;
-    total += 1;
-  }
-  return total;
-}
-
 // ---------------------------------------------------------------------------------------
 // count: level-synchronous BFS on LDS bitmaps, one thread per frontier word (reference
 // utils.py:53-74: `fringe = neighbors(fringe, A) - visited`, early break on an empty fringe).

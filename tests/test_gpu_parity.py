@@ -1264,6 +1264,49 @@ def test_many_hub_rows_are_summed_the_same_way_in_every_plan(eng):
     f.close(), G.close()
 
 
+@pytest.mark.parametrize("name", ["usair", "cora", "rand300", "star_iso"])
+def test_sizing_pass_from_cached_balls_equals_the_bfs(eng, monkeypatch, name):
+    """Plain multi-hop plans size their links by bitmap arithmetic on the cached BFS balls of the two
+    endpoints (csrc/s3grl_balls.hip) instead of a BFS per link (count_kernel): every output of the plan — node
+    lists, distances, row pointers and nodes, statistics, rows — is bit for bit the BFS plan's; the cache
+    grows level by level (2 hops, then 3 on the same graph), and a graph whose balls pass the memory cap
+    keeps the BFS."""
+    import torch
+
+    g = load_extract(name)
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = np.random.default_rng(11).standard_normal((n, 9))
+    links = np.concatenate([g["links"], g["links"][:5, ::-1]])
+    f = eng.features(X)
+    L = eng.links(links.T)
+    outs = {}
+    for flavour in ("balls", "bfs", "capped"):
+        for k in ("S3GRL_NO_BALL_CACHE", "S3GRL_BALL_CACHE_BYTES"):
+            monkeypatch.delenv(k, raising=False)
+        if flavour == "bfs":
+            monkeypatch.setenv("S3GRL_NO_BALL_CACHE", "1")
+        if flavour == "capped":
+            monkeypatch.setenv("S3GRL_BALL_CACHE_BYTES", "64")
+        G = eng.graph(A)
+        res = []
+        for hops, mode, K in ((2, "pos", 3), (3, "pos_plus", 2), (1, "pos", 2), (3, "pos", 5)):
+            p = eng.plan(G, L, mode=mode, num_hops=hops, sign_k=K, full_stats=(hops == 2))
+            st = dict(p.stats)
+            st.pop("workspace_bytes")
+            res.append(([t.clone() for t in p.export_subgraphs()], p.row_ptr().clone(), p.row_nodes().clone(), st,
+                        p.run(f).clone()))
+            p.close()
+        outs[flavour] = res
+        G.close()
+    for other in ("bfs", "capped"):
+        for (ea, pa, na, sa, ra), (eb, pb, nb, sb, rb) in zip(outs["balls"], outs[other]):
+            assert all(torch.equal(x, y) for x, y in zip(ea, eb))
+            assert torch.equal(pa, pb) and torch.equal(na, nb) and sa == sb
+            assert torch.equal(ra, rb)
+    f.close()
+
+
 @pytest.mark.parametrize("mode", ["pos", "pos_plus"])
 def test_half_million_nodes_two_hops_vs_c(eng, mode):
     """A 500 000-node power-law graph, two hops: beyond the LDS bitmap limit.  The sizing pass keeps
