@@ -210,6 +210,65 @@ def link_kernel_roofline(args, w, link_index, stats, phase_ms, K, F, collect):
     }
 
 
+def choose_replicate_fraction(dist, backend, eng, parallel, compute, shards, li_dev, cost, rank, world, K, F,
+                              exchange_op0, chunks):
+    """How much of the list should every rank compute itself instead of receiving it?  One compute-only
+    step of the sharded list and one all-gather of the full payload are timed (set-up, RCCL only); with the
+    cost model's share of the cheapest g of the list, a step takes about
+        max( own compute without them + their compute in full ,  first piece + (1 - g) * all-gather )
+    and g is taken from a grid.  Rank 0 decides for everybody."""
+    import torch
+
+    if backend != "nccl" and not os.environ.get("S3GRL_BENCH_TUNE_ANY_BACKEND"):   # (rehearsal hook: exercise this code over gloo)
+        return 0.0, {"note": "not RCCL: the exchange cannot be timed, nothing replicated"}
+    small = eng.device if backend == "nccl" else "cpu"      # where the few-number collectives live
+    L = li_dev.shape[1]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for rep_ in range(2):      # (the second run: buffers and caches warm)
+        dist.barrier()
+        ev[0].record()
+        parallel.sharded_precompute(compute, li_dev, rank=rank, world_size=world, gather=False, rows_per_link=2,
+                                    row_shape=(K + 1, F + 1), device=eng.device, reuse_buffers=True, shards=shards)
+        ev[1].record()
+        torch.cuda.synchronize()
+    t_comp = torch.tensor([ev[0].elapsed_time(ev[1])], device=small)
+    t_all = t_comp.clone()
+    dist.all_reduce(t_all, op=dist.ReduceOp.SUM)
+    dist.all_reduce(t_comp, op=dist.ReduceOp.MAX)
+    sent = [sum(nr) for nr in shards.transport(chunks, eng.device)[3]]
+    rmax = 2 * max(sent)
+    kx = K + 1 if exchange_op0 else K
+    buf = torch.empty((world * rmax, kx, F + 1), dtype=torch.float32, device=eng.device)
+    best = None
+    for _ in range(2):
+        dist.barrier()
+        ev[2].record()
+        parallel._all_gather(buf, buf[rank * rmax:(rank + 1) * rmax], None)
+        ev[3].record()
+        torch.cuda.synchronize()
+        t = ev[2].elapsed_time(ev[3])
+        best = t if best is None else min(best, t)
+    del buf
+    t_ag = torch.tensor([best], device=small)
+    dist.all_reduce(t_ag, op=dist.ReduceOp.MAX)
+    t_comp, t_all, t_ag = float(t_comp), float(t_all), float(t_ag)
+    c = np.sort(np.asarray(cost, dtype=np.float64))
+    share = np.concatenate([[0.0], np.cumsum(c) / max(c.sum(), 1e-30)])   # cost share of the cheapest k links
+    grid = [0.0, 0.05, 0.1, 0.15, 0.2, 0.25, 0.3, 0.35, 0.4, 0.45, 0.5, 0.55, 0.6]
+    est = {}
+    for gfr in grid:
+        cf = float(share[int(L * gfr)])
+        comp = t_comp * (1.0 - cf) + cf * t_all          # own share without them + all of them
+        wire = t_comp * (1.0 - cf) / max(chunks, 1) + (1.0 - gfr) * t_ag
+        est[gfr] = max(comp, wire) + 0.15 * (gfr > 0)     # (one more plan per step)
+    pick = min(grid, key=lambda gfr: est[gfr])
+    choice = torch.tensor([pick], device=small)
+    dist.broadcast(choice, src=0)
+    pick = round(float(choice), 4)
+    return pick, {"compute_only_ms_max": t_comp, "compute_only_ms_sum": t_all, "allgather_alone_ms": t_ag,
+                  "estimated_step_ms": {str(k): round(v, 3) for k, v in est.items()}}
+
+
 def cpu_baseline(w, link_index, y, budget_s, max_links):
     """The oracle (reference-structured CPU restatement, oracle/s3grl_oracle.py) timed on one
     core over a bounded sample of the same link list.  kind = "port"."""
@@ -427,6 +486,10 @@ def main():
     ap.add_argument("--exchange-operator0", action="store_true",
                     help="N > 1: all-gather whole rows (operator 0 = X[node] included) instead of letting every rank "
                          "fill operator 0 from its own copy of X (comparison)")
+    ap.add_argument("--replicate-fraction", type=float, default=-1.0,
+                    help="N > 1: share of the list (its cheapest links) that every rank computes itself instead of "
+                         "receiving it; -1 = chosen at set-up from one measured compute-only step and one measured "
+                         "all-gather (RCCL only), 0 = off")
     ap.add_argument("--exchange-mirrors", action="store_true",
                     help="N > 1: all-gather the rows of reversed duplicates too instead of rebuilding them on every "
                          "rank from their primaries' rows (comparison)")
@@ -544,6 +607,21 @@ def main():
                 fl[:, 0, 0, 1:] = x_dev[li_dev[0]]
                 fl[:, 1, 0, 1:] = x_dev[li_dev[1]]
 
+            # --- links every rank computes itself (the exchange, not the compute, bounds the step) ------------
+            replicate_info = None
+            frac = args.replicate_fraction
+            if gather and not args.contiguous_shards and frac != 0.0:
+                if frac < 0.0:
+                    frac, replicate_info = choose_replicate_fraction(
+                        dist, backend, eng, parallel, compute, shards, li_dev, cost, rank, world, K, F,
+                        args.exchange_operator0, args.chunks)
+                if frac > 0.0:
+                    rep = parallel.replicate_cheapest(link_index, cost, frac)
+                    shards = parallel.ShardPlan(li_dev, world, cost, pair_aware=True, device=eng.device, replicate=rep)
+                    replicate_info = dict(replicate_info or {}, fraction=frac, links=int(rep.sum()),
+                                          cost_share=float(np.asarray(cost)[rep].sum() / max(np.asarray(cost).sum(), 1e-30)))
+            shard_info["replicated"] = replicate_info
+
             def step_sharded():
                 return parallel.sharded_precompute(
                     compute, li_dev, rank=rank, world_size=world, gather=gather,
@@ -562,7 +640,7 @@ def main():
                 return parallel.sharded_precompute(compute_ragged, li_dev, rank=rank, world_size=world,
                                                    gather=gather, shards=shards)
         b = shards.bounds
-        shard_info = {"bounds": b, "links_per_rank": [b[r + 1] - b[r] for r in range(world)]}
+        shard_info.update({"bounds": b, "links_per_rank": [b[r + 1] - b[r] for r in range(world)]})
         if fixed_rows and gather and not args.exchange_mirrors and not args.contiguous_shards:
             sent = [sum(nr) for nr in shards.transport(args.chunks, eng.device)[3]]
             shard_info["links_sent_per_rank"] = sent
@@ -691,6 +769,7 @@ def main():
                                if fixed_rows else "sizes + one padded all_gather_into_tensor + compaction"),
                 "backend": backend, "links_per_rank": shard_info["links_per_rank"],
                 "links_sent_per_rank": shard_info.get("links_sent_per_rank"),
+                "replicated_links": shard_info.get("replicated"),
                 "per_rank": per_rank,
                 "compute_ms_per_rank": comp,
                 "imbalance_max_over_mean": max(comp) / (sum(comp) / len(comp)) if sum(comp) > 0 else None,

@@ -87,10 +87,29 @@ class ShardPlan:
     """An assignment made once (set-up, like the uploads) and reused by every step: the list grouped
     by rank on the device, where every column belongs in the caller's list, and the bounds."""
 
-    def __init__(self, link_index, world_size, cost=None, pair_aware=True, device=None):
+    def __init__(self, link_index, world_size, cost=None, pair_aware=True, device=None, replicate=None):
+        """`replicate` (bool mask over the list, pair-aware plans only): links that EVERY rank computes itself
+        instead of receiving them — the exchange, not the compute, bounds a sharded step (1.5 GB over xGMI
+        against 12 ms of engine for the whole headline list), and the cheapest links of a list cost a few
+        per cent of its compute but their full share of its bytes (`replicate_cheapest`).  They sit behind
+        the ranks' own links in `links` / `order`; `bounds` covers the sharded part only."""
         li = torch.as_tensor(link_index)
         self.num_links = int(li.shape[1])
-        order, self.bounds = shard_assignment(li, world_size, cost, pair_aware)
+        rep = None if replicate is None else np.asarray(replicate, dtype=bool)
+        if rep is not None and (not pair_aware or not rep.any()):
+            rep = None
+        if rep is None:
+            order, self.bounds = shard_assignment(li, world_size, cost, pair_aware)
+            self.rep_start = self.num_links
+        else:
+            assert rep.shape == (self.num_links,)
+            li_np = np.asarray(li.cpu())
+            keep, dup = np.flatnonzero(~rep), np.flatnonzero(rep)
+            c = None if cost is None else np.asarray(cost, dtype=np.float64)
+            o_s, self.bounds = shard_assignment(li_np[:, keep], world_size, None if c is None else c[keep], True)
+            o_r, _ = shard_assignment(li_np[:, dup], 1, None, True)      # partners next to each other
+            order = np.concatenate([keep[o_s], dup[o_r]]).astype(np.int64)
+            self.rep_start = len(keep)
         self.identity = not pair_aware
         self.order = torch.from_numpy(order)
         self.cost = None if cost is None else np.asarray(cost, dtype=np.float64)[order]
@@ -104,7 +123,7 @@ class ShardPlan:
         rev = np.zeros(self.num_links, dtype=bool)
         if pair_aware and self.num_links > 1:
             rev[1:] = (sl[0, 1:] == sl[1, :-1]) & (sl[1, 1:] == sl[0, :-1]) & (sl[0, 1:] != sl[1, 1:])
-            for r in range(world_size):                     # never across a rank boundary
+            for r in range(world_size + 1):                 # never across a rank boundary (or into the replicated part)
                 if 0 < self.bounds[r] < self.num_links:
                     rev[self.bounds[r]] = False
             # (a, b), (b, a), (a, b): the third is the reverse of a mirror, not of a primary — it travels
@@ -148,6 +167,25 @@ class ShardPlan:
         t = (pb, prim, mir, nprim)
         self._transport[key] = t
         return t
+
+
+def replicate_cheapest(link_index, cost, fraction):
+    """Mask of the links every rank should compute itself: the cheapest pairs (both directions of a pair
+    together, priced by their summed cost per link) up to `fraction` of the list."""
+    li = np.asarray(torch.as_tensor(link_index).cpu())
+    L = int(li.shape[1])
+    mask = np.zeros(L, dtype=bool)
+    want = int(L * float(fraction))
+    if want <= 0 or L == 0:
+        return mask
+    lo, hi = np.minimum(li[0], li[1]).astype(np.int64), np.maximum(li[0], li[1]).astype(np.int64)
+    _, inv, cnt = np.unique(lo * (int(hi.max()) + 1) + hi, return_inverse=True, return_counts=True)
+    per_link = np.bincount(inv, weights=np.asarray(cost, dtype=np.float64), minlength=len(cnt)) / cnt
+    groups = np.argsort(per_link, kind="stable")
+    take = groups[:int(np.searchsorted(np.cumsum(cnt[groups]), want, side="right"))]
+    pick = np.zeros(len(cnt), dtype=bool)
+    pick[take] = True
+    return pick[inv]
 
 
 def link_cost(A, link_index):
@@ -253,6 +291,8 @@ def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, grou
         shards = ShardPlan(li, world_size, cost, True)
     if shards is not None and not shards.identity:
         assert shards.num_links == L and len(shards.bounds) == world_size + 1
+        assert shards.rep_start == L or (gather and rows_per_link is not None), \
+            "replicated links belong to the gathered fixed-rows flavour"
         order, order_t, b = shards.order, shards.order_dev, shards.bounds
         li, cost = shards.links, shards.cost      # the list, grouped by rank; positions map back through `order`
     elif shards is not None:
@@ -262,12 +302,15 @@ def sharded_precompute(compute, link_index, *, rank, world_size, cost=None, grou
         b = shard_bounds(L, world_size, cost)
     lo, hi = b[rank], b[rank + 1]
     where = (lo, hi) if order is None else order_t[lo:hi]
+    if order is not None and shards.rep_start < L:      # + the links every rank computes itself
+        where = torch.cat([where, order_t[shards.rep_start:]])
     if rows_per_link is not None:
         rows, row_ptr, _ = _fixed(compute, li, b, rank, world_size, cost, group, gather, int(rows_per_link),
                                   max(int(chunks), 1), tuple(row_shape), dtype, device, timers,
                                   collective_at_world1, bool(reuse_buffers), order_t, local_operator0,
                                   shards if (mirror_rows and shards is not None and not shards.identity
-                                             and int(rows_per_link) == 2) else None)
+                                             and int(rows_per_link) == 2) else None,
+                                  L if shards is None else shards.rep_start)
         return rows, row_ptr, where
     rows, row_ptr = compute(li[:, lo:hi])
     if not gather or world_size == 1:
@@ -345,11 +388,14 @@ def _result(key, shape, dtype, device, reuse):
 
 
 def _fixed(compute, li, b, rank, world, cost, group, gather, rpl, chunks, row_shape, dtype, device,
-           timers, collective_at_world1=False, reuse=False, order=None, local_op0=None, mirrors=None):
+           timers, collective_at_world1=False, reuse=False, order=None, local_op0=None, mirrors=None,
+           rep_start=None):
     """`li` is the list grouped by rank (rank r owns columns b[r]:b[r+1]); `order` (device-resident
     positions in the caller's list, or None = identity) says where every column belongs;
     `local_op0`: see `sharded_precompute(local_operator0=…)`; `mirrors`: the ShardPlan when reversed
-    duplicates are rebuilt from their primaries instead of exchanged (`mirror_rows=True`)."""
+    duplicates are rebuilt from their primaries instead of exchanged (`mirror_rows=True`); `rep_start`:
+    the columns from there on are computed by every rank itself (ShardPlan(replicate=…)) while the pieces
+    of the others are on the wire."""
     L = int(li.shape[1])
     lo, hi = b[rank], b[rank + 1]
     row_ptr = torch.arange(0, rpl * L + 1, rpl, dtype=torch.int64, device=device)
@@ -398,6 +444,20 @@ def _fixed(compute, li, b, rank, world, cost, group, gather, rpl, chunks, row_sh
             else:      # scatter by list position: 2 rows x K(+1) x (1+F) floats per link
                 final_links_x.index_copy_(0, order[p0:p1], slot[r, :n].view((p1 - p0, rpl) + xshape))
 
+    rep_start = L if rep_start is None else int(rep_start)
+
+    def replicated():
+        """the links nobody sends: computed here, into their list positions (pieces of at most the size of
+        the exchange's slots, through the same staging buffer)"""
+        if rep_start >= L:
+            return
+        step = max(cap // rpl, 1)
+        buf = _Buffers.get(("rep", rank), (rpl * step,) + row_shape, dtype, device)
+        for a in range(rep_start, L, step):
+            z = min(a + step, L)
+            compute(li[:, a:z], buf[:rpl * (z - a)])
+            final_links.index_copy_(0, order[a:z], buf[:rpl * (z - a)].view((z - a, rpl) + row_shape))
+
     t_comm = 0.0
     for c in range(chunks):
         pmax = max(pmaxes[c], 1)
@@ -425,6 +485,8 @@ def _fixed(compute, li, b, rank, world, cost, group, gather, rpl, chunks, row_sh
         # in place: this rank's contribution already sits in its slice of the output
         works[c] = _all_gather(slot.view((world * slot.shape[1],) + xshape), slot[rank], group,
                                async_op=True)
+        if c == chunks - 1:
+            replicated()                    # while the pieces travel
         if c == 0 and local_op0 is not None:
             local_op0(final_links)          # while the first pieces travel
         if c >= 1:

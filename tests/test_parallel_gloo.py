@@ -160,6 +160,20 @@ def _worker_fixed(rank, world, port, chunks, q):
         rows_m, _, _ = parallel.sharded_precompute(compute_sym, tri, shards=plan_t, mirror_rows=True,
                                                    local_operator0=f0, **kwargs)
         ok = ok and np.array_equal(rows_m.numpy(), full_tri)
+    # the cheapest links computed by every rank itself instead of exchanged (ShardPlan(replicate=…)): the same
+    # tensor, fewer links on the wire; `where` = what this rank computed (its own share + the replicated links)
+    cost_t = parallel.link_cost(A, tri).astype(np.float64)
+    rep = parallel.replicate_cheapest(tri, cost_t, 0.3)
+    plan_r = parallel.ShardPlan(tri, world, cost_t, pair_aware=True, replicate=rep)
+    ok = ok and 0 < rep.sum() <= 0.3 * tri.shape[1] and plan_r.rep_start == tri.shape[1] - rep.sum()
+    both_dirs = set(map(tuple, tri.T.tolist()))
+    ok = ok and all(rep[i] == rep[j] for i, (a_, b_) in enumerate(tri.T.tolist()) if (b_, a_) in both_dirs
+                    for j in [next(k for k, ab in enumerate(tri.T.tolist()) if ab == [b_, a_])])
+    for f0, mr in ((None, False), (fill0_t, True)):
+        rows_r, _, where_r = parallel.sharded_precompute(compute_sym, tri, shards=plan_r, mirror_rows=mr,
+                                                         local_operator0=f0, **kwargs)
+        ok = ok and np.array_equal(rows_r.numpy(), full_tri)
+        ok = ok and set(np.flatnonzero(rep).tolist()) <= set(where_r.tolist())
     # gather=False hands back the local shard only
     rows_l, ptr_l, _ = parallel.sharded_precompute(
         compute, links, rank=rank, world_size=world, cost=parallel.link_cost(A, links),

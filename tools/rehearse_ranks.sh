@@ -2,6 +2,7 @@
 # (python -m torch.distributed.run ... bench.py --gpus N), with --verify: the sharded result must be
 # bit-equal to the unsharded one.  GPU box:  gpurun -- 'bash tools/rehearse_ranks.sh r03s 2 pubmed_pos_k3'
 # At most 5 ranks on a gpurun box: the launcher counts towards its limit of 6 processes per GPU.
+# BENCH_ARGS="--replicate-fraction 0.3" adds arguments to the bench line.
 set -o pipefail
 cd $GRAFT_REPO_ROOT; TAG=$1; N=${2:-2}; shift 2
 O=gpurun_out/$TAG; mkdir -p $O
@@ -9,7 +10,7 @@ python3 -c 'import __graft_entry__ as g; g.build()' > $O/build.log 2>&1 || { ech
 for wl in "$@"; do
   port=$((29500 + RANDOM % 500))
   S3GRL_BENCH_BACKEND=gloo timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N \
-      --master-addr 127.0.0.1 --master-port $port bench.py --gpus $N --steps 3 --warmup 1 --verify --workload $wl \
+      --master-addr 127.0.0.1 --master-port $port bench.py --gpus $N --steps 3 --warmup 1 --verify --workload $wl $BENCH_ARGS \
       > $O/ranks${N}_$wl.json 2> $O/ranks${N}_$wl.err
   rc=$?
   python3 - <<PY
