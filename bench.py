@@ -612,9 +612,12 @@ def main():
             frac = args.replicate_fraction
             if gather and not args.contiguous_shards and frac != 0.0:
                 if frac < 0.0:
-                    frac, replicate_info = choose_replicate_fraction(
-                        dist, backend, eng, parallel, compute, shards, li_dev, cost, rank, world, K, F,
-                        args.exchange_operator0, args.chunks)
+                    try:
+                        frac, replicate_info = choose_replicate_fraction(
+                            dist, backend, eng, parallel, compute, shards, li_dev, cost, rank, world, K, F,
+                            args.exchange_operator0, args.chunks)
+                    except Exception as e:      # (a measurement aid must not take the run down: nothing replicated)
+                        frac, replicate_info = 0.0, {"error": repr(e)}
                 if frac > 0.0:
                     rep = parallel.replicate_cheapest(link_index, cost, frac)
                     shards = parallel.ShardPlan(li_dev, world, cost, pair_aware=True, device=eng.device, replicate=rep)
