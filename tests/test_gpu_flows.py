@@ -257,6 +257,16 @@ def test_sharded_precompute_with_the_engine_world1_nccl(mode, chunks):
                     device=eng.device, collective_at_world1=True, shards=sp, mirror_rows=True, local_operator0=f0)
                 torch.cuda.synchronize()
                 assert torch.equal(rows_m, whole_b)
+            # ... and the cheapest links computed by every rank itself instead of exchanged (replicate)
+            cost_b = parallel.link_cost(A, both).astype(np.float64)
+            rep = parallel.replicate_cheapest(both, cost_b, 0.4)
+            sp_r = parallel.ShardPlan(torch.from_numpy(both), 1, cost_b, pair_aware=True, device=eng.device, replicate=rep)
+            assert 0 < sp_r.rep_start < both.shape[1]
+            rows_r, _, where_r = parallel.sharded_precompute(
+                compute, li_dev, rank=0, world_size=1, rows_per_link=2, chunks=chunks, row_shape=(K + 1, 7),
+                device=eng.device, collective_at_world1=True, shards=sp_r, mirror_rows=True)
+            torch.cuda.synchronize()
+            assert torch.equal(rows_r, whole_b) and where_r.numel() == both.shape[1]
         probe = whole[:8].clone()
         out = torch.empty_like(probe)
         dist.all_gather_into_tensor(out, probe)
