@@ -770,16 +770,18 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
   }
   if (n == 0) c = -1;
   // one atomic per (wave, class) instead of one per link
+  // (only the classes present in the wavefront are visited: two or three of kNumLists)
   const int lane = threadIdx.x & 63;
-  for (int k = 0; k < kNumLists; ++k) {
-    if (k == kNumClasses + 1) continue;
+  unsigned long long todo = __ballot(c >= 0);
+  while (todo) {
+    const int k = __shfl(c, __ffsll((long long)todo) - 1);
     const unsigned long long m = __ballot(c == k);
-    if (m == 0) continue;
     const int leader = __ffsll((long long)m) - 1;
     int base = 0;
     if (lane == leader) base = atomicAdd(&class_count[k], __popcll(m));
     base = __shfl(base, leader);
     if (c == k) class_list[(int64_t)k * L + base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)l;
+    todo &= ~m;
   }
   // class kNumClasses = links that do not fit LDS: they run with their lists in HBM scratch
   if (c == kNumClasses) atomicMax(&class_count[kNumClasses + 1], need);
