@@ -168,7 +168,7 @@ struct HubCache {
   int32_t* hoff = nullptr;       // row offsets, relative to col_base[k]
   uint16_t* hcols = nullptr;     // positions in the hub's row, ascending inside a row
 };
-constexpr int kHubMinDegree = 256;
+constexpr int kHubMinDegree = 128;
 constexpr int kHubClasses = 4;           // LDS classes of link_hub_kernel: 128 / 256 / 512 / 1024 threads; one more
                                          // (index kHubClasses) keeps its list of found edges in HBM slices
 constexpr int64_t kHubVolMax = 65536;    // Σ degree over the other endpoint's neighbourhood: beyond, the old path
