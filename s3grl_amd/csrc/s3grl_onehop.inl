@@ -352,12 +352,21 @@ __global__ __launch_bounds__(T, (T <= 256 ? 8 : 1)) void link_full_kernel(
     }
     __syncthreads();
     int vol_local = 0;
+    // (on-chip classes: the bounds of the oriented rows are fetched here, with the other per-node loads —
+    // the probes below then start from LDS.  They sit in dinv's / off's space, unused until the CSR is built.)
+    int32_t* qstart = reinterpret_cast<int32_t*>(dinv);   // [n] first entry of node t's oriented row
+    int32_t* qoff = off;                                    // [n + 1] running offsets of those rows
     for (int t = tid; t < n; t += T) {
       const int v = list[t];
       hs_insert(hkeys, hmask, v);
       hvals[hs_find(hkeys, hmask, v)] = t;
       c_ids[noff + t] = ext(v);
       vol_local += indptr[v + 1] - indptr[v];
+      if constexpr (!BMG) {
+        const int fb = fwd_indptr[v];
+        qstart[t] = fb;
+        qoff[t] = fwd_indptr[v + 1] - fb;
+      }
     }
     const int64_t rp = row_ptr[l];
     const int R = (int)(row_ptr[l + 1] - rp);
@@ -396,6 +405,43 @@ __global__ __launch_bounds__(T, (T <= 256 ? 8 : 1)) void link_full_kernel(
     S3GRL_FSTAMP(1)
 
     // ---- masked induced adjacency through the oriented rows (reference utils.py:76-80) ----------
+    if constexpr (!BMG) {
+      // The oriented rows are walked FLAT: entry e of their concatenation by thread e mod T — a subgraph of
+      // 25 nodes has ~40 oriented entries, and a walk with four lanes per row paid two dependent global
+      // round trips (bounds, then entries) for rows of one or two entries; here the bounds are in LDS.
+      {
+        const int per = (n + T - 1) / T;
+        const int t0 = min(tid * per, n), t1 = min(t0 + per, n);
+        int mine = 0;
+        for (int t = t0; t < t1; ++t) mine += qoff[t];
+        int total;
+        int run = block_excl_scan<T>(mine, sh, total);
+        for (int t = t0; t < t1; ++t) {
+          const int len = qoff[t];
+          qoff[t] = run;
+          run += len;
+        }
+        if (tid == 0) qoff[n] = total;
+      }
+      __syncthreads();
+      const int walk_total = qoff[n];
+      for (int e = tid; e < walk_total; e += T) {
+        int ra = 0, rb = n;   // the row holding entry e: last r with qoff[r] <= e
+        while (rb - ra > 1) {
+          const int mid = (ra + rb) >> 1;
+          if (qoff[mid] <= e) ra = mid; else rb = mid;
+        }
+        const int u = fwd_indices[qstart[ra] + (e - qoff[ra])];
+        const int v = list[ra];
+        const int slot = hs_find(hkeys, hmask, u);
+        const bool target = (v == src && u == dst) || (v == dst && u == src);
+        if (slot >= 0 && !target) {
+          const int i = ra, j = hvals[slot];
+          atomicOr(&bm_l[i * WB + (j >> 5)], 1u << (j & 31));
+          if (i != j) atomicOr(&bm_l[j * WB + (i >> 5)], 1u << (i & 31));
+        }
+      }
+    } else {
     walk_rows<T, G, 2>(
         0, n, list, fwd_indptr, fwd_indices, nullptr,
         [&](RowAcc& a, int v, int u, bool valid) {
@@ -425,6 +471,7 @@ __global__ __launch_bounds__(T, (T <= 256 ? 8 : 1)) void link_full_kernel(
           }
         },
         [](RowAcc&, int, int) {});
+    }
     if constexpr (BMG) __threadfence();   // the edge list is read back by other waves (through L2)
     __syncthreads();
     S3GRL_FSTAMP(2)
