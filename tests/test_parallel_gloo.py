@@ -241,3 +241,41 @@ def test_khop_cost_tracks_ball_size():
     assert np.array_equal(c1, parallel.link_cost(A, links) + 1)   # 1 + deg per endpoint
     c2 = parallel.khop_cost(A, links, 2)
     assert (c2 >= c1).all()
+
+
+def test_shard_plan_with_replicated_links_is_a_permutation_that_keeps_pairs_together():
+    """ShardPlan(replicate=…): every link appears once; the sharded part comes first, rank by rank, the
+    links every rank computes itself behind it; both directions of a pair are on the same side and next to
+    each other; the "reverse of the previous" marks never reach across a rank boundary or into the
+    replicated part; replicate_cheapest takes whole pairs, cheapest first."""
+    rng = np.random.default_rng(7)
+    n = 200
+    li = rng.integers(0, n, size=(2, 600))
+    li = li[:, li[0] != li[1]]
+    li = np.concatenate([li, li[::-1, :250], li[:, :30]], axis=1)
+    li = np.ascontiguousarray(li[:, rng.permutation(li.shape[1])])
+    L = li.shape[1]
+    cost = rng.random(L) * 100 + 1
+    rep = parallel.replicate_cheapest(li, cost, 0.25)
+    assert 0 < rep.sum() <= 0.25 * L
+    key = np.minimum(li[0], li[1]) * n + np.maximum(li[0], li[1])
+    for k in np.unique(key):                                   # whole pairs
+        assert len(set(rep[key == k].tolist())) == 1
+    mean_cost = lambda m: np.mean([cost[key == k].mean() for k in np.unique(key[m])])
+    assert mean_cost(rep) < mean_cost(~rep)
+    for world in (2, 3, 8):
+        sp = parallel.ShardPlan(li, world, cost, pair_aware=True, replicate=rep)
+        order = sp.order.numpy()
+        assert sorted(order.tolist()) == list(range(L))
+        assert sp.rep_start == L - rep.sum() and sp.bounds[0] == 0 and sp.bounds[-1] == sp.rep_start
+        assert not rep[order[:sp.rep_start]].any() and rep[order[sp.rep_start:]].all()
+        rank_of = np.full(L, world)
+        for r in range(world):
+            rank_of[order[sp.bounds[r]:sp.bounds[r + 1]]] = r
+        for k in np.unique(key):                               # a pair lives on one rank (or is replicated)
+            assert len(set(rank_of[key == k].tolist())) == 1
+        rev = sp.reverse_of_previous
+        links = sp.links.numpy()
+        for i in np.flatnonzero(rev):
+            assert links[0, i] == links[1, i - 1] and links[1, i] == links[0, i - 1] and not rev[i - 1]
+            assert i not in sp.bounds and i != sp.rep_start
