@@ -703,6 +703,7 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   }
   int32_t* e_cap = nullptr;
   int64_t* x_cap = nullptr;   // one-hop plans: (LDS need << 32 | bound of the edges outside the hub's cache), -1: no hub
+  bool balls = false;   // the sizing pass ran on the graph's cached balls (levels 1 .. num_hops are there)
   if (onehop) {
     S3GRL_TRY(arena_alloc(ctx, (size_t)L, &e_cap, own));
     plan->e_cap = e_cap;
@@ -716,7 +717,6 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   } else {
     // plain plans on graphs whose node balls fit: the sizing pass is bitmap arithmetic on the cached balls
     // of the two endpoints (s3grl_balls.hip) instead of a BFS per link
-    bool balls = false;
     if (relabel && !walks && !sampling)
       S3GRL_TRY(ensure_ball_cache(ctx, const_cast<s3grl_graph*>(g), cfg->num_hops, &balls));
     if (balls) {
@@ -735,11 +735,16 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   // offsets of nodes / rows / row pairs, their maxima (ds[1], ds[5]) and totals (ds[9..11]) in one go
   S3GRL_TRY(launch_scan3(ctx, plan->n_nodes, n_rows, n_jobs, L, plan->node_off, plan->row_ptr, plan->job_off,
                          scan_ws, ds + 1, ds + 5, ds + 9));
+  // Plans whose every operator reaches the whole subgraph, on graphs of the bitmap flavour with cached
+  // balls: the links run on their induced LDS CSR (s3grl_csr.hip); its classes are cut by the exact entry
+  // count, which a sizing kernel of its own produces once the node offsets are known
+  const bool csr_plan = !(cfg->flags & S3GRL_FLAG_COUNT_ONLY) && stash != nullptr && balls &&
+                        csr_mode_for(g, cfg->num_hops, K, balls, relabel && !walks && !sampling && !onehop);
   // PoS has no common-neighbour rows: the LDS classes are known without a round trip
-  if (!plus)
+  if (!plus && !csr_plan)
     S3GRL_TRY(launch_classify(ctx, g, 1, K, plan->n_nodes, p_nodes, lvl_max, L, class_count, class_list,
                               !sampling && !g->directed, e_cap, stash ? slot : 0, perm, x_cap));
-  S3GRL_HIP_TRY(hipMemcpyAsync(hs, ds, 48 * 8, hipMemcpyDeviceToHost, ctx->stream));   // scalars + class counts
+  S3GRL_HIP_TRY(hipMemcpyAsync(hs, ds, 56 * 8, hipMemcpyDeviceToHost, ctx->stream));   // scalars + class counts
   S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_stats + 3 * kStatRow, st + 3 * kStatRow, 2 * kStatRow * sizeof(int64_t),
                                hipMemcpyDeviceToHost, ctx->stream));
   S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -759,15 +764,24 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   const int64_t tot_n = hs[16], tot_rows = hs[17], njobs = hs[18];
   // (a relabelled PoS Plus plan sorts its common neighbours by the caller's ids inside cn[]: 3x)
   const int cn_cap = ((int)std::max<int64_t>(max_R - 2, 0) + 1) * ((relabel && plus) ? 3 : 1);
-  if (plus) {
-    S3GRL_TRY(launch_classify(ctx, g, cn_cap, K, plan->n_nodes, p_nodes, lvl_max, L, class_count,
-                              class_list, !sampling && !g->directed, e_cap, stash ? slot : 0, perm, x_cap));
-    S3GRL_HIP_TRY(hipMemcpyAsync(hs + 32, ds + 32, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  uint16_t* csr_cnt = nullptr;
+  int32_t* csr_e = nullptr;
+  if (csr_plan) {
+    S3GRL_TRY(arena_alloc(ctx, (size_t)std::max<int64_t>(tot_n, 1), &csr_cnt, tr));
+    S3GRL_TRY(arena_alloc(ctx, (size_t)L, &csr_e, tr));
+    S3GRL_TRY(launch_csr_count(ctx, &g_walk, links_walk, L, cfg->num_hops, plan->n_nodes, plan->node_off, plan->lvl,
+                               stash, slot, perm, csr_cnt, csr_e));
+  }
+  if (plus || csr_plan) {
+    S3GRL_TRY(launch_classify(ctx, g, plus ? cn_cap : 1, K, plan->n_nodes, p_nodes, lvl_max, L, class_count,
+                              class_list, !sampling && !g->directed, e_cap, stash ? slot : 0, perm, x_cap, csr_e));
+    S3GRL_HIP_TRY(hipMemcpyAsync(hs + 32, ds + 32, 24 * 8, hipMemcpyDeviceToHost, ctx->stream));
     S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
-  int32_t class_count_host[32];   // [0..5] bitmap classes, [6] HBM-scratch class, [7] its max need,
+  int32_t class_count_host[48];   // [0..5] bitmap classes, [6] HBM-scratch class, [7] its max need,
                                   // [8..13] hash classes, [14..19] one-hop classes, [20] one-hop
-                                  // class with its bit matrix in HBM (see classify_kernel)
+                                  // class with its bit matrix in HBM, [21..25] cached-hub classes, [29..31] maxima,
+                                  // [32..37] induced-CSR classes (see classify_kernel)
   std::memcpy(class_count_host, hs + 32, sizeof(class_count_host));
   if (getenv("S3GRL_DEBUG")) {
     fprintf(stderr, "[s3grl] L=%lld max_n=%lld classes:", (long long)L, (long long)max_n);
@@ -851,7 +865,7 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
                          plan->c_coef, plan->jobs, plan->job_z, plan->job_lim, plan->row_nodes, plan->lvl, st,
                          st + kStatRow, st + 2 * kStatRow, smp, stash, slot, e_cap, max_n,
                          relabel ? g->old_of_new : nullptr, relabel ? g->new_of_old : nullptr, split_t, seg_shift,
-                         x_cap));
+                         x_cap, csr_cnt, csr_e));
   if (split_t > 0) {   // pieces per job and their total (read with the statistics below)
     int32_t* pcnt;
     S3GRL_TRY(arena_alloc(ctx, (size_t)njobs, &pcnt, tr));

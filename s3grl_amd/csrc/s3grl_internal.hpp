@@ -377,6 +377,55 @@ s3grl_status launch_hub_class(s3grl_context* ctx, const HubLinkArgs& a, int K, i
                               int count, hipStream_t stream);
 s3grl_status launch_sort_hops(s3grl_context* ctx, const s3grl_plan* p, int32_t* nodes);
 
+// csr.hip — links whose every operator reaches the whole subgraph (sign_k - 1 >= num_hops: p == n), on
+// graphs of the bitmap flavour with cached balls: the masked induced adjacency is built ONCE per link as a
+// CSR of 16-bit list positions in LDS (member counts per row by a sizing kernel of their own, so that the
+// classes are cut by the EXACT LDS need), and all K operators are pulls over it — instead of walking the
+// global rows through the bitmaps once per operator (link_kernel: three full walks at PubMed sign_k = 5).
+// LDS of a link beyond the fixed part: row offsets (uint16 [n + 1]), columns (uint16 [e]) and a region
+// that holds the build's bitmaps / list / rank map first and the two float2 state arrays afterwards.
+constexpr int kCsrBase = 32;             // class lists kCsrBase .. kCsrBase + kNumClasses - 1 (class_count idx alike)
+constexpr int kCsrDinvTable = 256;       // D^-1/2 of degrees below this from an LDS table
+__host__ __device__ inline int csr_fixed_words(int cn_cap, int K) {
+  return 2 * cn_cap + kMaxLevels + 4 * K + 32 + kCsrDinvTable;
+}
+__host__ __device__ inline int csr_lds_need(int n, int e, int W) {
+  const int off_b = 2 * ((n + 2) & ~1), col_b = 2 * ((e + 1) & ~1);
+  const int build = 8 * W + 4 * n + 2 * ((n + 2) & ~1), pass = 16 * n;
+  return ((off_b + col_b + 7) & ~7) + (build > pass ? build : pass) + 8;
+}
+struct CsrLinkArgs {
+  const int32_t *indptr, *indices;   // the degree-ordered graph
+  int W, hops;
+  const uint32_t* balls;             // level `hops` of the ball cache (ball_hops(x) for every x), W words per node
+  const int64_t* links;              // translated into the degree order
+  int plus, cn_cap;
+  const uint16_t* cnt;               // [Σn] member neighbours of every list entry (csr_count_kernel)
+  const int32_t* csr_e;              // [L] their sum per link, -1: not a link of this flavour
+  const int64_t *node_off, *row_ptr, *job_off, *coef_off;
+  const int32_t* mirror_of;
+  int32_t* c_ids;
+  float* c_coef;
+  Job* jobs;
+  float* job_z;
+  int32_t* job_lim;
+  int64_t* row_nodes;
+  int32_t* lvl;
+  unsigned long long *tot_edges, *tot_support, *tot_vol;
+  const int32_t* stash;
+  int slot;
+  const int32_t* old_of_new;
+  int split_t, seg_shift;
+  unsigned long long* dbg;
+};
+int csr_class_bound(int cls, int cn_cap, int K);   // LDS bytes beyond the fixed part of class 0..kNumClasses-1
+bool csr_mode_for(const s3grl_graph* g, int hops, int K, bool balls, bool plain);
+s3grl_status launch_csr_count(s3grl_context* ctx, const s3grl_graph* g_walk, const int64_t* links, int64_t L, int hops,
+                              const int32_t* n_nodes, const int64_t* node_off, const int32_t* lvl,
+                              const int32_t* stash, int slot, const int32_t* perm, uint16_t* cnt, int32_t* csr_e);
+s3grl_status launch_csr_class(s3grl_context* ctx, const CsrLinkArgs& a, int K, int cls, const int32_t* class_list,
+                              int count, hipStream_t stream);
+
 // structure.hip
 s3grl_status launch_count(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                           int hops, int plus, int K, WalkSets ws,
@@ -426,7 +475,8 @@ s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_ca
                              const int32_t* n_nodes, const int32_t* p_nodes,
                              const int32_t* lvl_max, int64_t L, int32_t* class_count,
                              int32_t* class_list, bool allow_hash = true, const int32_t* e_cap = nullptr,
-                             int stash_slot = 0, const int32_t* perm = nullptr, const int64_t* x_cap = nullptr);
+                             int stash_slot = 0, const int32_t* perm = nullptr, const int64_t* x_cap = nullptr,
+                             const int32_t* csr_e = nullptr);
 // one-hop plans on big graphs (s3grl_onehop.inl): degree-oriented rows of the graph, and the
 // sizing pass that needs no bitmaps
 bool sparse_mode_for(const s3grl_graph* g);
@@ -448,7 +498,8 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           HopSampling smp = HopSampling{1.0, 0, 0}, const int32_t* stash = nullptr,
                           int slot = 0, const int32_t* e_cap = nullptr, int64_t max_nodes = 0,
                           const int32_t* old_of_new = nullptr, const int32_t* new_of_old = nullptr,
-                          int split_t = 0, int seg_shift = 0, const int64_t* x_cap = nullptr);
+                          int split_t = 0, int seg_shift = 0, const int64_t* x_cap = nullptr,
+                          const uint16_t* csr_cnt = nullptr, const int32_t* csr_e = nullptr);
 // pieces of the split jobs: piece_off [njobs + 1] (device) and *total (device scalar) first, the
 // piece arrays once the host knows the total
 s3grl_status launch_split_count(s3grl_context* ctx, const Job* jobs, int64_t njobs, int seg_shift,

@@ -696,6 +696,9 @@ constexpr int kFullBig = kFullBase + kNumClasses;
 // kHubBase.. = one-hop links with a cached hub neighbourhood, link_hub_kernel (s3grl_hub.hip) by LDS need
 constexpr int kHubBase = kFullBig + 1;
 constexpr int kNumLists = kHubBase + kHubClasses + 1;   // (+ the class with its found edges in HBM slices)
+static_assert(kNumLists <= 29, "class_count[29..31] carry maxima");
+// kCsrBase.. (s3grl_internal.hpp) = full-reach links on their induced LDS CSR, link_csr_kernel (s3grl_csr.hip)
+constexpr int kNumListsAll = kCsrBase + kNumClasses;
 
 __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
                                 const int32_t* __restrict__ p_nodes,
@@ -704,7 +707,7 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
                                 ClassBounds fbound, int bm_limit, int dm_max_n, int dm_class_mask,
                                 int32_t* __restrict__ class_count, int32_t* __restrict__ class_list,
                                 const int32_t* __restrict__ perm, const int64_t* __restrict__ x_cap,
-                                ClassBounds hbound) {
+                                ClassBounds hbound, const int32_t* __restrict__ csr_e, ClassBounds cbound, int W) {
   const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   // (perm: the class lists come out in the plan's processing order, up to the order of the atomics)
   const int64_t l = li < L ? (perm ? (int64_t)perm[li] : li) : L;
@@ -715,7 +718,18 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
   bool sparse = false;
   // one-hop plan (e_cap is only produced for those), every operator reaches all of S, local ids fit
   // 16 bits: link_full_kernel, by its LDS need with or without the bit matrix on chip
-  if (x_cap && n > 0 && p == n && x_cap[l] >= 0) {
+  // every operator reaches all of S and the sizing kernel of the induced-CSR flavour counted the link's
+  // entries (s3grl_csr.hip): link_csr_kernel, by its exact LDS need
+  if (csr_e && n > 0 && p == n && csr_e[l] >= 0) {
+    const int need_c = csr_lds_need(n, csr_e[l], W);
+    if (need_c <= cbound.b[kNumClasses - 1]) {
+      sparse = true;
+#pragma unroll
+      for (int k = 0; k < kNumClasses; ++k) c += need_c > cbound.b[k] ? 1 : 0;
+      c += kCsrBase;
+    }
+  }
+  if (!sparse && x_cap && n > 0 && p == n && x_cap[l] >= 0) {
     const int64_t stage = x_cap[l] >> 32, xb = x_cap[l] & 0xffffffffll;
     const int64_t need_h = hub_lds_need(n, xb) + stage;
     if (!hbound.b[kHubClasses] && need_h <= hbound.b[kHubClasses - 1]) {   // (b[kHubClasses]: test hook)
@@ -1869,7 +1883,7 @@ static int dm_class_mask_for(const s3grl_graph* g, int cn_cap, int K) {
 }
 
 #ifndef S3GRL_LINKS_PART
-int num_class_lists() { return kNumLists; }
+int num_class_lists() { return kNumListsAll; }
 
 // One-hop plans take the row-intersection path on graphs where the hash flavour is in use anyway.
 bool onehop_mode_for(const s3grl_graph* g) {
@@ -1931,7 +1945,7 @@ s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_ca
                              const int32_t* n_nodes, const int32_t* p_nodes,
                              const int32_t* lvl_max, int64_t L, int32_t* class_count,
                              int32_t* class_list, bool allow_hash, const int32_t* e_cap, int stash_slot,
-                             const int32_t* perm, const int64_t* x_cap) {
+                             const int32_t* perm, const int64_t* x_cap, const int32_t* csr_e) {
   if (L == 0) return S3GRL_OK;
   ClassBounds cb = class_bounds(g->num_nodes, cn_cap, K);
   const bool dm = allow_hash && stash_slot > 0 && dm_mode_for(g);
@@ -1945,13 +1959,15 @@ s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_ca
   static_assert(kHubClasses < kNumClasses, "one more entry for the test hook");
   for (int c = 0; c < kHubClasses; ++c) hb.b[c] = hub_class_bound(c, cn_cap, K);
   hb.b[kHubClasses] = getenv("S3GRL_FORCE_HUB_SLICES") ? 1 : 0;   // test hook: found edges in HBM slices
+  ClassBounds csrb{};
+  for (int c = 0; c < kNumClasses; ++c) csrb.b[c] = csr_class_bound(c, cn_cap, K);
   hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream,
                      n_nodes, p_nodes, lvl_max, L, cb, dm ? 2 : ((allow_hash && sparse_mode_for(g)) ? 1 : 0),
                      dm ? class_bounds_dm(g->num_nodes, cn_cap, K) : class_bounds_sparse(cn_cap, K), e_cap,
                      class_bounds_full(cn_cap, K),
                      getenv("S3GRL_FORCE_BM_HBM") ? 0 : (1 << 30),   // test hook: bit matrices in HBM
                      dm ? std::min(stash_slot + 2, 65535) : 0, dm ? dm_class_mask_for(g, cn_cap, K) : 0,
-                     class_count, class_list, perm, x_cap, hb);
+                     class_count, class_list, perm, x_cap, hb, csr_e, csrb, words_for(g->num_nodes));
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -1999,6 +2015,8 @@ struct LinkArgs {
   uint32_t* hub_slices;                     // link_hub_kernel's overflow class: found-edge list + columns per workgroup
   int64_t hub_slice_words;
   int hub_slice_grid;
+  const uint16_t* csr_cnt;                  // induced-CSR flavour (s3grl_csr.hip): members per list entry,
+  const int32_t* csr_e;                     // ... and per link
 };
 
 // One-hop full-reach classes (link_full_kernel).  Small classes run one wavefront per link (no
@@ -2097,10 +2115,12 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
   static const bool serial = getenv("S3GRL_SERIAL_CLASSES") != nullptr;
   // diagnostic only (with S3GRL_DEBUG_STAMPS): launch one class list, the results are incomplete
   static const int only = getenv("S3GRL_ONLY_CLASS") ? atoi(getenv("S3GRL_ONLY_CLASS")) : -1;
-  int32_t class_count_host[32];
-  for (int c = 0; c < 32; ++c) class_count_host[c] = (only < 0 || c == only || c >= kNumLists) ? class_count_in[c] : 0;
+  int32_t class_count_host[kNumListsAll];
+  for (int c = 0; c < kNumListsAll; ++c)
+    class_count_host[c] = (only < 0 || c == only || (c >= kNumLists && c < kCsrBase)) ? class_count_in[c] : 0;
   int launches = 0;
   for (int c = 0; c < kNumLists; ++c) launches += class_count_host[c] > 0 && c != kNumClasses + 1;
+  for (int c = kCsrBase; c < kNumListsAll; ++c) launches += class_count_host[c] > 0;
   const bool fork = !serial && launches > 1;
   if (fork) {
     S3GRL_TRY(side_streams(ctx));
@@ -2127,6 +2147,18 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
     } else {
       S3GRL_TRY((launch_link_class<1024, K>(ctx, a, L, kNumClasses, class_count_host[kNumClasses], next_stream())));
     }
+  }
+  for (int c = kNumListsAll - 1; c >= kCsrBase; --c) {   // full-reach links on their induced LDS CSR (s3grl_csr.hip)
+    if (class_count_host[c] == 0) continue;
+    CsrLinkArgs h{a.g->indptr, a.g->indices, words_for(a.g->num_nodes), a.hops,
+                  a.g->balls.bits + (int64_t)(a.hops - 1) * a.g->balls.level_stride, a.links, a.plus, a.cn_cap,
+                  a.csr_cnt, a.csr_e, a.node_off, a.row_ptr, a.job_off, a.coef_off, a.mirror_of, a.c_ids, a.c_coef,
+                  a.jobs, a.job_z, a.job_lim, a.row_nodes, a.lvl, reinterpret_cast<unsigned long long*>(a.tot_edges),
+                  reinterpret_cast<unsigned long long*>(a.tot_support),
+                  reinterpret_cast<unsigned long long*>(a.tot_vol), a.stash, a.slot, a.old_of_new, a.split_t,
+                  a.seg_shift, a.dbg};
+    S3GRL_TRY(launch_csr_class(ctx, h, K, c - kCsrBase, a.class_list + (int64_t)c * L, class_count_host[c],
+                               next_stream()));
   }
   if (class_count_host[kFullBig] > 0)
     S3GRL_TRY((launch_full_class<1024, K, true>(ctx, a, L, kFullBig, class_count_host[kFullBig], next_stream(),
@@ -2244,7 +2276,8 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           int64_t* tot_edges, int64_t* tot_support, int64_t* tot_vol,
                           HopSampling smp, const int32_t* stash, int slot, const int32_t* e_cap,
                           int64_t max_nodes, const int32_t* old_of_new, const int32_t* new_of_old,
-                          int split_t, int seg_shift, const int64_t* x_cap) {
+                          int split_t, int seg_shift, const int64_t* x_cap, const uint16_t* csr_cnt,
+                          const int32_t* csr_e) {
   if (L == 0) return S3GRL_OK;
   // links too large for LDS keep their lists in HBM scratch: one 256-byte aligned slice each
   Transient scratch_owner{ctx, {}};
@@ -2275,7 +2308,7 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
              smp, stash, slot, e_cap, nullptr, 0, 0, 0, old_of_new, new_of_old,
              (old_of_new && !getenv("S3GRL_NO_LEAF_WALK")) ? g->deg_le2_from : -1, split_t, seg_shift,
              DirGraph{g->out_indptr, g->out_indices, g->in_indptr, g->in_indices}, bm_ext_words, gs_chunk, 0,
-             x_cap, nullptr, 0, 0};
+             x_cap, nullptr, 0, 0, csr_cnt, csr_e};
   if (class_count_host[kHubBase + kHubClasses] > 0) {   // list of found edges (uint32) + columns (2 x uint16) per slice
     const int64_t xmax = ((int64_t)class_count_host[29] + 63) / 64 * 64;
     a.hub_slice_words = 2 * xmax;

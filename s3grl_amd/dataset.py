@@ -28,13 +28,27 @@ from . import cache as _cache
 from .tuned_SIGN import LinkDataList, OptimizedSignOperations
 
 
+class OperatorStandIn:
+    """One element of `GlobalOperators`: no values, only the number of entries the reference's
+    `SparseTensor(row, col)` would hold — one per column of the edge_index, duplicates included."""
+
+    def __init__(self, num_entries):
+        self._n = int(num_entries)
+
+    def nnz(self):
+        return self._n
+
+
 class GlobalOperators(list):
     """Stand-in for the reference's `powers_of_A` (sgrl_link_pred.py:161-178: K torch_sparse
     SparseTensors Â, Â², …): the engine rebuilds Â from A's structure and never materialises a
-    power, so the list only carries its length (= sign_k) and truthiness."""
+    power, so the list carries its length (= sign_k), truthiness and — with `num_entries`, the
+    number of columns of the edge_index Â is built from — what the SoP operator needs to tell a
+    pair listed m times (m entries) from a pair of weight m (one entry), which A's summed data
+    cannot (`tuned_SIGN._multiplicity_of`).  Without it: every stored pair counts once."""
 
-    def __init__(self, sign_k):
-        super().__init__([None] * int(sign_k))
+    def __init__(self, sign_k, num_entries=None):
+        super().__init__([None if num_entries is None else OperatorStandIn(num_entries)] * int(sign_k))
 
 
 def _hybrid_combine(pos_part, sop_part, sign_k):
@@ -117,6 +131,19 @@ def create_rw_cache(A, edges, device, rw_m, rw_M, seed=0):
     return scaled.create_rw_cache(g_dev, edges, device, rw_m, rw_M, seed=seed, engine=eng)
 
 
+def coalesce(edge_index, edge_weight, num_nodes):
+    """torch_sparse `coalesce(index, value, m, n)` as sgrl_link_pred.py:102-105 uses it (`use_coalesce`,
+    ogbl-collab): pairs sorted row-major, duplicates merged, their weights ADDED (None stays None)."""
+    ei = np.asarray(edge_index)
+    key = ei[0].astype(np.int64) * int(num_nodes) + ei[1]
+    uniq, inv = np.unique(key, return_inverse=True)
+    out = np.stack([uniq // int(num_nodes), uniq % int(num_nodes)])
+    if edge_weight is None:
+        return out, None
+    w = np.asarray(edge_weight).reshape(-1)
+    return out, np.bincount(inv, weights=w, minlength=len(uniq)).astype(w.dtype)
+
+
 def train_graph(edge_index, num_nodes, edge_weight=None):
     """sgrl_link_pred.py:107-114: `ssp.csr_matrix((edge_weight, (row, col)), shape=(N, N))`, int
     ones when the data has no weights; duplicate entries are summed by scipy."""
@@ -156,7 +183,7 @@ def make_sign_kwargs(*, sign_k, sign_type, optimize_sign=True, k_heuristic=0,
 def process_split(split, split_edge, edge_index, num_nodes, x, num_hops, *, sign_k, sign_type="PoS",
                   optimize_sign=True, k_heuristic=0, k_node_set_strategy="intersection",
                   use_feature=True, node_label="zo", ratio_per_hop=1.0, max_nodes_per_hop=None,
-                  directed=False, edge_weight=None, m=0, M=0, rw_seed=0, percent=100,
+                  directed=False, edge_weight=None, use_coalesce=False, m=0, M=0, rw_seed=0, percent=100,
                   dataset_root=None, seed=0, device=None):
     """`SEALDataset.process` for `model == 'SIGN'`, non-pairwise (sgrl_link_pred.py:96-220):
     link lists of the split -> train graph A -> sign_kwargs (+ the global-operator stand-in for
@@ -173,7 +200,9 @@ def process_split(split, split_edge, edge_index, num_nodes, x, num_hops, *, sign
 
     def compute():
         pos_edge, neg_edge = pos_neg_edges(split, split_edge, percent)
-        A = train_graph(edge_index, num_nodes, edge_weight)
+        ei, ew = (coalesce(edge_index, edge_weight, num_nodes) if use_coalesce      # :102-105
+                  else (np.asarray(edge_index), edge_weight))
+        A = train_graph(ei, num_nodes, ew)
         A_csc = A.tocsc() if directed else None
         sign_kwargs = make_sign_kwargs(sign_k=sign_k, sign_type=sign_type, optimize_sign=optimize_sign,
                                        k_heuristic=k_heuristic, k_node_set_strategy=k_node_set_strategy,
@@ -189,7 +218,7 @@ def process_split(split, split_edge, edge_index, num_nodes, x, num_hops, *, sign
                 cached_neg = create_rw_cache(A, neg_edge, device, m, M, seed=rw_seed)
             rw_kwargs = {"rw_m": m, "rw_M": M, "sign": True, "seed": rw_seed,
                          "cached_pos_rws": cached_pos, "cached_neg_rws": cached_neg}
-        powers_of_A = GlobalOperators(sign_k) if sign_type in ("SoP", "hybrid") else []
+        powers_of_A = GlobalOperators(sign_k, ei.shape[1]) if sign_type in ("SoP", "hybrid") else []
         print("Setting up Positive Subgraphs")
         pos_list = extract_enclosing_subgraphs(pos_edge, A, x, 1, num_hops, node_label, ratio_per_hop,
                                                max_nodes_per_hop, directed, A_csc, rw_kwargs, sign_kwargs,

@@ -451,38 +451,94 @@ def _sampling_of(ratio_per_hop, max_nodes_per_hop):
             "max_nodes_per_hop": max_nodes_per_hop, "seed": SAMPLING_SEED}
 
 
-def _multiplicity_of(A):
-    """The reference's SoP operator is built from the UNCOALESCED edge_index: a pair that occurs m times
-    counts m times (sgrl_link_pred.py:161-172).  `A` is what the caller made of the same edge_index
-    with int ones as weights (sgrl_link_pred.py:107-114), so an integer A.data > 1 IS that multiplicity
-    (scipy sums duplicates).  A float-weighted A (a dataset with edge_weight) says nothing about
-    duplicates: treated as coalesced."""
+def _operator_entries(op):
+    """What the first element of the caller's `powers_of_A` tells about the edge_index Â was built
+    from: ("pairs", row, col) when it exposes its entries (torch_sparse `SparseTensor.coo()`, a scipy
+    matrix, the stand-in of s3grl_amd.dataset), ("count", n) when only an entry count (`nnz()` /
+    `.nnz`), None for a placeholder."""
     import numpy as np
 
-    data = getattr(A, "data", None)
-    if data is None or not len(data) or data.dtype.kind not in "iu" or int(data.max()) <= 1:
+    if op is None:
         return None
+
+    def arr(t):
+        return np.asarray(t.cpu() if hasattr(t, "cpu") else t).reshape(-1).astype(np.int64)
+
+    coo = getattr(op, "coo", None)
+    if callable(coo):                                      # torch_sparse.SparseTensor
+        got = coo()
+        return ("pairs", arr(got[0]), arr(got[1]))
+    if hasattr(op, "tocoo"):                               # scipy (non-optimised callers densify, :180-182)
+        c = op.tocoo()
+        return ("pairs", arr(c.row), arr(c.col))
+    if hasattr(op, "row") and hasattr(op, "col") and not callable(op.row):
+        return ("pairs", arr(op.row), arr(op.col))
+    n = getattr(op, "nnz", None)
+    if callable(n):
+        n = n()
+    return None if n is None else ("count", int(n))
+
+
+def _multiplicity_of(A, powers_of_A=()):
+    """How often every stored entry of A counts in the reference's SoP operator, or None for "once".
+
+    The reference builds Â from `SparseTensor(row, col)` of the edge_index AS IT STANDS
+    (sgrl_link_pred.py:161-172): weights never enter, and a pair listed m times is m entries.  `A`
+    cannot tell the two apart — scipy has summed duplicates AND weights into its data
+    (sgrl_link_pred.py:107-114; with `use_coalesce`, :102-105 and :1099, the edge_index is coalesced
+    and A.data are summed edge weights) — so the answer comes from what the caller hands in as
+    `powers_of_A[0]`, which has exactly the entries of that edge_index:
+      * its (row, col) pairs, when exposed: counted per pair;
+      * else its entry count: equal to A's stored entries => coalesced => once, whatever A.data holds;
+        larger => duplicates, and then A's integer data are the counts iff they add up to it;
+      * a placeholder says nothing: once (structural), the behaviour of a coalesced edge_index."""
+    import numpy as np
     import scipy.sparse as ssp
 
+    info = _operator_entries(powers_of_A[0]) if len(powers_of_A) else None
+    if info is None:
+        return None
     C_ = ssp.csr_matrix(A)
     if not C_.has_canonical_format:
         C_ = C_.copy()
         C_.sum_duplicates()
-    return np.asarray(C_.data, dtype=np.float32)
+    n = C_.shape[0]
+    if info[0] == "pairs":
+        row, col = info[1], info[2]
+        if len(row) == C_.nnz:
+            return None
+        if len(row) < C_.nnz:
+            raise ValueError(f"powers_of_A[0] has {len(row)} entries, A stores {C_.nnz}: not the same graph")
+        counted = ssp.csr_matrix((np.ones(len(row), dtype=np.int64), (row, col)), shape=(n, n))
+        counted.sum_duplicates()
+        if counted.nnz != C_.nnz or not np.array_equal(counted.indptr, C_.indptr) \
+                or not np.array_equal(counted.indices, C_.indices):
+            raise ValueError("powers_of_A[0] and A do not have the same entries")
+        return np.asarray(counted.data, dtype=np.float32)
+    count = info[1]
+    if count == C_.nnz:
+        return None
+    data = np.asarray(C_.data)
+    if count > C_.nnz and data.dtype.kind in "iu" and int(data.sum()) == count:
+        return data.astype(np.float32)
+    raise ValueError(f"powers_of_A[0] has {count} entries and A stores {C_.nnz} whose data do not add up "
+                     "to that: cannot tell how often each pair is listed (hand in an operator that "
+                     "exposes its entries, e.g. torch_sparse.SparseTensor.coo())")
 
 
 class OptimizedSignOperations:
     @staticmethod
     def get_SoP_prepped_ds(powers_of_A, link_index, A, x, y):
-        """Reference tuned_SIGN.py:49-134.  `powers_of_A` is only consulted for its length
-        (= sign_k): the engine rebuilds Â from A's structure, which is what the reference's
-        caller derived it from (sgrl_link_pred.py:161-178)."""
+        """Reference tuned_SIGN.py:49-134.  `powers_of_A` is consulted for its length (= sign_k) and, in
+        its first element, for the entries of the edge_index it was built from (how often a pair is
+        listed, `_multiplicity_of`); its values are never read: the engine rebuilds Â from A's
+        structure, which is what the reference's caller derived it from (sgrl_link_pred.py:161-178)."""
         print("SoP Optimized Flow.")
         K = len(powers_of_A)
         if K < 1:
             raise ValueError("powers_of_A is empty")
         eng, g, xd = _device_inputs(A, x)
-        res = eng.precompute(g, xd, eng.links(link_index), mode="sop", sign_k=K, multiplicity=_multiplicity_of(A))
+        res = eng.precompute(g, xd, eng.links(link_index), mode="sop", sign_k=K, multiplicity=_multiplicity_of(A, powers_of_A))
         return _as_data_list(res, K, y, fixed_rows=2)
 
     @staticmethod

@@ -193,3 +193,82 @@ def test_upload_cache_detects_new_and_mutated_inputs(monkeypatch):
     _, _, x5 = ts._device_inputs(B, xn)
     assert x5 is not x4
     ts._cache.clear()
+
+
+# ---- SoP: how often a pair counts is decided from powers_of_A[0], not from A.data ------------------------
+class _SparseTensorLike:
+    """What the drop-in may see of torch_sparse.SparseTensor: `coo()` -> (row, col, value), `nnz()`."""
+
+    def __init__(self, row, col):
+        self._r, self._c = torch.as_tensor(row), torch.as_tensor(col)
+
+    def coo(self):
+        return self._r, self._c, None
+
+    def nnz(self):
+        return int(self._r.numel())
+
+
+class _CountOnly:
+    def __init__(self, n):
+        self._n = n
+
+    def nnz(self):
+        return self._n
+
+
+def _multi_edge_index(seed=0, n=12, m=30, dup=9):
+    rng = np.random.default_rng(seed)
+    e = np.unique(np.sort(rng.integers(0, n, size=(m, 2)), axis=1), axis=0)
+    e = e[e[:, 0] != e[:, 1]]
+    both = np.concatenate([e, e[rng.choice(len(e), dup)]])
+    return n, np.concatenate([both, both[:, ::-1]]).T
+
+
+def test_sop_multiplicity_follows_the_callers_operator():
+    """sgrl_link_pred.py:102-114,161-172: Â is built from SparseTensor(row, col) of the edge_index as
+    it stands — duplicates are entries, weights are not.  A's data cannot tell (scipy sums both)."""
+    import scipy.sparse as ssp
+    from s3grl_amd.dataset import GlobalOperators, coalesce, train_graph
+
+    n, ei = _multi_edge_index()
+    A = train_graph(ei, n)                                   # int ones, duplicates summed
+    assert A.data.max() >= 2
+    want = A.data.astype(np.float32)
+    # uncoalesced edge_index: entries exposed, count only, the twin's stand-in
+    for ops in ([_SparseTensorLike(ei[0], ei[1])] * 2, [_CountOnly(ei.shape[1])] * 2,
+                GlobalOperators(2, ei.shape[1])):
+        assert np.array_equal(ts._multiplicity_of(A, ops), want)
+    # use_coalesce: one entry per pair, the counts have become integer WEIGHTS -> every pair once
+    cei, cw = coalesce(ei, np.ones(ei.shape[1], dtype=np.int64), n)
+    Aw = train_graph(cei, n, cw)
+    assert np.array_equal(Aw.data, A.data) and cei.shape[1] == A.nnz
+    for ops in ([_SparseTensorLike(cei[0], cei[1])], [_CountOnly(cei.shape[1])], GlobalOperators(1, cei.shape[1])):
+        assert ts._multiplicity_of(Aw, ops) is None
+    # a placeholder says nothing: structural
+    assert ts._multiplicity_of(A, [None, None]) is None and ts._multiplicity_of(A, GlobalOperators(3)) is None
+    # duplicates AND weights: only the entries can tell; a bare count cannot
+    w = np.arange(1, ei.shape[1] + 1, dtype=np.int64)
+    Adw = train_graph(ei, n, w)
+    assert np.array_equal(ts._multiplicity_of(Adw, [_SparseTensorLike(ei[0], ei[1])]), want)
+    with pytest.raises(ValueError):
+        ts._multiplicity_of(Adw, [_CountOnly(ei.shape[1])])
+    # float weights, no duplicates
+    Af = ssp.csr_matrix((np.random.default_rng(1).random(cei.shape[1]), (cei[0], cei[1])), shape=(n, n))
+    assert ts._multiplicity_of(Af, [_CountOnly(cei.shape[1])]) is None
+    # an operator of another graph is refused
+    with pytest.raises(ValueError):
+        ts._multiplicity_of(A, [_SparseTensorLike(ei[0][:-2], (ei[1][:-2] + 1) % n)])
+    with pytest.raises(ValueError):
+        ts._multiplicity_of(A, [_CountOnly(A.nnz - 1)])
+
+
+def test_coalesce_twin():
+    """torch_sparse.coalesce as `use_coalesce` calls it: sorted pairs, weights of duplicates added."""
+    from s3grl_amd.dataset import coalesce
+
+    ei = np.array([[2, 0, 2, 1, 0], [1, 3, 1, 0, 3]])
+    out, w = coalesce(ei, np.array([1, 2, 3, 4, 5]), 4)
+    assert out.tolist() == [[0, 1, 2], [3, 0, 1]] and w.tolist() == [7, 4, 4]
+    out, w = coalesce(ei, None, 4)
+    assert out.tolist() == [[0, 1, 2], [3, 0, 1]] and w is None

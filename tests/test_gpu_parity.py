@@ -1118,9 +1118,11 @@ def test_split_jobs_on_the_one_hop_path(eng, monkeypatch):
 @pytest.mark.parametrize("K", [1, 2, 3, 4])
 def test_sop_on_a_multigraph(eng, K):
     """SoP's global operator counts duplicate entries of the caller's edge_index (the reference builds
-    it from the uncoalesced SparseTensor, sgrl_link_pred.py:161-172).  A carries the multiplicity as
-    its integer data (duplicates summed by scipy, sgrl_link_pred.py:107-114): the drop-in operator
-    reads it from there; against the oracle's operator built from the edge list itself."""
+    it from the uncoalesced SparseTensor, sgrl_link_pred.py:161-172).  The drop-in learns how often a
+    pair is listed from the entries of `powers_of_A[0]` (a stand-in exposing `nnz()` here), never from
+    A's data alone; against the oracle's operator built from the edge list itself.  The same A.data
+    as summed WEIGHTS of a coalesced edge_index (`use_coalesce`, :102-105) gives the unweighted
+    operator."""
     import scipy.sparse as ssp
     import torch
     from s3grl_amd.tuned_SIGN import OptimizedSignOperations as ops, clear_cache
@@ -1136,7 +1138,10 @@ def test_sop_on_a_multigraph(eng, K):
     assert A.data.max() >= 2
     X = rng.standard_normal((n, 7)).astype(np.float32)
     links = g["links"].T
-    lst = ops.get_SoP_prepped_ds([None] * K, torch.from_numpy(links), A, torch.from_numpy(X), 1)
+    from s3grl_amd.dataset import GlobalOperators
+
+    lst = ops.get_SoP_prepped_ds(GlobalOperators(K, ei.shape[1]), torch.from_numpy(links), A,
+                                 torch.from_numpy(X), 1)
     P = oracle.global_normalized_powers(A, K, np.float64, edge_index=ei)
     ref = oracle.get_SoP_prepped_ds(P, links, A, X.astype(np.float64), 1, dtype=np.float64)
     for i in range(links.shape[1]):
@@ -1146,6 +1151,12 @@ def test_sop_on_a_multigraph(eng, K):
     plain = oracle.get_SoP_prepped_ds(oracle.global_normalized_powers(A, K, np.float64), links, A,
                                       X.astype(np.float64), 1, dtype=np.float64)
     assert max(rel_err(lst[i]["x1"].numpy(), plain[i]["x1"]) for i in range(links.shape[1])) > 1e-3
+    # coalesced edge_index, integer weights: one entry per pair -> the unweighted operator
+    for standin in (GlobalOperators(K, A.nnz), [None] * K):
+        lw = ops.get_SoP_prepped_ds(standin, torch.from_numpy(links), A, torch.from_numpy(X), 1)
+        for i in range(links.shape[1]):
+            for k in ["x"] + [f"x{j}" for j in range(1, K + 1)]:
+                assert rel_err(lw[i][k].numpy(), plain[i][k]) < TOL
     clear_cache()
 
 
