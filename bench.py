@@ -7,11 +7,15 @@ One "step" = one pass of the hot path (plan: extraction + operator rows; run: fe
 over the workload's whole link list (train/valid/test x pos/neg, 164 000 links for PubMed) with
 the graph and X already resident in HBM.  Prints ONE JSON line (rank 0).
 
-N > 1: STRONG scaling, as BASELINE.json's north_star describes it — the SAME link list is cut into
-N contiguous cost-balanced ranges, one per GPU (graph + X replicated), every rank runs the engine
-on its range and the result is reassembled on every rank by RCCL all-gathers over xGMI that are
-timed inside the step (`s3grl_amd/parallel.py`; pieces of a range are gathered while the next
-piece is computed).  value = links of the whole list / max-over-ranks step time.
+N > 1: STRONG scaling, as BASELINE.json's north_star describes it — the SAME link list is assigned to
+the N GPUs once at set-up (graph + X replicated): pair-aware shards balanced by the engine's per-link cost
+model (`parallel.ShardPlan`: both directions of a pair on one rank; `--contiguous-shards` = cost-balanced
+contiguous ranges), every rank runs the engine on its links and the result is reassembled on every rank by
+RCCL all-gathers over xGMI that are timed inside the step (`s3grl_amd/parallel.py`: the pieces of a shard
+are gathered while the next piece is computed; what a rank can form itself — operator 0, reversed
+duplicates, the cheapest links — does not travel).  value = links of the whole list / max-over-ranks step
+time.  A rank that dies or a rendezvous that times out ends the run with a non-zero exit code and a
+one-line reason on stderr.
 Launched either by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`
 (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or directly as `python bench.py --gpus N`,
 which starts the N ranks itself as child processes BEFORE anything touches the GPU.
@@ -216,7 +220,9 @@ def choose_replicate_fraction(dist, backend, eng, parallel, compute, shards, li_
     step of the sharded list and one all-gather of the full payload are timed (set-up, RCCL only); with the
     cost model's share of the cheapest g of the list, a step takes about
         max( own compute without them + their compute in full ,  first piece + (1 - g) * all-gather )
-    and g is taken from a grid.  Rank 0 decides for everybody."""
+    and g is taken from a grid.  Rank 0 decides for everybody.  What can fail on ONE rank (the probe
+    buffer, the compute-only steps) runs before any collective, and the ranks agree on its success first:
+    a rank that failed must not leave the others waiting, nor build a ShardPlan of its own."""
     import torch
 
     if backend != "nccl" and not os.environ.get("S3GRL_BENCH_TUNE_ANY_BACKEND"):   # (rehearsal hook: exercise this code over gloo)
@@ -224,21 +230,30 @@ def choose_replicate_fraction(dist, backend, eng, parallel, compute, shards, li_
     small = eng.device if backend == "nccl" else "cpu"      # where the few-number collectives live
     L = li_dev.shape[1]
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    for rep_ in range(2):      # (the second run: buffers and caches warm)
-        dist.barrier()
-        ev[0].record()
-        parallel.sharded_precompute(compute, li_dev, rank=rank, world_size=world, gather=False, rows_per_link=2,
-                                    row_shape=(K + 1, F + 1), device=eng.device, reuse_buffers=True, shards=shards)
-        ev[1].record()
-        torch.cuda.synchronize()
-    t_comp = torch.tensor([ev[0].elapsed_time(ev[1])], device=small)
+    buf, t_local, err = None, 0.0, None
+    try:
+        sent = [sum(nr) for nr in shards.transport(chunks, eng.device)[3]]
+        rmax = 2 * max(sent)
+        kx = K + 1 if exchange_op0 else K
+        buf = torch.empty((world * rmax, kx, F + 1), dtype=torch.float32, device=eng.device)
+        for rep_ in range(2):      # (the second run: buffers and caches warm)
+            ev[0].record()
+            parallel.sharded_precompute(compute, li_dev, rank=rank, world_size=world, gather=False, rows_per_link=2,
+                                        row_shape=(K + 1, F + 1), device=eng.device, reuse_buffers=True, shards=shards)
+            ev[1].record()
+            torch.cuda.synchronize()
+        t_local = ev[0].elapsed_time(ev[1])
+    except Exception as e:
+        err = repr(e)
+    agreed = torch.tensor([0 if err else 1], dtype=torch.int64, device=small)
+    dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+    if int(agreed.item()) == 0:
+        del buf
+        return 0.0, {"error": err or "the probe failed on another rank", "note": "nothing replicated (all ranks)"}
+    t_comp = torch.tensor([t_local], device=small)
     t_all = t_comp.clone()
     dist.all_reduce(t_all, op=dist.ReduceOp.SUM)
     dist.all_reduce(t_comp, op=dist.ReduceOp.MAX)
-    sent = [sum(nr) for nr in shards.transport(chunks, eng.device)[3]]
-    rmax = 2 * max(sent)
-    kx = K + 1 if exchange_op0 else K
-    buf = torch.empty((world * rmax, kx, F + 1), dtype=torch.float32, device=eng.device)
     best = None
     for _ in range(2):
         dist.barrier()
@@ -267,6 +282,40 @@ def choose_replicate_fraction(dist, backend, eng, parallel, compute, shards, li_
     pick = round(float(choice), 4)
     return pick, {"compute_only_ms_max": t_comp, "compute_only_ms_sum": t_all, "allgather_alone_ms": t_ag,
                   "estimated_step_ms": {str(k): round(v, 3) for k, v in est.items()}}
+
+
+def rccl_summary(path):
+    """What RCCL said about the communicator it built (NCCL_DEBUG=INFO, subsystems INIT and GRAPH, written to
+    `path` by this rank): channels, the transports of its connections, ring / tree lines — the facts DESIGN §6's
+    estimates depend on (a direct all-gather over 7 xGMI links, or a ring through one).  Never raises."""
+    import re
+
+    out = {"log": str(path)}
+    try:
+        text = Path(path).read_text(errors="replace")
+    except OSError as e:
+        return dict(out, error=repr(e))
+    lines = [ln.split("NCCL INFO", 1)[1].strip() for ln in text.splitlines() if "NCCL INFO" in ln]
+    out["info_lines"] = len(lines)
+    ch = [ln for ln in lines if re.match(r"Channel \d+/\d+", ln)]
+    if ch:
+        m = re.match(r"Channel \d+/(\d+)", ch[0])
+        out["channels"] = int(m.group(1)) if m else len(ch)
+        out["first_ring"] = ch[0][:160]
+    via = {}
+    for ln in lines:
+        m = re.search(r"via (\S+)", ln)
+        if m and "->" in ln:
+            via[m.group(1)] = via.get(m.group(1), 0) + 1
+    if via:
+        out["connections_via"] = via
+    for key, pat in (("trees", r"^Trees "), ("rings_connected", r"Connected all rings"), ("trees_connected", r"Connected all trees"),
+                     ("thresholds", r"threadThresholds"), ("comm", r"comm 0x\S+ rank \d+ nranks \d+"),
+                     ("version", r"(RCCL|NCCL) version"), ("xgmi", r"(?i)xgmi"), ("algo", r"(?i)\balgo")):
+        hit = [ln for ln in lines if re.search(pat, ln)]
+        if hit:
+            out[key] = hit[0][:200] if key not in ("xgmi", "algo") else [h[:160] for h in hit[:4]]
+    return out
 
 
 def cpu_baseline(w, link_index, y, budget_s, max_links):
@@ -450,14 +499,36 @@ def spawn_ranks(args):
         if ndev < args.gpus:                 # rehearsal on a box with fewer GPUs: share them, gloo
             env.setdefault("S3GRL_BENCH_BACKEND", "gloo")
         procs.append(subprocess.Popen([sys.executable, str(REPO / "bench.py")] + sys.argv[1:], env=env))
-    rc = 0
+    # A dead rank must not leave the others (and this parent) waiting in a collective: the first child to
+    # fail, or the deadline, ends them all — non-zero exit code, one line saying why.
+    deadline = time.monotonic() + float(os.environ.get("S3GRL_BENCH_TIMEOUT", "1500"))
+    rc, why = 0, None
     try:
-        for p in procs:
-            rc = p.wait() or rc
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                rc = bad[0][1] if bad[0][1] > 0 else 1
+                why = "rank %d exited with code %d" % bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > deadline:
+                rc, why = 124, "no result after S3GRL_BENCH_TIMEOUT = %.0f s (ranks still running: %s)" % (
+                    float(os.environ.get("S3GRL_BENCH_TIMEOUT", "1500")), [r for r, c in enumerate(codes) if c is None])
+                break
+            time.sleep(0.2)
     finally:
         for p in procs:
             if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
                 p.kill()
+    if why:
+        sys.stderr.write("bench.py --gpus %d FAILED: %s; the other ranks were stopped\n" % (args.gpus, why))
     return rc
 
 
@@ -509,6 +580,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    rccl_log = None
     # one rank per GPU; a rehearsal with more ranks than GPUs (S3GRL_BENCH_BACKEND=gloo on a
     # one-GPU box) shares the devices round-robin
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
@@ -516,12 +588,24 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
+        import datetime
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(dev_index)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend)
+        if backend == "nccl" and "NCCL_DEBUG" not in os.environ:
+            # RCCL's own account of the communicator (channels, transports) goes into the JSON line
+            rccl_log = "/tmp/s3grl_rccl_%d_rank%d.log" % (os.getppid(), rank)
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH", NCCL_DEBUG_FILE=rccl_log)
+        wait = datetime.timedelta(seconds=float(os.environ.get("S3GRL_BENCH_RENDEZVOUS_S", "300")))
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=wait)
+            else:
+                dist.init_process_group(backend, timeout=wait)
+        except Exception as e:
+            sys.stderr.write("bench.py rank %d/%d FAILED: init_process_group(%s) did not complete within %.0f s: %r\n"
+                             % (rank, world, backend, wait.total_seconds(), e))
+            sys.exit(3)
     torch.cuda.set_device(dev_index)
 
     import __graft_entry__ as ge
@@ -611,13 +695,10 @@ def main():
             replicate_info = None
             frac = args.replicate_fraction
             if gather and not args.contiguous_shards and frac != 0.0:
-                if frac < 0.0:
-                    try:
-                        frac, replicate_info = choose_replicate_fraction(
-                            dist, backend, eng, parallel, compute, shards, li_dev, cost, rank, world, K, F,
-                            args.exchange_operator0, args.chunks)
-                    except Exception as e:      # (a measurement aid must not take the run down: nothing replicated)
-                        frac, replicate_info = 0.0, {"error": repr(e)}
+                if frac < 0.0:      # (its one-rank failures are agreed on inside; a failing collective ends the run)
+                    frac, replicate_info = choose_replicate_fraction(
+                        dist, backend, eng, parallel, compute, shards, li_dev, cost, rank, world, K, F,
+                        args.exchange_operator0, args.chunks)
                 if frac > 0.0:
                     rep = parallel.replicate_cheapest(link_index, cost, frac)
                     shards = parallel.ShardPlan(li_dev, world, cost, pair_aware=True, device=eng.device, replicate=rep)
@@ -770,7 +851,8 @@ def main():
                                 "primary's in swapped order, rebuilt on every rank (%d of %d links)"
                                 % (shard_info.get("links_not_sent", 0), L))
                                if fixed_rows else "sizes + one padded all_gather_into_tensor + compaction"),
-                "backend": backend, "links_per_rank": shard_info["links_per_rank"],
+                "backend": backend, "rccl": rccl_summary(rccl_log) if rccl_log else None,
+                "links_per_rank": shard_info["links_per_rank"],
                 "links_sent_per_rank": shard_info.get("links_sent_per_rank"),
                 "replicated_links": shard_info.get("replicated"),
                 "per_rank": per_rank,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define S3GRL_ABI_VERSION 5
+#define S3GRL_ABI_VERSION 6
 
 typedef enum s3grl_status {
   S3GRL_OK = 0,
@@ -215,6 +215,9 @@ s3grl_status s3grl_plan_destroy(s3grl_plan* p);
 s3grl_status s3grl_plan_get_stats(const s3grl_plan* p, s3grl_plan_stats* out);
 /* ΣR alone (host int64 out): what the caller sizes `rows` by; never waits */
 s3grl_status s3grl_plan_total_rows(const s3grl_plan* p, int64_t* total_rows);
+/* what the host knows of a plan the moment it exists (host int64 [4] out; never waits): [0] links,
+ * [1] total rows ΣR, [2] links folded into their reversed duplicate, [3] row pairs (gather jobs) */
+s3grl_status s3grl_plan_counts(const s3grl_plan* p, int64_t* what);
 /* device int64 [L+1] out */
 s3grl_status s3grl_plan_row_ptr(const s3grl_plan* p, int64_t* row_ptr);
 /* device int64 [total_rows] out: global node id of every output row */

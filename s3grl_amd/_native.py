@@ -31,7 +31,7 @@ SYMBOLS = [
     "s3grl_context_create", "s3grl_context_destroy", "s3grl_context_timings",
     "s3grl_context_set_profiling", "s3grl_context_trim", "s3grl_plan_gather_traffic",
     "s3grl_graph_create", "s3grl_graph_create_directed", "s3grl_graph_destroy",
-    "s3grl_plan_create", "s3grl_plan_create_sets", "s3grl_walk_sets", "s3grl_plan_destroy", "s3grl_plan_get_stats", "s3grl_plan_total_rows", "s3grl_plan_row_ptr",
+    "s3grl_plan_create", "s3grl_plan_create_sets", "s3grl_walk_sets", "s3grl_plan_destroy", "s3grl_plan_get_stats", "s3grl_plan_total_rows", "s3grl_plan_counts", "s3grl_plan_row_ptr",
     "s3grl_plan_row_nodes", "s3grl_plan_export_subgraphs", "s3grl_plan_link_cost", "s3grl_run",
     "s3grl_sop_create", "s3grl_sop_create_weighted", "s3grl_sop_destroy", "s3grl_sop_run", "s3grl_sop_features",
     "s3grl_features_create", "s3grl_features_destroy", "s3grl_features_info", "s3grl_run_features",
@@ -52,7 +52,7 @@ class NodeSets(C.Structure):
                 ("num_set_nodes", C.c_int64), ("per_link", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 FLAG_FULL_STATS, FLAG_NO_FOLD, FLAG_COUNT_ONLY = 1, 2, 4
 
 
@@ -112,6 +112,7 @@ def lib():
         "s3grl_plan_destroy": [vp],
         "s3grl_plan_get_stats": [vp, C.POINTER(PlanStats)],
         "s3grl_plan_total_rows": [vp, C.POINTER(i64)],
+        "s3grl_plan_counts": [vp, C.POINTER(i64)],
         "s3grl_plan_row_ptr": [vp, vp],
         "s3grl_plan_row_nodes": [vp, vp],
         "s3grl_plan_export_subgraphs": [vp, vp, vp, vp],

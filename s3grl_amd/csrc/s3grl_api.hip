@@ -964,6 +964,15 @@ s3grl_status s3grl_plan_total_rows(const s3grl_plan* p, int64_t* total_rows) {
   return S3GRL_OK;
 }
 
+s3grl_status s3grl_plan_counts(const s3grl_plan* p, int64_t* what) {
+  if (!p || !what) return S3GRL_ERR_INVALID_ARGUMENT;
+  what[0] = p->L;
+  what[1] = p->stats.total_rows;
+  what[2] = p->stats.folded_links;
+  what[3] = p->njobs;
+  return S3GRL_OK;
+}
+
 s3grl_status s3grl_plan_link_cost(const s3grl_plan* p, float* cost) {
   if (!p || (!cost && p->L)) return S3GRL_ERR_INVALID_ARGUMENT;
   if (p->L == 0) return S3GRL_OK;

@@ -132,9 +132,9 @@ class Plan:
         self._h = h
         engine._children.add(self)
         self._stats = None
-        tr = C.c_int64()
-        N.check(N.lib().s3grl_plan_total_rows(h, C.byref(tr)), "s3grl_plan_total_rows")
-        self.total_rows = int(tr.value)
+        cnt = (C.c_int64 * 4)()
+        N.check(N.lib().s3grl_plan_counts(h, cnt), "s3grl_plan_counts")
+        self.total_rows, self.folded_links = int(cnt[1]), int(cnt[2])
 
     @property
     def stats(self):
@@ -348,6 +348,18 @@ class Engine:
             N.check(N.lib().s3grl_plan_export_subgraphs(p._h, _ptr(node_ptr), C.c_void_p(0), C.c_void_p(0)),
                     "s3grl_plan_export_subgraphs")
             return node_ptr.diff()
+        finally:
+            p.close()
+
+    def folded_mask(self, graph, links):
+        """bool [L] on the device: the links a plan serves from the extraction of their reversed duplicate
+        earlier in the list (a count-only plan reports them with an empty subgraph)."""
+        p = self.plan(graph, links, mode="pos", num_hops=1, sign_k=1, count_only=True, fold_reversed=True)
+        try:
+            node_ptr = torch.empty(p.num_links + 1, dtype=torch.int64, device=self.device)
+            N.check(N.lib().s3grl_plan_export_subgraphs(p._h, _ptr(node_ptr), C.c_void_p(0), C.c_void_p(0)),
+                    "s3grl_plan_export_subgraphs")
+            return node_ptr.diff() == 0
         finally:
             p.close()
 

@@ -1,8 +1,9 @@
 """Multi-GPU: link pairs are independent, so the link list is sharded and nothing else.
 
 One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI).  Graph and X are
-replicated on every rank; each rank runs the engine on a contiguous, cost-balanced range of the
-link list (reference tuned_SIGN.py:147-187: the loop bodies share no state).  The one exchange
+replicated on every rank; each rank runs the engine on its share of the link list — cost-balanced,
+pair-aware (`ShardPlan`: both directions of a pair on one rank) or, on request, contiguous ranges
+(reference tuned_SIGN.py:147-187: the loop bodies share no state).  The one exchange
 step is the reassembly of the result on every rank: padded `all_gather_into_tensor` calls (equal
 sized contributions: a single RCCL all-gather, each rank's slice crossing each xGMI link once)
 followed by a compaction of the padded slices into the reference's order.
@@ -223,7 +224,7 @@ def sop_cost(engine, graph, A, link_index):
     the scalar phase grows with the 1-hop ball (deg src + deg dst), and a reversed duplicate that the
     engine folds into its primary costs its output rows only (it is recognised by the sizing pass of a
     count-only plan, like for PoS)."""
-    folded = engine.link_costs(graph, engine.links(link_index), num_hops=1).cpu().numpy() == 250.0
+    folded = engine.folded_mask(graph, engine.links(link_index)).cpu().numpy()
     return np.where(folded, 8.0, link_cost(A, link_index) + 32.0)
 
 
@@ -402,6 +403,15 @@ def _fixed(compute, li, b, rank, world, cost, group, gather, rpl, chunks, row_sh
     if order is not None:
         order = order.to(device)
     if not gather or (world == 1 and not collective_at_world1):
+        if gather and order is not None:
+            # one rank, whole list, but grouped by a pair-aware plan (the replicated links at its end):
+            # computed in that order — the folds of the plan survive — and put back into the caller's
+            final = _result(("final", rank), (rpl * L,) + row_shape, dtype, device, reuse)
+            tmp = _Buffers.get(("grouped", rank), (rpl * L,) + row_shape, dtype, device)
+            if L:
+                compute(li, tmp)
+                final.view((L, rpl) + row_shape).index_copy_(0, order, tmp.view((L, rpl) + row_shape))
+            return final, row_ptr, (lo, hi)
         rows = _result(("local", rank), (rpl * (hi - lo),) + row_shape, dtype, device, reuse)
         compute(li[:, lo:hi], rows)
         return rows, row_ptr[lo:hi + 1] - rpl * lo, (lo, hi)
@@ -532,9 +542,9 @@ def engine_compute(engine, graph, x, *, mode="pos", num_hops=1, sign_k=3, stats=
         plan = engine.plan(graph, links, mode=mode, num_hops=num_hops, sign_k=sign_k, **kw)
         try:
             plan.run(x, out)
-            if stats is not None:
-                stats["links"] = stats.get("links", 0) + plan.stats["num_links"]
-                stats["folded_links"] = stats.get("folded_links", 0) + plan.stats["folded_links"]
+            if stats is not None:      # counts the host already holds: no wait for the plan's kernels
+                stats["links"] = stats.get("links", 0) + plan.num_links
+                stats["folded_links"] = stats.get("folded_links", 0) + plan.folded_links
         finally:
             plan.close()
 

@@ -29,7 +29,7 @@ def test_exports_every_declared_symbol(lib):
 
 
 def test_abi_version_and_status_strings(lib):
-    assert lib.s3grl_abi_version() == 5
+    assert lib.s3grl_abi_version() == 6
     assert lib.s3grl_status_string(0) == b"ok"
     assert lib.s3grl_status_string(2) == b"not implemented"
 

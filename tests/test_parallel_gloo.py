@@ -279,3 +279,108 @@ def test_shard_plan_with_replicated_links_is_a_permutation_that_keeps_pairs_toge
         for i in np.flatnonzero(rev):
             assert links[0, i] == links[1, i - 1] and links[1, i] == links[0, i - 1] and not rev[i - 1]
             assert i not in sp.bounds and i != sp.rep_start
+
+
+def _rows_sym(p):
+    """rows of (d, s) = rows of (s, d) in swapped order, like the engine's (3 operators, 7 columns)."""
+    p = np.asarray(p)
+    sd = np.stack([p[0] * 1000.0 + p[1], p[1] * 1000.0 + p[0]], 1)
+    return (sd[:, :, None, None] + 0.5 * np.arange(3)[None, None, :, None] +
+            0.25 * np.arange(7)[None, None, None, :]).reshape(-1, 3, 7)
+
+
+def _pair_rich_list(seed, n=120, m=260):
+    rng = np.random.default_rng(seed)
+    li = rng.integers(0, n, size=(2, m))
+    li = li[:, li[0] != li[1]]
+    li = np.concatenate([li, li[::-1, :m // 2], li[:, :10], li[::-1, 5:15]], axis=1)
+    return np.ascontiguousarray(li[:, rng.permutation(li.shape[1])])
+
+
+@pytest.mark.parametrize("replicate", [False, True])
+@pytest.mark.parametrize("gather", [True, False])
+def test_one_rank_with_a_pair_aware_plan_keeps_the_callers_order(replicate, gather):
+    """world_size == 1 without the collective path (what a single-GPU caller of the multi-GPU entry gets):
+    with a pair-aware ShardPlan the list is computed in the plan's grouped order — and must come back in
+    the caller's, the replicated links included (they used to be dropped, the rest came back grouped)."""
+    li = _pair_rich_list(3)
+    L = li.shape[1]
+    cost = np.random.default_rng(0).random(L) + 1.0
+    rep = parallel.replicate_cheapest(li, cost, 0.3) if replicate else None
+    plan = parallel.ShardPlan(li, 1, cost, pair_aware=True, replicate=rep)
+    if replicate:
+        assert plan.rep_start < L
+
+    def compute(piece, out):
+        out.copy_(torch.from_numpy(_rows_sym(piece.numpy() if torch.is_tensor(piece) else piece)))
+
+    if replicate and not gather:
+        with pytest.raises(AssertionError):      # replicated links belong to the gathered flavour
+            parallel.sharded_precompute(compute, li, rank=0, world_size=1, shards=plan, gather=False,
+                                        rows_per_link=2, row_shape=(3, 7), dtype=torch.float64, device="cpu")
+        return
+    rows, ptr, where = parallel.sharded_precompute(compute, li, rank=0, world_size=1, shards=plan, gather=gather,
+                                                   rows_per_link=2, row_shape=(3, 7), dtype=torch.float64,
+                                                   device="cpu")
+    if gather:
+        assert np.array_equal(rows.numpy(), _rows_sym(li))
+        assert np.array_equal(ptr.numpy(), np.arange(0, 2 * L + 1, 2))
+    else:                                        # the local shard: rows in the order of `where`
+        assert np.array_equal(rows.numpy(), _rows_sym(li[:, where.numpy()]))
+    assert sorted(where.tolist()) == list(range(L))
+
+
+def _worker_everything(rank, world, port, chunks, q):
+    """All layers of the exchange together, as bench.py --gpus N runs them: a pair-aware ShardPlan with
+    replicated links, pipelined pieces, reversed duplicates rebuilt from their primaries, operator 0 filled
+    locally.  Bit-equal to the unsharded tensor on every rank."""
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    li = _pair_rich_list(11, n=300, m=900)
+    L = li.shape[1]
+    cost = np.random.default_rng(1).random(L) * 50 + 1
+    full = _rows_sym(li)
+    computed = []
+
+    def compute(piece, out):
+        p = piece.numpy() if torch.is_tensor(piece) else piece
+        computed.append(p.shape[1])
+        out.copy_(torch.from_numpy(_rows_sym(p)))
+
+    def fill0(fl):
+        fl[:, :, 0, :] = torch.from_numpy(full).view(L, 2, 3, 7)[:, :, 0, :]
+
+    ok = True
+    rep = parallel.replicate_cheapest(li, cost, 0.2)
+    for replicate in (None, rep):
+        plan = parallel.ShardPlan(li, world, cost, pair_aware=True, replicate=replicate)
+        for f0, mr in ((None, False), (fill0, True), (None, True), (fill0, False)):
+            for _ in range(2):      # the second step reuses plan, transport tables and buffers
+                rows, ptr, where = parallel.sharded_precompute(
+                    compute, li, rank=rank, world_size=world, shards=plan, rows_per_link=2, chunks=chunks,
+                    row_shape=(3, 7), dtype=torch.float64, device="cpu", mirror_rows=mr, local_operator0=f0,
+                    reuse_buffers=True)
+                ok = ok and np.array_equal(rows.numpy(), full) and int(ptr[-1]) == 2 * L
+        own = plan.bounds[rank + 1] - plan.bounds[rank]
+        ok = ok and len(where) == own + (L - plan.rep_start)
+    q.put((rank, ok, 0, 0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,chunks", [(8, 3)])
+def test_world8_every_exchange_layer_together(world, chunks):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_everything, args=(r, world, port, chunks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert len(res) == world and all(ok for _, ok, _, _ in res)
