@@ -144,6 +144,13 @@ const char* s3grl_last_error(void);
 /* `stream` is a hipStream_t passed as void* (NULL = the legacy default stream). */
 s3grl_status s3grl_context_create(int32_t device, void* stream, s3grl_context** out);
 s3grl_status s3grl_context_destroy(s3grl_context* ctx);
+/* Loads the library's GPU code now instead of at the first launch of each kernel family (HIP loads a code
+ * object lazily: ~16 ms of a process's first s3grl_graph_create and ~7-20 ms of its first plan + run are that,
+ * whatever the size of the graph).  units: bit 0 = what every PoS / PoS Plus call at sign_k 3 or 4 needs, bit 1 =
+ * the link kernels of the other sign_k, bit 2 = SoP and the pooling; ms (host double [16], may be NULL) =
+ * milliseconds per unit.  Optional — nothing depends on it; a host thread can call it while the caller still
+ * loads its dataset (s3grl_amd.tuned_SIGN does at import). */
+s3grl_status s3grl_context_preload(s3grl_context* ctx, uint32_t units, double* ms);
 
 /* CSR of A as scipy holds it (reference sgrl_link_pred.py:111-114): indptr [N+1], indices
  * [nnz] strictly ascending within a row (canonical format: sorted, duplicates summed); the

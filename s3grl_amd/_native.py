@@ -28,7 +28,7 @@ STRATEGY = {"intersection": 0, "union": 1}
 # every symbol include/s3grl.h declares; tests check the library exports all of them
 SYMBOLS = [
     "s3grl_abi_version", "s3grl_status_string", "s3grl_last_error",
-    "s3grl_context_create", "s3grl_context_destroy", "s3grl_context_timings",
+    "s3grl_context_create", "s3grl_context_preload", "s3grl_context_destroy", "s3grl_context_timings",
     "s3grl_context_set_profiling", "s3grl_context_trim", "s3grl_plan_gather_traffic",
     "s3grl_graph_create", "s3grl_graph_create_directed", "s3grl_graph_destroy",
     "s3grl_plan_create", "s3grl_plan_create_sets", "s3grl_walk_sets", "s3grl_plan_destroy", "s3grl_plan_get_stats", "s3grl_plan_total_rows", "s3grl_plan_counts", "s3grl_plan_row_ptr",
@@ -98,6 +98,7 @@ def lib():
     L.s3grl_last_error.restype = C.c_char_p
     proto = {
         "s3grl_context_create": [i32, vp, C.POINTER(vp)],
+        "s3grl_context_preload": [vp, C.c_uint32, C.POINTER(C.c_double)],
         "s3grl_context_destroy": [vp],
         "s3grl_context_timings": [vp, C.POINTER(C.c_double)],
         "s3grl_context_set_profiling": [vp, i32],

@@ -1,5 +1,6 @@
 // extern "C" entry points of libs3grl_hip.so (see include/s3grl.h) and host orchestration.
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -12,8 +13,28 @@ static thread_local std::string g_last_error;
 void set_last_error(const std::string& msg) { g_last_error = msg; }
 
 Arena::~Arena() {
-  for (auto& kv : free_) (void)hipFree(kv.second);
-  for (auto& kv : live_) (void)hipFree(kv.first);
+  for (auto& kv : free_)
+    if (!carved_.count(kv.second)) (void)hipFree(kv.second);
+  for (auto& kv : live_)
+    if (!carved_.count(kv.first)) (void)hipFree(kv.first);
+  for (auto& sl : slabs_)
+    if (sl.base) (void)hipFree(sl.base);
+}
+
+s3grl_status Arena::reserve(size_t bytes) {
+  if (bytes < (1u << 20) || cached_ * 2 >= bytes) return S3GRL_OK;   // small, or the cache will serve most of it
+  if (cur_slab_ >= 0 && slabs_[cur_slab_].size - slabs_[cur_slab_].used >= bytes) return S3GRL_OK;
+  bytes = (bytes + (2u << 20) - 1) / (2u << 20) * (2u << 20);
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) {   // no slab: the allocations go one by one (and report for themselves)
+    (void)hipGetLastError();
+    cur_slab_ = -1;
+    return S3GRL_OK;
+  }
+  held_ += bytes;
+  slabs_.push_back(Slab{static_cast<char*>(p), bytes, 0, 0});
+  cur_slab_ = (int)slabs_.size() - 1;
+  return S3GRL_OK;
 }
 
 s3grl_status Arena::alloc(size_t bytes, void** out) {
@@ -25,18 +46,28 @@ s3grl_status Arena::alloc(size_t bytes, void** out) {
   if (it != free_.end() && it->first <= bytes * 2 + (4u << 20)) {
     *out = it->second;
     live_[it->second] = it->first;
+    cached_ -= it->first;
     free_.erase(it);
     return S3GRL_OK;
+  }
+  if (cur_slab_ >= 0) {   // carve it out of the reserved block
+    Slab& sl = slabs_[cur_slab_];
+    if (sl.size - sl.used >= bytes) {
+      void* p = sl.base + sl.used;
+      sl.used += bytes;
+      sl.blocks += 1;
+      carved_[p] = cur_slab_;
+      live_[p] = bytes;
+      *out = p;
+      return S3GRL_OK;
+    }
   }
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, bytes);
   if (e != hipSuccess) {
     // give cached blocks back and retry once
-    for (auto& kv : free_) {
-      (void)hipFree(kv.second);
-      held_ -= kv.first;
-    }
-    free_.clear();
+    (void)hipGetLastError();
+    trim();
     e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {
       set_last_error("hipMalloc(" + std::to_string(bytes) + "): " + hipGetErrorString(e));
@@ -52,10 +83,24 @@ s3grl_status Arena::alloc(size_t bytes, void** out) {
 size_t Arena::trim() {
   size_t freed = 0;
   for (auto& kv : free_) {
-    (void)hipFree(kv.second);
-    freed += kv.first;
+    auto c = carved_.find(kv.second);
+    if (c == carved_.end()) {
+      (void)hipFree(kv.second);
+      freed += kv.first;
+    } else {   // part of a slab: forgotten; the slab goes when its last block has
+      const int si = c->second;
+      Slab& sl = slabs_[si];
+      carved_.erase(c);
+      if (--sl.blocks == 0 && sl.base) {
+        if (si == cur_slab_) cur_slab_ = -1;
+        (void)hipFree(sl.base);
+        freed += sl.size;
+        sl.base = nullptr;
+      }
+    }
   }
   free_.clear();
+  cached_ = 0;
   held_ -= freed;
   return freed;
 }
@@ -65,6 +110,7 @@ void Arena::release(void* p) {
   auto it = live_.find(p);
   if (it == live_.end()) return;
   free_.emplace(it->second, p);
+  cached_ += it->second;
   live_.erase(it);
 }
 
@@ -225,6 +271,29 @@ s3grl_status s3grl_context_create(int32_t device, void* stream, s3grl_context** 
   return S3GRL_OK;
 }
 
+s3grl_status s3grl_context_preload(s3grl_context* ctx, uint32_t units, double* ms) {
+  if (!ctx) return S3GRL_ERR_INVALID_ARGUMENT;
+  S3GRL_HIP_TRY(hipSetDevice(ctx->device));
+  struct Unit {
+    void (*touch)();
+    uint32_t group;
+  };
+  // group 1: what every PoS / PoS Plus plan at sign_k 3, 4 touches; 2: the other sign_k; 4: SoP and the pooling
+  static const Unit units_all[] = {{touch_api, 1},      {touch_relabel, 1}, {touch_structure, 1}, {touch_balls, 1},
+                                   {touch_features, 1}, {touch_packed, 1},  {touch_gather, 1},    {touch_csr, 1},
+                                   {touch_hub, 1},      {touch_links_a, 2}, {touch_links_b, 2},   {touch_links_c, 2},
+                                   {touch_sop, 4},      {touch_pool, 4}};
+  int k = 0;
+  for (const Unit& u : units_all) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (units & u.group) u.touch();
+    if (ms) ms[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ++k;
+  }
+  (void)hipGetLastError();
+  return S3GRL_OK;
+}
+
 s3grl_status s3grl_context_destroy(s3grl_context* ctx) {
   if (!ctx) return S3GRL_OK;
   (void)hipSetDevice(ctx->device);
@@ -360,6 +429,9 @@ s3grl_status s3grl_graph_create(s3grl_context* ctx, int64_t num_nodes, const int
     return S3GRL_ERR_GRAPH_TOO_LARGE;
   }
   S3GRL_HIP_TRY(hipSetDevice(ctx->device));
+  // everything this call allocates (two copies of the CSR, the permutations, the sort keys and rocPRIM's
+  // temporaries), out of one block when the arena is cold
+  S3GRL_TRY(ctx->arena.reserve((size_t)64 * (size_t)std::max<int64_t>(num_nodes, nnz) + (size_t)96 * num_nodes + (4u << 20)));
   auto* g = new s3grl_graph();
   g->ctx = ctx;
   g->num_nodes = num_nodes;
@@ -574,6 +646,9 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
     return S3GRL_OK;
   }
   S3GRL_TRY(record(ctx, 0));
+  // the per-link arrays of the sizing pass (a cold arena: one block instead of two dozen)
+  S3GRL_TRY(ctx->arena.reserve((size_t)L * (size_t)(160 + 4 * num_class_lists() + 4 * kMaxLevels) +
+                               (size_t)mirror_table_slots(L) * 12 + (2u << 20)));
   S3GRL_TRY(arena_alloc(ctx, (size_t)L * 2, &plan->links, own));
   S3GRL_HIP_TRY(hipMemcpyAsync(plan->links, links, (size_t)L * 16, hipMemcpyDeviceToDevice,
                                ctx->stream));
@@ -781,7 +856,7 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   int32_t class_count_host[48];   // [0..5] bitmap classes, [6] HBM-scratch class, [7] its max need,
                                   // [8..13] hash classes, [14..19] one-hop classes, [20] one-hop
                                   // class with its bit matrix in HBM, [21..25] cached-hub classes, [29..31] maxima,
-                                  // [32..37] induced-CSR classes (see classify_kernel)
+                                  // [32..45] induced-CSR classes (see classify_kernel)
   std::memcpy(class_count_host, hs + 32, sizeof(class_count_host));
   if (getenv("S3GRL_DEBUG")) {
     fprintf(stderr, "[s3grl] L=%lld max_n=%lld classes:", (long long)L, (long long)max_n);
@@ -841,6 +916,9 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
     tot_coef = hs[20];
     coef_off = co;
   }
+  // ids, coefficients, jobs, rows: sizes known now
+  S3GRL_TRY(ctx->arena.reserve((size_t)std::max<int64_t>(tot_n, 1) * 4 + (size_t)std::max<int64_t>(tot_coef, 1) * 8 * K +
+                               (size_t)njobs * (sizeof(Job) + 12 * K + 8) + (size_t)tot_rows * 8 + (16u << 20)));
   S3GRL_TRY(arena_alloc(ctx, (size_t)std::max<int64_t>(tot_n, 1), &plan->c_ids, own));
   S3GRL_TRY(arena_alloc(ctx, (size_t)std::max<int64_t>(tot_coef, 1) * 2 * K, &plan->c_coef, own));
   S3GRL_TRY(arena_alloc(ctx, (size_t)njobs, &plan->jobs, own));
@@ -908,6 +986,11 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
                       "deg %lld  ops<K %lld  last op %lld  tail %lld\n",
               (long long)hs[16], (long long)hs[17], (long long)hs[18], (long long)hs[19],
               (long long)hs[20], (long long)hs[21]);
+      if (csr_plan)
+        fprintf(stderr, "[s3grl] link_csr_kernel phase cycles (same slots): bitmap+ranks+offsets %lld  ids+rows %lld  "
+                        "columns %lld  passes %lld   links %lld, mean LDS %lld B\n",
+                (long long)hs[16], (long long)hs[17], (long long)hs[18], (long long)hs[19], (long long)hs[20],
+                (long long)(hs[21] / std::max<int64_t>(hs[20], 1)));
       if (x_cap)
         fprintf(stderr, "[s3grl] link_hub_kernel phase cycles (same slots): nodes %lld  ids+rows %lld  walk %lld  "
                         "small csr %lld  passes %lld  tail %lld\n",
@@ -1090,3 +1173,5 @@ s3grl_status s3grl_run(s3grl_context* ctx, const s3grl_plan* p, const float* X, 
 }
 
 }  // extern "C"
+
+S3GRL_DEFINE_TOUCH(api)

@@ -255,3 +255,5 @@ s3grl_status launch_count_balls(s3grl_context* ctx, const s3grl_graph* g, const 
 }
 
 }  // namespace s3grl
+
+S3GRL_DEFINE_TOUCH(balls)

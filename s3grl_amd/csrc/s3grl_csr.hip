@@ -35,6 +35,9 @@ namespace s3grl {
 namespace {
 
 constexpr int kCsrCountT = 128;
+#ifndef S3GRL_CSR_COUNT_UN
+#define S3GRL_CSR_COUNT_UN 4   // row groups in flight per lane group of the sizing walk (build-time tuning hook)
+#endif
 
 // ---- sizing: members per row ------------------------------------------------------------------
 __global__ __launch_bounds__(kCsrCountT) void csr_count_kernel(
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(kCsrCountT) void csr_count_kernel(
     e_local += c;
   }
   __syncthreads();
-  walk_rows<T, 4, 2>(
+  walk_rows<T, 4, S3GRL_CSR_COUNT_UN>(
       0, n - walk_from, list, indptr, indices, nullptr,
       [&](RowAcc& a, int v, int u, bool valid) {
         const int mp = v == src ? dst : (v == dst ? src : -1);
@@ -123,12 +126,22 @@ __global__ __launch_bounds__(T) void link_csr_kernel(const CsrLinkArgs a, const 
   // build view of the shared region ...
   uint32_t* vis = reinterpret_cast<uint32_t*>(ubase);
   uint32_t* wpre = vis + W;
-  int32_t* list = reinterpret_cast<int32_t*>(wpre + W);
-  uint16_t* por = reinterpret_cast<uint16_t*>(list + n);   // list position of the member of rank r
+  int32_t* gb = reinterpret_cast<int32_t*>(wpre + W);      // where the global row of list entry t starts ...
+  uint16_t* gdeg = reinterpret_cast<uint16_t*>(gb + n);    // ... and its length (max_degree <= 256 on this path)
+  uint16_t* por = gdeg + ((n + 1) & ~1);                   // list position of the member of rank r
   // ... and the view of the passes
   float2* cur = reinterpret_cast<float2*>(ubase);
   float2* nxs = cur + n;
 
+  // diagnostic only (S3GRL_DEBUG_STAMPS): cycles per phase, summed over workgroups
+  unsigned long long t_prev = a.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+#define S3GRL_CSR_STAMP(idx)                                           \
+  if (a.dbg) {                                                         \
+    __syncthreads();                                                   \
+    const unsigned long long t_now = __builtin_amdgcn_s_memtime();     \
+    if (threadIdx.x == 0) atomicAdd(&a.dbg[idx], t_now - t_prev);      \
+    t_prev = t_now;                                                    \
+  }
   const int src = (int)a.links[2 * (int64_t)l], dst = (int)a.links[2 * (int64_t)l + 1];
   const int pos_src = src < dst ? 0 : 1, pos_dst = 1 - pos_src;
   const int32_t* lv = a.lvl + (int64_t)l * kMaxLevels;   // left by the sizing pass; rewritten below
@@ -139,31 +152,61 @@ __global__ __launch_bounds__(T) void link_csr_kernel(const CsrLinkArgs a, const 
     const uint32_t* __restrict__ bs = a.balls + (int64_t)src * W;
     const uint32_t* __restrict__ bd = a.balls + (int64_t)dst * W;
     for (int w = tid; w < W; w += T) vis[w] = bs[w] | bd[w];
-    const int32_t* __restrict__ st = a.stash + (int64_t)l * a.slot;
-    for (int t = tid; t < n; t += T) list[t] = t < 2 ? (t == 0 ? min(src, dst) : max(src, dst)) : st[t - 2];
   }
   __syncthreads();
-  rank_prefix<T>(vis, wpre, W, sh);
-  // offsets: exclusive scan of the member counts (thread-contiguous runs, one block scan)
+  // ONE block scan for both prefix sums: the popcount prefix of the bitmap (rank of a member: <= n < 2^13) in
+  // the high half, the row offsets (member counts: <= e < 2^16) in the low half — neither carries
   {
-    const int C = (n + T - 1) / T;
-    const int t0 = min(tid * C, n), t1 = min(t0 + C, n);
-    int mine = 0;
-    for (int t = t0; t < t1; ++t) mine += a.cnt[noff + t];
+    const int CW = (W + T - 1) / T, CN = (n + T - 1) / T;
+    const int w0 = min(tid * CW, W), w1 = min(w0 + CW, W);
+    const int t0 = min(tid * CN, n), t1 = min(t0 + CN, n);
+    int pop = 0, cnt = 0;
+    for (int w = w0; w < w1; ++w) pop += __popc(vis[w]);
+    for (int t = t0; t < t1; ++t) cnt += a.cnt[noff + t];
     int total;
-    int run = block_excl_scan<T>(mine, sh, total);
-    for (int t = t0; t < t1; ++t) {
-      off[t] = (uint16_t)run;
-      run += a.cnt[noff + t];
+    const int run = block_excl_scan<T>((pop << 16) | cnt, sh, total);
+    int rp_ = run >> 16, ro = run & 0xffff;
+    for (int w = w0; w < w1; ++w) {
+      wpre[w] = rp_;
+      rp_ += __popc(vis[w]);
     }
-    if (tid == 0) off[n] = (uint16_t)total;
+    for (int t = t0; t < t1; ++t) {
+      off[t] = (uint16_t)ro;
+      ro += a.cnt[noff + t];
+    }
+    if (tid == 0) off[n] = (uint16_t)(total & 0xffff);
   }
+  __syncthreads();
+  S3GRL_CSR_STAMP(0)
   int vol_local = 0;   // vol(S) = Σ global degrees, the 4·vol(S) term of the algorithmic bytes
-  for (int t = tid; t < n; t += T) {
-    const int v = list[t];
-    a.c_ids[noff + t] = ext(v);
-    vol_local += indptr[v + 1] - indptr[v];
-    por[rank_of(vis, wpre, v)] = (uint16_t)t;
+  {
+    const int32_t* __restrict__ st = a.stash + (int64_t)l * a.slot;
+    // four list entries per thread and trip: their ids, then their row bounds, are in flight together (two
+    // dependent global loads per entry; one entry at a time made this loop a seventh of the kernel)
+    for (int t0 = tid; t0 < n; t0 += 4 * T) {
+      int v[4], b[4], en[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int t = min(t0 + k * T, n - 1);
+        v[k] = t < 2 ? (t == 0 ? min(src, dst) : max(src, dst)) : st[t - 2];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        b[k] = indptr[(uint32_t)v[k]];
+        en[k] = indptr[(uint32_t)v[k] + 1u];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int t = t0 + k * T;
+        if (t < n) {
+          a.c_ids[noff + t] = ext(v[k]);
+          vol_local += en[k] - b[k];
+          gb[t] = b[k];
+          gdeg[t] = (uint16_t)(en[k] - b[k]);
+          por[rank_of(vis, wpre, v[k])] = (uint16_t)t;
+        }
+      }
+    }
   }
   const int64_t rp = a.row_ptr[l];
   const int R = (int)(a.row_ptr[l + 1] - rp);
@@ -197,7 +240,9 @@ __global__ __launch_bounds__(T) void link_csr_kernel(const CsrLinkArgs a, const 
   if (tid == 0)
     for (int d = 0; d < kMaxLevels; ++d) a.lvl[(int64_t)l * kMaxLevels + d] = d < nlev ? lvl_end[d] : n;
 
-  // ---- columns: one walk of the global rows, four lanes per row, two rows per lane group in flight ----
+  S3GRL_CSR_STAMP(1)
+  // ---- columns: one walk of the global rows (their bounds are on chip), four lanes per row, two rows per
+  // lane group in flight ----
   // Lane g of a row's group takes the stored neighbours g, g + 4, ...; the members of a step are placed by a
   // ballot over the group's four lanes, so a row's columns keep the ascending order of the global row.
   {
@@ -209,12 +254,11 @@ __global__ __launch_bounds__(T) void link_csr_kernel(const CsrLinkArgs a, const 
       for (int u = 0; u < 2; ++u) {
         const int t = base + u * RPI + tid / G;
         const bool ok = t < n;
-        const int v = list[min(t, n - 1)];
-        const int b = indptr[(uint32_t)v], en = indptr[(uint32_t)v + 1u];
+        const int b = gb[min(t, n - 1)];
         c0[u] = ok ? b + g : 0;
-        e1[u] = ok ? en : 0;
+        e1[u] = ok ? b + (int)gdeg[min(t, n - 1)] : 0;
         wc[u] = off[min(t, n)];
-        mp[u] = v == src ? dst : (v == dst ? src : -1);
+        mp[u] = t == pos_src ? dst : (t == pos_dst ? src : -1);   // the target link is masked (utils.py:79-80)
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) nx[u] = indices[(uint32_t)(c0[u] < e1[u] ? c0[u] : 0)];
@@ -241,6 +285,7 @@ __global__ __launch_bounds__(T) void link_csr_kernel(const CsrLinkArgs a, const 
     }
   }
   __syncthreads();   // the CSR is complete; bitmaps, list and rank map are dead from here on
+  S3GRL_CSR_STAMP(2)
 
   auto dinv_of = [&](int t) -> float {
     const int d = (int)off[t + 1] - (int)off[t];
@@ -346,8 +391,13 @@ __global__ __launch_bounds__(T) void link_csr_kernel(const CsrLinkArgs a, const 
     }
     __syncthreads();
   }
+  S3GRL_CSR_STAMP(3)
   vol_local = block_sum<T>(vol_local, sh);
   if (tid == 0) {
+    if (a.dbg) {
+      atomicAdd(&a.dbg[4], 1ull);
+      atomicAdd(&a.dbg[5], (unsigned long long)(4 * csr_fixed_words(a.cn_cap, K) + csr_lds_need(n, e, W)));
+    }
     atomicAdd(stat_slot(a.tot_edges), (unsigned long long)e * (mirror >= 0 ? 2ull : 1ull));
     atomicAdd(stat_slot(a.tot_vol), (unsigned long long)vol_local * (mirror >= 0 ? 2ull : 1ull));
   }
@@ -356,9 +406,9 @@ __global__ __launch_bounds__(T) void link_csr_kernel(const CsrLinkArgs a, const 
 }  // namespace
 
 int csr_class_bound(int cls, int cn_cap, int K) {
-  static const int nominal[kNumClasses] = S3GRL_CLASS_BOUNDS;
+  static const int nominal[kCsrClasses] = S3GRL_CSR_CLASS_BOUNDS;
   const int avail = 163840 - 4 * csr_fixed_words(cn_cap, K);
-  return cls == kNumClasses - 1 ? avail : std::min(nominal[cls], avail);
+  return cls == kCsrClasses - 1 ? avail : std::min(nominal[cls], avail);
 }
 
 // Plan-level switch: plain relabelled plans with cached balls whose operators all reach the whole
@@ -391,7 +441,7 @@ s3grl_status launch_csr_class(s3grl_context* ctx, const CsrLinkArgs& a, int K, i
                               int count, hipStream_t stream) {
   if (count == 0) return S3GRL_OK;
   const size_t lds = (size_t)4 * csr_fixed_words(a.cn_cap, K) + (size_t)csr_class_bound(cls, a.cn_cap, K);
-  int t = cls == 0 ? 128 : (lds <= 40 * 1024 ? 256 : (lds <= 80 * 1024 ? 512 : 1024));
+  int t = lds <= 10 * 1024 ? 128 : (lds <= 40 * 1024 ? 256 : (lds <= 80 * 1024 ? 512 : 1024));
   {
     char name[32];   // tuning hook
     snprintf(name, sizeof(name), "S3GRL_TC_CLASS%d", cls);
@@ -411,3 +461,5 @@ s3grl_status launch_csr_class(s3grl_context* ctx, const CsrLinkArgs& a, int K, i
 }
 
 }  // namespace s3grl
+
+S3GRL_DEFINE_TOUCH(csr)

@@ -352,3 +352,5 @@ s3grl_status s3grl_features_info(const s3grl_features* f, int64_t* nnz, int32_t*
 }
 
 }  // extern "C"
+
+S3GRL_DEFINE_TOUCH(features)

@@ -232,3 +232,5 @@ s3grl_status launch_gather(s3grl_context* ctx, const GatherView& v, const int32_
 }
 
 }  // namespace s3grl
+
+S3GRL_DEFINE_TOUCH(gather)

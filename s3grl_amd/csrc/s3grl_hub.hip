@@ -1005,3 +1005,5 @@ s3grl_status build_hub_cache(s3grl_context* ctx, s3grl_graph* g) {
 }
 
 }  // namespace s3grl
+
+S3GRL_DEFINE_TOUCH(hub)

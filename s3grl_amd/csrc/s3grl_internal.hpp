@@ -122,11 +122,26 @@ class Arena {
   void release(void* p);
   size_t trim();   // hipFree every cached (not live) block; returns the bytes given back
   size_t bytes_held() const { return held_; }
+  // A cold arena pays one hipMalloc per block, and a hipMalloc of a megabyte or more costs 0.3-3 ms (a
+  // process's first s3grl_graph_create on PubMed: a dozen of them, 4 of its 4.4 ms; its first plan: thirty).
+  // reserve(bytes): when the cached blocks could not serve about that much, ONE block of that size is
+  // allocated and the allocations that follow are carved out of it.  Carved blocks are cached and reused
+  // like any other; their slab goes back to HIP when none of them is live or cached any more (trim).
+  s3grl_status reserve(size_t bytes);
+  size_t cached_bytes() const { return cached_; }
 
  private:
+  struct Slab {
+    char* base;
+    size_t size, used;
+    int blocks;   // carved blocks still live or cached
+  };
   std::multimap<size_t, void*> free_;
   std::map<void*, size_t> live_;
-  size_t held_ = 0;
+  std::map<void*, int> carved_;   // block -> slab
+  std::vector<Slab> slabs_;
+  int cur_slab_ = -1;
+  size_t held_ = 0, cached_ = 0;
 };
 
 }  // namespace s3grl
@@ -302,10 +317,42 @@ struct s3grl_sop {
   const float* mult = nullptr;  // [nnz] multiplicity of the stored entries (null: 1), see s3grl_sop_create_weighted
   double* dinv = nullptr; // [N] global D^-1/2
   double* Y = nullptr;    // [K+1, N, ldy] f64; Y[0] = X, Y[i] = Â Y[i-1]
+  float* Yhi = nullptr;   // [K+1, N, ldy] the same rounded to f32 — what the per-link row kernel reads
+  float* Ylo = nullptr;   // [K, N, ldy] Y[i] - Yhi[i] rounded to f32, i = 1..K (read where a row cancels)
   std::vector<void*> owned;
 };
 
+// Code-object preload (s3grl_context_preload): HIP loads a translation unit's code object at the first launch
+// of one of its kernels — 16 of the 17 ms of a process's first s3grl_graph_create.  Every unit defines an
+// empty kernel and a function that asks for its attributes, which loads the unit's code object on the spot.
+#define S3GRL_DEFINE_TOUCH_(unit)                                                              \
+  namespace s3grl {                                                                            \
+  namespace {                                                                                  \
+  __global__ void touch_kernel_##unit() {}                                                     \
+  }                                                                                            \
+  void touch_##unit() {                                                                        \
+    hipFuncAttributes at;                                                                      \
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(touch_kernel_##unit));       \
+  }                                                                                            \
+  }
+#define S3GRL_DEFINE_TOUCH(unit) S3GRL_DEFINE_TOUCH_(unit)
+
 namespace s3grl {
+
+void touch_api();
+void touch_structure();
+void touch_links_a();
+void touch_links_b();
+void touch_links_c();
+void touch_gather();
+void touch_packed();
+void touch_features();
+void touch_sop();
+void touch_pool();
+void touch_relabel();
+void touch_hub();
+void touch_balls();
+void touch_csr();
 
 struct Transient {  // released on scope exit (stream-ordered reuse is safe: one stream per context)
   s3grl_context* ctx;
@@ -384,14 +431,21 @@ s3grl_status launch_sort_hops(s3grl_context* ctx, const s3grl_plan* p, int32_t* 
 // global rows through the bitmaps once per operator (link_kernel: three full walks at PubMed sign_k = 5).
 // LDS of a link beyond the fixed part: row offsets (uint16 [n + 1]), columns (uint16 [e]) and a region
 // that holds the build's bitmaps / list / rank map first and the two float2 state arrays afterwards.
-constexpr int kCsrBase = 32;             // class lists kCsrBase .. kCsrBase + kNumClasses - 1 (class_count idx alike)
+constexpr int kCsrBase = 32;             // class lists kCsrBase .. kCsrBase + kCsrClasses - 1 (class_count idx alike)
+// A link holds the LDS of its CLASS, and the kernel's speed follows the links in flight (measured: +35 % LDS
+// per link = +0.8 ms on PubMed sign_k = 5): finer classes than the six of link_kernel
+constexpr int kCsrClasses = 14;
+#define S3GRL_CSR_CLASS_BOUNDS {4096, 6144, 8192, 12288, 16384, 20480, 24576, 32768, 40960, 49152, 65536, 98304, 131072, 163840}
+struct CsrBounds {
+  int b[kCsrClasses];
+};
 constexpr int kCsrDinvTable = 256;       // D^-1/2 of degrees below this from an LDS table
 __host__ __device__ inline int csr_fixed_words(int cn_cap, int K) {
   return 2 * cn_cap + kMaxLevels + 4 * K + 32 + kCsrDinvTable;
 }
 __host__ __device__ inline int csr_lds_need(int n, int e, int W) {
   const int off_b = 2 * ((n + 2) & ~1), col_b = 2 * ((e + 1) & ~1);
-  const int build = 8 * W + 4 * n + 2 * ((n + 2) & ~1), pass = 16 * n;
+  const int build = 8 * W + 4 * n + 4 * ((n + 2) & ~1), pass = 16 * n;
   return ((off_b + col_b + 7) & ~7) + (build > pass ? build : pass) + 8;
 }
 struct CsrLinkArgs {
@@ -418,7 +472,7 @@ struct CsrLinkArgs {
   int split_t, seg_shift;
   unsigned long long* dbg;
 };
-int csr_class_bound(int cls, int cn_cap, int K);   // LDS bytes beyond the fixed part of class 0..kNumClasses-1
+int csr_class_bound(int cls, int cn_cap, int K);   // LDS bytes beyond the fixed part of class 0..kCsrClasses-1
 bool csr_mode_for(const s3grl_graph* g, int hops, int K, bool balls, bool plain);
 s3grl_status launch_csr_count(s3grl_context* ctx, const s3grl_graph* g_walk, const int64_t* links, int64_t L, int hops,
                               const int32_t* n_nodes, const int64_t* node_off, const int32_t* lvl,

@@ -683,3 +683,5 @@ s3grl_status launch_gather_packed(s3grl_context* ctx, const s3grl_plan* p, const
 }
 
 }  // namespace s3grl
+
+S3GRL_DEFINE_TOUCH(packed)

@@ -121,3 +121,5 @@ s3grl_status s3grl_centre_pool_backward(s3grl_context* ctx, const float* h, cons
 }
 
 }  // extern "C"
+
+S3GRL_DEFINE_TOUCH(pool)

@@ -384,3 +384,5 @@ s3grl_status launch_sort_hops(s3grl_context* ctx, const s3grl_plan* p, int32_t* 
 }
 
 }  // namespace s3grl
+
+S3GRL_DEFINE_TOUCH(relabel)

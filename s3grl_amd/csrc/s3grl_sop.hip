@@ -27,12 +27,14 @@ namespace s3grl {
 namespace {
 
 __global__ void to_f64_pad_kernel(const float* __restrict__ X, int64_t ldx, int64_t N, int64_t F,
-                                  double* __restrict__ Y, int64_t ldy) {
+                                  double* __restrict__ Y, float* __restrict__ Yhi, int64_t ldy) {
   const int64_t total = N * ldy;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / ldy, c = i - r * ldy;
-    Y[i] = c < F ? (double)X[r * ldx + c] : 0.0;
+    const float x = c < F ? X[r * ldx + c] : 0.0f;
+    Y[i] = (double)x;
+    Yhi[i] = x;      // plane 0 of the f32 table the row kernel reads: X itself, exact
   }
 }
 
@@ -63,6 +65,7 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void spmm_norm_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
     const double* __restrict__ dinv, const double* __restrict__ Yin, double* __restrict__ Yout,
+    float* __restrict__ Hout, float* __restrict__ Lout,
     int64_t N, int64_t ldy, int tiles, const float* __restrict__ mult) {
   const int lane = threadIdx.x & 63;
   const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -97,8 +100,23 @@ __global__ __launch_bounds__(256) void spmm_norm_kernel(
   }
   const double dv = dinv[v];
   double* __restrict__ yo = Yout + v * ldy;
-  if (oka) *reinterpret_cast<double2_t*>(yo + ca) = dv * acc_a;
-  if (okb) *reinterpret_cast<double2_t*>(yo + cb) = dv * acc_b;
+  // ... and the same values as an f32 pair hi + lo (hi = the value rounded to f32, lo = what the rounding
+  // dropped, rounded to f32: together 48 bits of the f64 value) — what the per-link row kernel reads
+  auto split_store = [&](int64_t c, const double2_t y) {
+    const float hx = (float)y.x, hy = (float)y.y;
+    *reinterpret_cast<float2*>(Hout + v * ldy + c) = make_float2(hx, hy);
+    *reinterpret_cast<float2*>(Lout + v * ldy + c) = make_float2((float)(y.x - (double)hx), (float)(y.y - (double)hy));
+  };
+  if (oka) {
+    const double2_t y = dv * acc_a;
+    *reinterpret_cast<double2_t*>(yo + ca) = y;
+    split_store(ca, y);
+  }
+  if (okb) {
+    const double2_t y = dv * acc_b;
+    *reinterpret_cast<double2_t*>(yo + cb) = y;
+    split_store(cb, y);
+  }
 }
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
@@ -244,12 +262,24 @@ __global__ void sop_order_keys_kernel(const int64_t* __restrict__ links, int64_t
   vals[l] = (int32_t)l;
 }
 
+// The table is read as F32: plane i of `Yhi` holds Y_i rounded to f32 (plane 0 = X, exact), `Ylo` what the
+// rounding dropped (planes 1..K).  x_i[s] = Y_i[s] - Â^i[s,d]·X[d] is formed in f64 from the f32 value and
+// the f64 scalar: its error is the table's rounding, 2^-24·|Y_i[s,c]| — harmless unless the subtraction
+// removes most of the row (a leaf s hanging off d: the reference's masked row is EXACTLY zero there).  So
+// every (operator, endpoint) row keeps the largest |Y| and the largest |result| it met; where the result's
+// norm is below a quarter of Y's (then the rounding could reach 2.4e-7 of it) the row is formed again from
+// hi + lo — 48 bits, f64 for this purpose: an exact zero of the reference comes out below 1e-14.  The
+// decision is uniform over the wavefront and depends on the link alone.  Half the bytes of the f64 table
+// per read; the second pass touches a few per cent of the rows (links with a degree-1 endpoint).
+#ifndef S3GRL_SOP_ROWS_UNROLL
+#define S3GRL_SOP_ROWS_UNROLL 3   // column trips in flight per wavefront (build-time tuning hook)
+#endif
 template <int KT>
 __global__ __launch_bounds__(256) void sop_rows_kernel(
     const int64_t* __restrict__ links, const int32_t* __restrict__ order,
     const int32_t* __restrict__ partner, const int32_t* __restrict__ mirror_of, int64_t L,
-    const double* __restrict__ Y, int64_t N,
-    int64_t ldy, int F, int K, const double* __restrict__ scal, float* __restrict__ rows) {
+    const float* __restrict__ Yhi, const float* __restrict__ Ylo, int64_t N,
+    int64_t ldh, int F, int K, const double* __restrict__ scal, float* __restrict__ rows) {
   const int lane = threadIdx.x & 63;
   const int64_t pos = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pos >= L) return;
@@ -259,44 +289,96 @@ __global__ __launch_bounds__(256) void sop_rows_kernel(
   if (partner && partner[l] >= 0) return;
   const int64_t m = mirror_of ? (int64_t)mirror_of[l] : -1;
   const int KK = KT > 0 ? KT : K;
+  constexpr int KA = KT > 0 ? KT : kMaxSignK;
   const int64_t s = links[2 * l], d = links[2 * l + 1];
   const int Fp = F + 1;
   float* __restrict__ out_s = rows + (2 * l) * (int64_t)(KK + 1) * Fp;
   float* __restrict__ out_d = out_s + (int64_t)(KK + 1) * Fp;
   float* __restrict__ mir_s = m >= 0 ? rows + (2 * m) * (int64_t)(KK + 1) * Fp : nullptr;   // = our dst row
   float* __restrict__ mir_d = m >= 0 ? mir_s + (int64_t)(KK + 1) * Fp : nullptr;            // = our src row
-  const double* __restrict__ x_s = Y + s * ldy;
-  const double* __restrict__ x_d = Y + d * ldy;
-  const int64_t plane = N * ldy;
-  double sd[kMaxSignK];
+  const float* __restrict__ h_s = Yhi + s * ldh;
+  const float* __restrict__ h_d = Yhi + d * ldh;
+  const int64_t plane = N * ldh;
+  double sd[KA];
+  float ymax_s[KA], ymax_d[KA], rmax_s[KA], rmax_d[KA];
 #pragma unroll
-  for (int i = 0; i < (KT > 0 ? KT : kMaxSignK); ++i) sd[i] = i < KK ? scal[(l * KK + i) * 3 + 0] : 0.0;
-  for (int c = lane; c < F; c += 64) {
-    const double xs = x_s[c], xd = x_d[c];
-    double ys[KT > 0 ? KT : kMaxSignK], yd[KT > 0 ? KT : kMaxSignK];
+  for (int i = 0; i < KA; ++i) {
+    sd[i] = i < KK ? scal[(l * KK + i) * 3 + 0] : 0.0;
+    ymax_s[i] = ymax_d[i] = rmax_s[i] = rmax_d[i] = 0.f;
+  }
+  // UNR column trips per iteration: all their 2(K+1) row loads are issued before the first result is stored
+  // (columns past F read column 0 and are not stored)
+  constexpr int UNR = S3GRL_SOP_ROWS_UNROLL;
+  for (int c0 = lane; c0 < F; c0 += 64 * UNR) {
+    float xs[UNR], xd[UNR], ys[UNR][KA], yd[UNR][KA];
 #pragma unroll
-    for (int i = 0; i < (KT > 0 ? KT : kMaxSignK); ++i) {
-      if (i < KK) {
-        ys[i] = x_s[(int64_t)(i + 1) * plane + c];
-        yd[i] = x_d[(int64_t)(i + 1) * plane + c];
+    for (int u = 0; u < UNR; ++u) {
+      const int c = c0 + 64 * u < F ? c0 + 64 * u : 0;
+      xs[u] = h_s[c];
+      xd[u] = h_d[c];
+#pragma unroll
+      for (int i = 0; i < KA; ++i) {
+        if (i < KK) {
+          ys[u][i] = h_s[(int64_t)(i + 1) * plane + c];
+          yd[u][i] = h_d[(int64_t)(i + 1) * plane + c];
+        }
       }
     }
-    out_s[1 + c] = (float)xs;   // operator 0: x = [[1|X[s]],[1|X[d]]]  (tuned_SIGN.py:119-125)
-    out_d[1 + c] = (float)xd;
-    if (m >= 0) {
-      mir_s[1 + c] = (float)xd;
-      mir_d[1 + c] = (float)xs;
-    }
 #pragma unroll
-    for (int i = 0; i < (KT > 0 ? KT : kMaxSignK); ++i) {
-      if (i < KK) {
-        const float vs = (float)(ys[i] - sd[i] * xd), vd = (float)(yd[i] - sd[i] * xs);
-        out_s[(int64_t)(i + 1) * Fp + 1 + c] = vs;
-        out_d[(int64_t)(i + 1) * Fp + 1 + c] = vd;
-        if (m >= 0) {
-          mir_s[(int64_t)(i + 1) * Fp + 1 + c] = vd;
-          mir_d[(int64_t)(i + 1) * Fp + 1 + c] = vs;
+    for (int u = 0; u < UNR; ++u) {
+      const int c = c0 + 64 * u;
+      if (c >= F) break;
+      out_s[1 + c] = xs[u];   // operator 0: x = [[1|X[s]],[1|X[d]]]  (tuned_SIGN.py:119-125)
+      out_d[1 + c] = xd[u];
+      if (m >= 0) {
+        mir_s[1 + c] = xd[u];
+        mir_d[1 + c] = xs[u];
+      }
+#pragma unroll
+      for (int i = 0; i < KA; ++i) {
+        if (i < KK) {
+          const float vs = (float)((double)ys[u][i] - sd[i] * (double)xd[u]),
+                      vd = (float)((double)yd[u][i] - sd[i] * (double)xs[u]);
+          ymax_s[i] = fmaxf(ymax_s[i], fabsf(ys[u][i]));
+          ymax_d[i] = fmaxf(ymax_d[i], fabsf(yd[u][i]));
+          rmax_s[i] = fmaxf(rmax_s[i], fabsf(vs));
+          rmax_d[i] = fmaxf(rmax_d[i], fabsf(vd));
+          out_s[(int64_t)(i + 1) * Fp + 1 + c] = vs;
+          out_d[(int64_t)(i + 1) * Fp + 1 + c] = vd;
+          if (m >= 0) {
+            mir_s[(int64_t)(i + 1) * Fp + 1 + c] = vd;
+            mir_d[(int64_t)(i + 1) * Fp + 1 + c] = vs;
+          }
         }
+      }
+    }
+  }
+  // rows that lost most of their norm in the subtraction: once more, from hi + lo
+#pragma unroll
+  for (int i = 0; i < KA; ++i) {
+    if (i >= KK) continue;
+    float a = ymax_s[i], b = rmax_s[i], e = ymax_d[i], f = rmax_d[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      a = fmaxf(a, __shfl_xor(a, o));
+      b = fmaxf(b, __shfl_xor(b, o));
+      e = fmaxf(e, __shfl_xor(e, o));
+      f = fmaxf(f, __shfl_xor(f, o));
+    }
+    const bool again_s = b < 0.25f * a, again_d = f < 0.25f * e;   // uniform over the wavefront
+    if (!(again_s || again_d)) continue;
+    const float* __restrict__ l_s = Ylo + ((int64_t)i * N + s) * ldh;
+    const float* __restrict__ l_d = Ylo + ((int64_t)i * N + d) * ldh;
+    for (int c = lane; c < F; c += 64) {
+      if (again_s) {
+        const float v = (float)(((double)h_s[(int64_t)(i + 1) * plane + c] + (double)l_s[c]) - sd[i] * (double)h_d[c]);
+        out_s[(int64_t)(i + 1) * Fp + 1 + c] = v;
+        if (m >= 0) mir_d[(int64_t)(i + 1) * Fp + 1 + c] = v;
+      }
+      if (again_d) {
+        const float v = (float)(((double)h_d[(int64_t)(i + 1) * plane + c] + (double)l_d[c]) - sd[i] * (double)h_s[c]);
+        out_d[(int64_t)(i + 1) * Fp + 1 + c] = v;
+        if (m >= 0) mir_s[(int64_t)(i + 1) * Fp + 1 + c] = v;
       }
     }
   }
@@ -426,18 +508,25 @@ s3grl_status s3grl_sop_create_weighted(s3grl_context* ctx, const s3grl_graph* g,
   S3GRL_TRY(ctx->arena.alloc((size_t)(K + 1) * N * s->ldy * 8, &p));
   s->owned.push_back(p);
   s->Y = static_cast<double*>(p);
+  S3GRL_TRY(ctx->arena.alloc((size_t)(K + 1) * N * s->ldy * 4, &p));   // the same table as f32 (plane 0 = X) ...
+  s->owned.push_back(p);
+  s->Yhi = static_cast<float*>(p);
+  S3GRL_TRY(ctx->arena.alloc((size_t)K * N * s->ldy * 4, &p));         // ... and what the rounding dropped, planes 1..K
+  s->owned.push_back(p);
+  s->Ylo = static_cast<float*>(p);
   if (ctx->profiling) S3GRL_HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
   hipLaunchKernelGGL(global_dinv_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream,
                      g->indptr, s->mult, N, s->dinv);
   const int64_t total = N * s->ldy;
   hipLaunchKernelGGL(to_f64_pad_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 8192)),
-                     dim3(256), 0, ctx->stream, X, ldx, N, F, s->Y, s->ldy);
+                     dim3(256), 0, ctx->stream, X, ldx, N, F, s->Y, s->Yhi, s->ldy);
   const int spmm_tiles = (int)((s->ldy + 255) / 256);
   if (ctx->profiling) S3GRL_HIP_TRY(hipEventRecord(ctx->ev[5], ctx->stream));
   for (int i = 1; i <= K; ++i)
     hipLaunchKernelGGL(spmm_norm_kernel, dim3((unsigned)((N * spmm_tiles + 3) / 4)), dim3(256), 0, ctx->stream,
                        g->indptr, g->indices, s->dinv, s->Y + (int64_t)(i - 1) * N * s->ldy,
-                       s->Y + (int64_t)i * N * s->ldy, N, s->ldy, spmm_tiles, s->mult);
+                       s->Y + (int64_t)i * N * s->ldy, s->Yhi + (int64_t)i * N * s->ldy,
+                       s->Ylo + (int64_t)(i - 1) * N * s->ldy, N, s->ldy, spmm_tiles, s->mult);
   S3GRL_HIP_TRY(hipGetLastError());
   if (ctx->profiling) {
     S3GRL_HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
@@ -490,6 +579,8 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
   int64_t *node_off, *scan_ws;
   double* scal;
   void* q;
+  // (a cold arena: the per-link arrays below out of one block)
+  S3GRL_TRY(ctx->arena.reserve((size_t)L * (size_t)(128 + 24 * K) + (size_t)mirror_table_slots(L) * 12 + (8u << 20)));
   S3GRL_TRY(alloc((size_t)L * 4, &q)); n_nodes = (int32_t*)q;
   S3GRL_TRY(alloc((size_t)L * 4, &q)); p_nodes = (int32_t*)q;
   S3GRL_TRY(alloc((size_t)L * 4, &q)); n_rows = (int32_t*)q;
@@ -604,7 +695,7 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
     const dim3 grid((unsigned)((L + 3) / 4)), block(256);
 #define S3GRL_ROWS(KT)                                                                            \
   hipLaunchKernelGGL(sop_rows_kernel<KT>, grid, block, 0, ctx->stream, links, order, partner, mirror_of, L, \
-                     s->Y, g->num_nodes, \
+                     s->Yhi, s->Ylo, g->num_nodes, \
                      s->ldy, (int)s->F, K, scal, rows)
     switch (K) {   // the common sign_k get their loops unrolled (2K + 2 loads in registers)
       case 1: S3GRL_ROWS(1); break;
@@ -631,3 +722,5 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
 }
 
 }  // extern "C"
+
+S3GRL_DEFINE_TOUCH(sop)

@@ -698,7 +698,7 @@ constexpr int kHubBase = kFullBig + 1;
 constexpr int kNumLists = kHubBase + kHubClasses + 1;   // (+ the class with its found edges in HBM slices)
 static_assert(kNumLists <= 29, "class_count[29..31] carry maxima");
 // kCsrBase.. (s3grl_internal.hpp) = full-reach links on their induced LDS CSR, link_csr_kernel (s3grl_csr.hip)
-constexpr int kNumListsAll = kCsrBase + kNumClasses;
+constexpr int kNumListsAll = kCsrBase + kCsrClasses;
 
 __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
                                 const int32_t* __restrict__ p_nodes,
@@ -707,7 +707,8 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
                                 ClassBounds fbound, int bm_limit, int dm_max_n, int dm_class_mask,
                                 int32_t* __restrict__ class_count, int32_t* __restrict__ class_list,
                                 const int32_t* __restrict__ perm, const int64_t* __restrict__ x_cap,
-                                ClassBounds hbound, const int32_t* __restrict__ csr_e, ClassBounds cbound, int W) {
+                                ClassBounds hbound, const int32_t* __restrict__ csr_e, CsrBounds cbound, int W,
+                                int csr_pct) {
   const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   // (perm: the class lists come out in the plan's processing order, up to the order of the atomics)
   const int64_t l = li < L ? (perm ? (int64_t)perm[li] : li) : L;
@@ -721,11 +722,11 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
   // every operator reaches all of S and the sizing kernel of the induced-CSR flavour counted the link's
   // entries (s3grl_csr.hip): link_csr_kernel, by its exact LDS need
   if (csr_e && n > 0 && p == n && csr_e[l] >= 0) {
-    const int need_c = csr_lds_need(n, csr_e[l], W);
-    if (need_c <= cbound.b[kNumClasses - 1]) {
+    const int need_c = (int)((int64_t)csr_lds_need(n, csr_e[l], W) * csr_pct / 100);   // (csr_pct: measurement hook)
+    if (need_c <= cbound.b[kCsrClasses - 1]) {
       sparse = true;
 #pragma unroll
-      for (int k = 0; k < kNumClasses; ++k) c += need_c > cbound.b[k] ? 1 : 0;
+      for (int k = 0; k < kCsrClasses; ++k) c += need_c > cbound.b[k] ? 1 : 0;
       c += kCsrBase;
     }
   }
@@ -1959,15 +1960,16 @@ s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_ca
   static_assert(kHubClasses < kNumClasses, "one more entry for the test hook");
   for (int c = 0; c < kHubClasses; ++c) hb.b[c] = hub_class_bound(c, cn_cap, K);
   hb.b[kHubClasses] = getenv("S3GRL_FORCE_HUB_SLICES") ? 1 : 0;   // test hook: found edges in HBM slices
-  ClassBounds csrb{};
-  for (int c = 0; c < kNumClasses; ++c) csrb.b[c] = csr_class_bound(c, cn_cap, K);
+  CsrBounds csrb{};
+  for (int c = 0; c < kCsrClasses; ++c) csrb.b[c] = csr_class_bound(c, cn_cap, K);
   hipLaunchKernelGGL(classify_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream,
                      n_nodes, p_nodes, lvl_max, L, cb, dm ? 2 : ((allow_hash && sparse_mode_for(g)) ? 1 : 0),
                      dm ? class_bounds_dm(g->num_nodes, cn_cap, K) : class_bounds_sparse(cn_cap, K), e_cap,
                      class_bounds_full(cn_cap, K),
                      getenv("S3GRL_FORCE_BM_HBM") ? 0 : (1 << 30),   // test hook: bit matrices in HBM
                      dm ? std::min(stash_slot + 2, 65535) : 0, dm ? dm_class_mask_for(g, cn_cap, K) : 0,
-                     class_count, class_list, perm, x_cap, hb, csr_e, csrb, words_for(g->num_nodes));
+                     class_count, class_list, perm, x_cap, hb, csr_e, csrb, words_for(g->num_nodes),
+                     getenv("S3GRL_CSR_LDS_PCT") ? std::max(100, atoi(getenv("S3GRL_CSR_LDS_PCT"))) : 100);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -2360,3 +2362,8 @@ s3grl_status launch_dists(s3grl_context* ctx, const int64_t* node_off, const int
 #endif  // S3GRL_LINKS_PART
 
 }  // namespace s3grl
+
+#ifndef S3GRL_TOUCH_UNIT
+#define S3GRL_TOUCH_UNIT structure
+#endif
+S3GRL_DEFINE_TOUCH(S3GRL_TOUCH_UNIT)

@@ -11,6 +11,7 @@ computation goes through libs3grl_hip.so.  Nothing here computes on the CPU.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 from dataclasses import dataclass, field
 
@@ -268,7 +269,9 @@ class Sop:
 class Engine:
     """One context = one device + one stream + one workspace arena."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, preload=None):
+        """preload: which code objects to load at once (Engine.PRELOAD_* bits; default: the PoS / PoS Plus set,
+        S3GRL_NO_PRELOAD=1 or 0 = none: everything loads at first use)."""
         if not torch.cuda.is_available():
             raise RuntimeError("s3grl_amd needs a HIP device (MI355X); there is no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
@@ -280,6 +283,24 @@ class Engine:
                 "s3grl_context_create")
         self._ctx = h
         self._children = weakref.WeakSet()
+        self.preload_ms = None
+        if preload is None:
+            preload = 0 if os.environ.get("S3GRL_NO_PRELOAD") else self.PRELOAD_POS
+        if preload:
+            self.preload(preload)
+
+    PRELOAD_POS, PRELOAD_OTHER_K, PRELOAD_SOP = 1, 2, 4
+    _UNITS = ["api", "relabel", "structure", "balls", "features", "packed", "gather", "csr", "hub", "links_a",
+              "links_b", "links_c", "sop", "pool"]
+
+    def preload(self, units=1):
+        """Load the library's GPU code now (s3grl_context_preload): HIP loads a code object at the first launch
+        of one of its kernels, which is most of a process's first Graph() and first plan (16 + 7 ms on USAir,
+        whatever the graph).  Returns the milliseconds per unit."""
+        ms = (C.c_double * 16)()
+        N.check(N.lib().s3grl_context_preload(self._ctx, int(units), ms), "s3grl_context_preload")
+        self.preload_ms = {u: float(ms[i]) for i, u in enumerate(self._UNITS) if ms[i] > 0.005}
+        return self.preload_ms
 
     # ---- inputs ---------------------------------------------------------------------------
     def graph(self, A=None, *, indptr=None, indices=None, num_nodes=None, directed=False, A_csc=None):
@@ -513,13 +534,17 @@ class Engine:
 
 
 _default = {}
+_default_lock = __import__("threading").Lock()
 
 
-def default_engine(device=None):
-    key = str(device) if device is not None else "cur%d" % torch.cuda.current_device()
-    if key not in _default:
-        _default[key] = Engine(device)
-    return _default[key]
+def default_engine(device=None, preload=None):
+    """The process-wide engine of a device (created on first use; a warm-up thread and the caller may ask for
+    it at the same time)."""
+    with _default_lock:
+        key = str(device) if device is not None else "cur%d" % torch.cuda.current_device()
+        if key not in _default:
+            _default[key] = Engine(device, preload=preload)
+        return _default[key]
 
 
 def precompute(indptr, indices, X, links, *, mode="pos", num_hops=1, sign_k=3,

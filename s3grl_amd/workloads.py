@@ -25,6 +25,19 @@ def load_topology(name):
     return n, e
 
 
+def load_features(name):
+    """The public node features of a dataset as a dense fp32 matrix, NOT yet normalised
+    (s3grl_amd/data/feat_<name>.npz: the CSR structure of the non-zeros, see tools/make_features.py;
+    an empty `data` array means every stored value is 1 — Cora's binary bag of words)."""
+    t = np.load(DATA / f"feat_{name}.npz")
+    n, f = (int(v) for v in t["shape"])
+    indptr, indices = t["indptr"].astype(np.int64), t["indices"].astype(np.int64)
+    data = t["data"] if t["data"].size else np.ones(len(indices), dtype=np.float32)
+    X = np.zeros((n, f), dtype=np.float32)
+    X[np.repeat(np.arange(n), np.diff(indptr)), indices] = data
+    return X
+
+
 def chung_lu(n, m, gamma=2.5, d_max=700, seed=3):
     """Power-law expected-degree graph (BASELINE config 5), self-loops / multi-edges removed."""
     rng = np.random.default_rng(seed)
@@ -252,6 +265,10 @@ def make(name):
         rng = np.random.default_rng(1)
         X = (rng.random((n, 1433)) < 0.0127).astype(np.float32)
         return Workload(name, edge_split(n, e, seed=1), row_normalize(X), "pos_plus", 3, 3)
+    if name == "cora_posplus_k3_real":   # config 2 on Cora's own bag-of-words rows (paper entry
+        # configs/paper/auc_s3grl.json:259; Planetoid NormalizeFeatures, sgrl_link_pred.py:851)
+        n, e = load_topology("cora")
+        return Workload(name, edge_split(n, e, seed=1), normalize_features(load_features("cora")), "pos_plus", 3, 3)
     if name == "usair_pos_k2":       # config 1
         n, e = load_topology("usair")
         X = np.random.default_rng(0).standard_normal((n, 16)).astype(np.float32)

@@ -93,7 +93,7 @@ def test_csr_flavour_equals_the_walking_flavours(eng, monkeypatch, name, hops, K
 
 def test_csr_flavour_is_taken(eng, monkeypatch):
     """The hook really switches flavours (a silently ignored switch would make the test above vacuous):
-    with S3GRL_DEBUG the plan prints its class counts; the induced-CSR classes are lists 32..37."""
+    with S3GRL_DEBUG the plan prints its class counts; the induced-CSR classes are lists 32..45."""
     import ctypes
     import io
     import os
@@ -127,8 +127,8 @@ def test_csr_flavour_is_taken(eng, monkeypatch):
     monkeypatch.delenv("S3GRL_DEBUG", raising=False)
     monkeypatch.delenv("S3GRL_FORCE_CSR", raising=False)
     off, on = counts
-    assert sum(off[32:38]) == 0
-    assert sum(on[32:38]) == len(g["links"]) and sum(on[:26]) == 0
+    assert sum(off[32:46]) == 0
+    assert sum(on[32:46]) == len(g["links"]) and sum(on[:26]) == 0
     G.close()
 
 
