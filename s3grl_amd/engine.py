@@ -339,7 +339,10 @@ class Engine:
 
     def features(self, x, mode="auto"):
         """Upload x (fp32 [N,F]) and prepare it for the gather; see `Features`."""
-        x = torch.as_tensor(x).to(device=self.device, dtype=torch.float32).contiguous()
+        x = torch.as_tensor(x)
+        if not x.is_cuda:       # converted on the host: the upload is a plain copy
+            x = x.to(dtype=torch.float32).contiguous()
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
         return Features(self, x, mode)
 
     def links(self, link_index):
@@ -348,6 +351,8 @@ class Engine:
         li = torch.as_tensor(link_index)
         if li.dim() != 2 or li.shape[0] != 2:
             raise ValueError("link_index must be [2, L]")
+        if not li.is_cuda:      # transposed on the host: the upload is then a plain copy (no strided-copy kernel,
+            return li.t().to(dtype=torch.int64).contiguous().to(self.device)   # whose first use costs ~60 ms)
         return li.t().to(device=self.device, dtype=torch.int64).contiguous()
 
     def link_pairs(self, pairs):
@@ -355,6 +360,8 @@ class Engine:
         li = torch.as_tensor(pairs)
         if li.dim() != 2 or li.shape[1] != 2:
             raise ValueError("pairs must be [L, 2]")
+        if not li.is_cuda:
+            li = li.to(dtype=torch.int64).contiguous()
         return li.to(device=self.device, dtype=torch.int64).contiguous()
 
     # ---- the batched native entry ----------------------------------------------------------

@@ -105,6 +105,8 @@ def warm_up(block=False):
                 t.add_(1).sum().item()
                 torch.arange(4, device=eng.device).t().contiguous()
                 eng.preload(_engine.Engine.PRELOAD_POS | _engine.Engine.PRELOAD_OTHER_K | _engine.Engine.PRELOAD_SOP)
+                if _host_mode() != "pinned" and os.environ.get("S3GRL_OUTPUT_DEVICE", "cpu") == "cpu":
+                    _get_ring(eng.device)          # the page-locked ring of the host copies (128 MiB, ~15 ms)
             except Exception:        # no device, no library: the first real call reports it
                 pass
 
@@ -201,12 +203,13 @@ def clear_cache(trim=True):
         if hasattr(v[2], "close"):
             v[2].close()
     _pool.clear()
+    _ring.clear()
     if trim and _engine._default:
         for eng in _engine._default.values():
             eng.trim()
 
 
-# ---- host staging ------------------------------------------------------------------------------
+# ---- host staging (S3GRL_HOST_OUTPUT=pinned; the default is described at `_to_host`) -----------
 # The caller owns the tensors it gets back, so a staging buffer cannot simply be
 # reused for the next call: the previous list may still be alive (pos_list while neg_list is being
 # computed, sgrl_link_pred.py:195-204).  Page-locking fresh memory for every call costs more than
@@ -269,17 +272,157 @@ def _staging(n):
     return alias[:n]
 
 
+# ---- rows to the host ---------------------------------------------------------------------------------------
+# The reference's contract is CPU tensors, and a run makes its six calls ONCE: every result is FRESH host memory.
+# Fresh page-locked memory costs its page-locking — 0.1 s per GB, 0.35 s for the headline's 2.6 GB, more than
+# everything else of a cold run together — and a plain `.cpu()` its 4 KiB page faults (9 GB/s).  Default
+# therefore: the result is ordinary pageable memory that asked for transparent huge pages (madvise: 2 MiB faults),
+# filled through a small page-locked ring — D2H of chunk k+1 at the link's rate while the CPU copies chunk k out
+# of the ring (torch's multi-threaded copy): 1.2 GB in 28 ms = 42 GB/s measured, cold or warm, against 117 ms for
+# a fresh page-locked block (tools/host_copy_probe.py).  The ring (2 x 64 MiB) is allocated once per process, by
+# the import-time warm-up when there is time.  S3GRL_HOST_OUTPUT=pinned: the results themselves page-locked,
+# from a pool that reuses blocks nobody refers to any more (57 GB/s once warm; what a loop that drops its results
+# wants).
+_RING_BYTES = 64 << 20
+_ring = {}
+
+
+def _host_mode():
+    return os.environ.get("S3GRL_HOST_OUTPUT", "pageable")
+
+
+def _get_ring(device):
+    """(two page-locked slots, their events, the copy stream) of a device, or None when page-locking is refused."""
+    key = str(device)
+    r = _ring.get(key)
+    if r is None:
+        try:
+            slots = [torch.empty(_RING_BYTES // 4, dtype=torch.float32, pin_memory=True) for _ in range(2)]
+        except RuntimeError:
+            _ring[key] = False
+            return None
+        r = (slots, [torch.cuda.Event(), torch.cuda.Event()], torch.cuda.Stream(device=device))
+        _ring[key] = r
+    return r or None
+
+
+def _huge_empty(n):
+    """n float32 of fresh pageable memory starting on a 2 MiB boundary, advised to use transparent huge pages."""
+    import ctypes
+
+    pad = (1 << 21) // 4
+    out = torch.empty(int(n) + pad, dtype=torch.float32)
+    p = out.data_ptr()
+    lo = (p + (1 << 21) - 1) & ~((1 << 21) - 1)
+    ln = (p + out.numel() * 4 - lo) & ~((1 << 21) - 1)
+    if ln > 0:
+        try:
+            ctypes.CDLL(None, use_errno=True).madvise(ctypes.c_void_p(lo), ctypes.c_size_t(ln), 14)   # MADV_HUGEPAGE
+        except Exception:      # no madvise: plain pages, slower, same result
+            pass
+    off = (lo - p) // 4 if ln > 0 else 0
+    return out[off:off + int(n)]
+
+
+def _usable_cpus():
+    """Host threads this process may really use: the affinity mask, capped by the cgroup's CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(n, 1)
+
+
+_copy_pool = None
+
+
+def _parallel_copy(dst, src):
+    """dst <- src (contiguous CPU float32 tensors of equal length) with a handful of threads of our own: the copy
+    is bound by the page faults of the fresh destination, which scale with the threads that take them (1 thread
+    12 GB/s, 4 threads 42 GB/s into huge pages) — and torch's own intra-op pool is sized by the machine, not by
+    the cgroup (128 threads on a 16-core share: slower than one).  numpy's copy releases the GIL."""
+    global _copy_pool
+    import numpy as np
+
+    n = dst.numel()
+    workers = min(8, _usable_cpus())
+    if workers <= 1 or n < (1 << 20):
+        np.copyto(dst.numpy(), src.numpy())
+        return
+    if _copy_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _copy_pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="s3grl-copy")
+    d, r = dst.numpy(), src.numpy()
+    step = -(-n // workers)
+    step = -(-step // (1 << 19)) * (1 << 19)          # whole 2 MiB pages per thread
+    futs = [_copy_pool.submit(np.copyto, d[a:a + step], r[a:a + step]) for a in range(0, n, step)]
+    for f in futs:
+        f.result()
+
+
+class _RingCopy:
+    """Copies device ranges into a host tensor through the page-locked ring.  `push(dst, src, after)` queues the
+    D2H of a range (after an event on the compute stream) and copies out whatever the ring has to give back;
+    `finish()` drains it.  The CPU-side copies of one range overlap the D2H of the next and whatever the GPU
+    computes meanwhile."""
+
+    def __init__(self, device):
+        self.ring = _get_ring(device)
+        self.pending = []
+        self.k = 0
+
+    def _drain_one(self):
+        dst, slot, m = self.pending.pop(0)
+        slots, evs, _ = self.ring
+        evs[slot].synchronize()
+        _parallel_copy(dst, slots[slot][:m])
+
+    def push(self, dst_flat, src_flat, after=None):
+        slots, evs, stream = self.ring
+        ce = slots[0].numel()
+        if after is not None:
+            stream.wait_event(after)
+        n = src_flat.numel()
+        for off in range(0, n, ce):
+            m = min(ce, n - off)
+            slot = self.k % 2
+            if len(self.pending) == 2:
+                self._drain_one()
+            with torch.cuda.stream(stream):
+                slots[slot][:m].copy_(src_flat[off:off + m], non_blocking=True)
+                evs[slot].record(stream)
+            self.pending.append((dst_flat[off:off + m], slot, m))
+            self.k += 1
+
+    def finish(self):
+        while self.pending:
+            self._drain_one()
+
+
 def _to_host(rows):
-    """D2H into pooled page-locked memory (2.6 GB of PubMed rows: 0.05 s; a pageable `.cpu()`
-    0.27 s), handed over without a second copy — the result is a PINNED tensor.  Beyond the cap of
-    `_pinned_cap()` bytes (or when page-locking is refused) it is an ordinary pageable copy."""
-    stage = _staging(rows.numel())
-    if stage is None:
+    """The rows of a call as a CPU tensor (see above): pageable huge-page memory filled through the ring, or —
+    S3GRL_HOST_OUTPUT=pinned — pooled page-locked memory; a plain `.cpu()` when page-locking is refused."""
+    if _host_mode() == "pinned":
+        stage = _staging(rows.numel())
+        if stage is None:
+            return rows.cpu()
+        stage = stage.view(rows.shape)
+        stage.copy_(rows, non_blocking=True)
+        torch.cuda.current_stream(rows.device).synchronize()
+        return stage
+    rc = _RingCopy(rows.device)
+    if rc.ring is None or not rows.is_contiguous():
         return rows.cpu()
-    stage = stage.view(rows.shape)
-    stage.copy_(rows, non_blocking=True)
-    torch.cuda.current_stream(rows.device).synchronize()
-    return stage
+    out = _huge_empty(rows.numel())
+    done = torch.cuda.Event()
+    done.record(torch.cuda.current_stream(rows.device))
+    rc.push(out, rows.reshape(-1), after=done)
+    rc.finish()
+    return out.view(rows.shape)
 
 
 # ---- compute / copy overlap of a PoS call -----------------------------------------------------------
@@ -311,13 +454,23 @@ def _pos_pipelined(eng, g, xd, link_index, num_hops, K, kw):
         return None
     F = int(xd.shape[1])
     shape = (2 * L, K + 1, F + 1)
-    stage = _staging(shape[0] * shape[1] * shape[2])
-    if stage is None:
-        return None
+    pinned = _host_mode() == "pinned"
+    rc = None
+    if pinned:
+        stage = _staging(shape[0] * shape[1] * shape[2])
+        if stage is None:
+            return None
+    else:
+        rc = _RingCopy(eng.device)
+        if rc.ring is None:
+            return None
+        stage = _huge_empty(shape[0] * shape[1] * shape[2])
     stage = stage.view(shape)
+    flat = stage.view(-1)
+    per_link = 2 * shape[1] * shape[2]
     links = eng.links(link_index)
     dev = torch.empty(shape, dtype=torch.float32, device=eng.device)
-    copy_stream = torch.cuda.Stream(device=eng.device)
+    copy_stream = torch.cuda.Stream(device=eng.device) if pinned else None
     main = torch.cuda.current_stream(eng.device)
     bounds = [L * i // pieces for i in range(pieces + 1)]
     for a, b in zip(bounds[:-1], bounds[1:]):
@@ -330,10 +483,16 @@ def _pos_pipelined(eng, g, xd, link_index, num_hops, K, kw):
             plan.close()
         done = torch.cuda.Event()
         done.record(main)
-        copy_stream.wait_event(done)
-        with torch.cuda.stream(copy_stream):
-            stage[2 * a:2 * b].copy_(dev[2 * a:2 * b], non_blocking=True)
-    copy_stream.synchronize()
+        if pinned:
+            copy_stream.wait_event(done)
+            with torch.cuda.stream(copy_stream):
+                stage[2 * a:2 * b].copy_(dev[2 * a:2 * b], non_blocking=True)
+        else:      # through the ring; the CPU copies of this piece run while the GPU computes the next ones
+            rc.push(flat[a * per_link:b * per_link], dev.view(-1)[a * per_link:b * per_link], after=done)
+    if pinned:
+        copy_stream.synchronize()
+    else:
+        rc.finish()
     return stage
 
 
