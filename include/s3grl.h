@@ -48,10 +48,10 @@ typedef enum s3grl_status {
   S3GRL_ERR_OUT_OF_MEMORY = 4,
   S3GRL_ERR_HIP = 5,              /* a HIP runtime call failed; see s3grl_last_error() */
   S3GRL_ERR_NO_DEVICE = 6,        /* no gfx950 device visible */
-  S3GRL_ERR_GRAPH_TOO_LARGE = 7,  /* nnz or num_nodes >= 2^31; SoP on a graph whose N-bit LDS bitmaps
-                                     exceed 160 KiB (num_nodes > 327 680) or a SoP ball that does not
-                                     fit LDS.  PoS / PoS Plus plans have no node limit: beyond the LDS
-                                     bitmaps the sizing pass and the overflow class keep them in HBM */
+  S3GRL_ERR_GRAPH_TOO_LARGE = 7,  /* nnz or num_nodes >= 2^31; a SoP ball (radius ceil(K/2), or one less for
+                                     odd K) that does not fit LDS.  No plan has a node limit: beyond ~327 680
+                                     nodes the N-bit bitmaps of the sizing pass, of the overflow class and of
+                                     the SoP scalar kernel live in HBM slices instead of LDS */
   S3GRL_ERR_SELF_LINK = 8         /* src == dst: the reference duplicates the node; unsupported */
 } s3grl_status;
 

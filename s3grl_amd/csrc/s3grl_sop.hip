@@ -127,23 +127,29 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 
 // Per link: Â^i[s,d], Â^i[s,s], Â^i[d,d] for i = 1..K.  LDS: vis/nxt/wpre bitmaps, list[n],
 // r[HB][n] double2 (x: propagated from s, y: from d), misc.
-template <int T, int G>
+// EXT: the three N-bit bitmaps live in an HBM slice per workgroup (`ext`, `ext_stride` words) instead of LDS —
+// graphs of more than kMaxNodesLds nodes; same code, slower memory; launched over chunks of a class list, so
+// that a bounded number of slices serves any number of links (like count_kernel's EXT flavour).
+template <int T, int G, bool EXT = false>
 __global__ __launch_bounds__(T) void sop_scalar_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, int W,
     const double* __restrict__ gdinv, const int64_t* __restrict__ links,
     const int32_t* __restrict__ class_list, const int64_t* __restrict__ node_off, int K, int HB, int RB,
-    int hubs, double* __restrict__ scal /* [L][K][3] = sd, ss, dd */, const float* __restrict__ mult) {
+    int hubs, double* __restrict__ scal /* [L][K][3] = sd, ss, dd */, const float* __restrict__ mult,
+    uint32_t* __restrict__ ext, int64_t ext_stride) {
   extern __shared__ uint32_t smem[];
   const int tid = threadIdx.x;
   const int l = class_list[blockIdx.x];
   const int n_alloc = (int)(node_off[l + 1] - node_off[l]);
-  uint32_t* vis = smem;
-  uint32_t* nxt = smem + W;
-  uint32_t* wpre = smem + 2 * W;
-  int* lvl_end = reinterpret_cast<int*>(smem + 3 * W);
+  const int WL = EXT ? 0 : W;   // bitmap words that sit in LDS
+  uint32_t* bmp = EXT ? ext + (int64_t)blockIdx.x * ext_stride : smem;
+  uint32_t* vis = bmp;
+  uint32_t* nxt = bmp + W;
+  uint32_t* wpre = bmp + 2 * W;
+  int* lvl_end = reinterpret_cast<int*>(smem + 3 * WL);
   int* sh = lvl_end + kMaxLevels;
   int* hub = hubs ? sh + 32 : nullptr;
-  const int red_off = (3 * W + kMaxLevels + 32 + kHubWords + 1) & ~1;   // doubles: 8-byte aligned
+  const int red_off = (3 * WL + kMaxLevels + 32 + kHubWords + 1) & ~1;   // doubles: 8-byte aligned
   double* red = reinterpret_cast<double*>(smem + red_off);           // [16 waves][3]
   int32_t* list = reinterpret_cast<int32_t*>(smem + red_off + 96);
   double2* r = reinterpret_cast<double2*>(smem + ((red_off + 96 + n_alloc + 3) & ~3));  // [HB][n]
@@ -483,10 +489,6 @@ s3grl_status s3grl_sop_create_weighted(s3grl_context* ctx, const s3grl_graph* g,
     set_last_error("SoP on a directed graph is not implemented (the closed form relies on a symmetric operator)");
     return S3GRL_ERR_NOT_IMPLEMENTED;
   }
-  if (g->num_nodes > kMaxNodesLds) {
-    set_last_error("num_nodes exceeds the LDS bitmap limit");
-    return S3GRL_ERR_GRAPH_TOO_LARGE;
-  }
   S3GRL_HIP_TRY(hipSetDevice(ctx->device));
   std::unique_ptr<s3grl_sop, s3grl_status (*)(s3grl_sop*)> s(new s3grl_sop(), s3grl_sop_destroy);
   s->ctx = ctx;
@@ -642,7 +644,11 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
                            n_jobs, lvl_max, reinterpret_cast<int32_t*>(ds), ctx->d_stats));
   }
   S3GRL_TRY(launch_scan_i32_to_i64(ctx, n_nodes, L, node_off, scan_ws));
-  const int fixed = 4 * (3 * W + kMaxLevels + 32 + kHubWords + 6 * 16) + 64;
+  // graphs whose three N-bit bitmaps do not fit a CU's LDS (num_nodes > ~327 680): the bitmaps of the scalar
+  // kernel live in HBM slices, one per workgroup of a launch, and the class lists run in chunks over them
+  const bool ext = 4 * (3 * (int64_t)W + kMaxLevels + 32 + kHubWords + 6 * 16) + 64 + 4096 > 163840 ||
+                   getenv("S3GRL_FORCE_EXT_BITMAPS") != nullptr;
+  const int fixed = 4 * (3 * (ext ? 0 : W) + kMaxLevels + 32 + kHubWords + 6 * 16) + 64;
   const int per_node = 4 + 16 * HB;
   const int b2 = 163840 - fixed, b1 = std::min(b2, 49152), b0 = std::min(b2, 12288);
   hipLaunchKernelGGL(sop_classify_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -668,17 +674,37 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
   }
   const int bounds[3] = {b0, b1, b2};
   const bool sparse = (double)g->nnz / (double)std::max<int64_t>(g->num_nodes, 1) <= 6.0;
+  uint32_t* ext_slices = nullptr;
+  const int64_t ext_stride = ((int64_t)3 * W + 63) / 64 * 64;
+  int ext_chunk = 0;
+  if (ext) {
+    const int most = std::max(cc[0], std::max(cc[1], cc[2]));
+    ext_chunk = (int)std::min<int64_t>(std::max(most, 1), std::max<int64_t>(256, ((int64_t)1 << 29) / (ext_stride * 4)));
+    S3GRL_TRY(alloc((size_t)ext_stride * 4 * ext_chunk, &q));
+    ext_slices = static_cast<uint32_t*>(q);
+  }
   for (int c = 2; c >= 0; --c) {
     if (cc[c] == 0) continue;
     const size_t lds = (size_t)fixed + bounds[c];
-#define S3GRL_SOP_LAUNCH(TT, GG)                                                                   \
+#define S3GRL_SOP_LAUNCH_(KERN, TT, LIST, COUNT)                                                   \
   do {                                                                                             \
-    auto kern = sop_scalar_kernel<TT, GG>;                                                         \
+    auto kern = KERN;                                                                              \
     S3GRL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                         \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
-    hipLaunchKernelGGL(kern, dim3((unsigned)cc[c]), dim3(TT), lds, ctx->stream, g->indptr,         \
-                       g->indices, W, s->dinv, links, class_list + (int64_t)c * L, node_off, K,    \
-                       HB, RB, g->max_degree > kHubArmDegree ? 1 : 0, scal, s->mult);                 \
+    hipLaunchKernelGGL(kern, dim3((unsigned)(COUNT)), dim3(TT), lds, ctx->stream, g->indptr,       \
+                       g->indices, W, s->dinv, links, LIST, node_off, K,                           \
+                       HB, RB, g->max_degree > kHubArmDegree ? 1 : 0, scal, s->mult, ext_slices,   \
+                       ext_stride);                                                                \
+  } while (0)
+#define S3GRL_SOP_LAUNCH(TT, GG)                                                                   \
+  do {                                                                                             \
+    if (!ext) {                                                                                    \
+      S3GRL_SOP_LAUNCH_((sop_scalar_kernel<TT, GG, false>), TT, class_list + (int64_t)c * L, cc[c]); \
+    } else {                                                                                       \
+      for (int base = 0; base < cc[c]; base += ext_chunk)                                          \
+        S3GRL_SOP_LAUNCH_((sop_scalar_kernel<TT, GG, true>), TT, class_list + (int64_t)c * L + base, \
+                          std::min(ext_chunk, cc[c] - base));                                      \
+    }                                                                                              \
   } while (0)
     if (c == 0 && RB <= 1) {   // a ball of a dozen nodes: one wavefront per link, no cross-wave barriers
       if (sparse) S3GRL_SOP_LAUNCH(64, 4); else S3GRL_SOP_LAUNCH(64, 8);
@@ -688,6 +714,7 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
       if (sparse) S3GRL_SOP_LAUNCH(1024, 4); else S3GRL_SOP_LAUNCH(1024, 8);
     }
 #undef S3GRL_SOP_LAUNCH
+#undef S3GRL_SOP_LAUNCH_
     S3GRL_HIP_TRY(hipGetLastError());
   }
   if (ctx->profiling) S3GRL_HIP_TRY(hipEventRecord(ctx->ev[5], ctx->stream));

@@ -1682,3 +1682,59 @@ def test_node_list_handover_and_its_fallback(eng, monkeypatch, flavour):
     np.testing.assert_array_equal(outs[0][1].cpu().numpy(), ptr)
     assert rel_err(outs[0][0].cpu().numpy(), ref) < TOL
     G.close()
+
+
+@pytest.mark.parametrize("K", [2, 3, 4])
+def test_sop_bitmaps_in_hbm_change_nothing(eng, monkeypatch, K):
+    """Beyond ~327 680 nodes the three N-bit bitmaps of the SoP scalar kernel do not fit a CU's LDS: they then
+    live in HBM slices, the class lists run in chunks over them (like the sizing pass of PoS).
+    S3GRL_FORCE_EXT_BITMAPS sends the small fixtures down that road: the same rows bit for bit."""
+    import torch
+
+    g = load_extract("usair")
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = np.random.default_rng(3).standard_normal((n, 11))
+    links = np.concatenate([g["links"], g["links"][:5, ::-1]])
+    G = eng.graph(A)
+    f = eng.features(X)
+    L = eng.links(links.T)
+    out = []
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("S3GRL_FORCE_EXT_BITMAPS", "1")
+        else:
+            monkeypatch.delenv("S3GRL_FORCE_EXT_BITMAPS", raising=False)
+        out.append(eng.precompute(G, f, L, mode="sop", sign_k=K).rows.clone())
+    monkeypatch.delenv("S3GRL_FORCE_EXT_BITMAPS", raising=False)
+    assert torch.equal(out[0], out[1])
+    G.close()
+
+
+@pytest.mark.parametrize("K", [2, 3])
+def test_sop_on_half_a_million_nodes(eng, K):
+    """SoP has no node limit any more (reference tuned_SIGN.py:49-134 has none either): a 500 000-node sparse
+    graph, links at its best-connected nodes and at random, against the oracle's global powers."""
+    from s3grl_amd import workloads
+
+    rng = np.random.default_rng(21)
+    n = 500000
+    e = rng.integers(0, n, size=(750000, 2))
+    e = e[e[:, 0] != e[:, 1]]
+    e = np.unique(np.sort(e, axis=1), axis=0)
+    A = workloads.csr_from_undirected(n, e)
+    deg = np.diff(A.indptr)
+    top = np.argsort(-deg)[:40]
+    links = np.concatenate([e[rng.choice(len(e), 150, replace=False)], rng.integers(0, n, size=(100, 2)),
+                            np.stack([top[:-1], top[1:]], 1)])
+    links = links[links[:, 0] != links[:, 1]]
+    X = rng.random((n, 6)).astype(np.float32)
+    G = eng.graph(A)
+    f = eng.features(X)
+    res = eng.precompute(G, f, eng.links(links.T), mode="sop", sign_k=K)
+    P = oracle.global_normalized_powers(A, K, np.float64)
+    ref, _, _ = oracle.collate_rows(oracle.get_SoP_prepped_ds(P, links.T, A, X.astype(np.float64), 1, dtype=np.float64), K)
+    err = rel_err(res.rows.cpu().numpy(), ref)
+    report_errors(f"half_million_nodes_sop[K={K}]", err, err)
+    assert err < TOL
+    f.close(), G.close()
