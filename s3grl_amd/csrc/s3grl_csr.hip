@@ -441,7 +441,10 @@ s3grl_status launch_csr_class(s3grl_context* ctx, const CsrLinkArgs& a, int K, i
                               int count, hipStream_t stream) {
   if (count == 0) return S3GRL_OK;
   const size_t lds = (size_t)4 * csr_fixed_words(a.cn_cap, K) + (size_t)csr_class_bound(cls, a.cn_cap, K);
-  int t = lds <= 10 * 1024 ? 128 : (lds <= 40 * 1024 ? 256 : (lds <= 80 * 1024 ? 512 : 1024));
+  // threads per link by the LDS a link of the class holds (measured on PubMed sign_k = 5, S3GRL_TC_CLASS<c>
+  // sweeps: the uniform part of the kernel is most of a small link's cost — fewer threads; the classes that
+  // leave a CU three or four workgroups want 512)
+  int t = lds <= 18 * 1024 ? 128 : (lds <= 26 * 1024 ? 256 : (lds <= 80 * 1024 ? 512 : 1024));
   {
     char name[32];   // tuning hook
     snprintf(name, sizeof(name), "S3GRL_TC_CLASS%d", cls);
@@ -454,6 +457,7 @@ s3grl_status launch_csr_class(s3grl_context* ctx, const CsrLinkArgs& a, int K, i
     S3GRL_HIP_TRY(hipGetLastError());
     return S3GRL_OK;
   };
+  if (t <= 64) return go(link_csr_kernel<64>, 64);
   if (t <= 128) return go(link_csr_kernel<128>, 128);
   if (t <= 256) return go(link_csr_kernel<256>, 256);
   if (t <= 512) return go(link_csr_kernel<512>, 512);

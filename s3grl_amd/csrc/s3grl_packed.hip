@@ -565,11 +565,124 @@ __global__ __launch_bounds__(256) void gather_traffic_kernel(
   atomicAdd(&out[7], (unsigned long long)tiles);
 }
 
+// TIMING-ONLY prototype (S3GRL_GATHER_PROTO=<variant>, results are WRONG): what would the
+// gather cost at eight wavefronts per SIMD?  The real kernel holds 117 VGPRs (four waves per SIMD): the
+// accumulators of up to three operators and two or three chunk buffers of 32 registers each.  Eight waves
+// leave 64 registers: one operator's accumulators (16) and ONE buffer of U = 4 rows (32), or two of U = 2 —
+// i.e. phase B of the real kernel (the last operator over the rows beyond the prefix, four fifths of the
+// headline's rows) with nothing pipelined by hand, the wavefronts covering each other's latency.  This
+// kernel runs that phase over the WHOLE list of every job and writes the last operator's rows only.
+// DB: two buffers of U rows (the loads of group g + 1 in flight under the multiply-adds of group g).
+template <int K, int U, bool DB, int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void gather_last_proto_kernel(
+    const Job* __restrict__ jobs, int njobs, const int32_t* __restrict__ c_ids, const float* __restrict__ c_coef,
+    const int32_t* __restrict__ job_order, const PackedHdr* __restrict__ hdr, const float4_t* __restrict__ data,
+    uint32_t data_bytes, int64_t N, int F, float* __restrict__ rows_out) {
+  constexpr int CH = 2;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x);
+  if (wid >= njobs) return;
+  const int jid = __builtin_amdgcn_readfirstlane(job_order[wid]);
+  const int col0 = blockIdx.y * kTile;
+  const Job job = jobs[jid];
+  if (job.split != 0) return;
+  const int cnt = __builtin_amdgcn_readfirstlane(job.support);
+  const uint32_t* __restrict__ uid = reinterpret_cast<const uint32_t*>(c_ids + job.ids_off);
+  const float2* __restrict__ cf = reinterpret_cast<const float2*>(c_coef) + job.coef_off + (int64_t)(K - 1) * cnt;
+  const PackedHdr* __restrict__ th = hdr + (int64_t)blockIdx.y * N;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float4_t*>(data), 0, (int)data_bytes, 0x00020000);
+  const uint32_t oobv = kOobOffset;
+  float4_t acc[2][CH];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[r][c] = (float4_t)(0.f);
+  auto issue = [&](int g, float4_t(&v)[U][CH]) __attribute__((always_inline)) {
+    uint32_t id[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) id[u] = uid[min(g * U + u, cnt - 1)];
+    PackedHdr h[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) h[u] = th[id[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = g * U + u < cnt;
+      const uint32_t base = (uint32_t)h[u].off;
+      const uint32_t a0 = (base + (uint32_t)below(h[u].m0)) << 4;
+      const uint32_t a1 = (base + (uint32_t)__popcll(h[u].m0) + (uint32_t)below(h[u].m1)) << 4;
+      v[u][0] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                                                 rsrc, (int)select_or_oob(ok ? h[u].m0 : 0ull, a0, oobv), 0, 0));
+      v[u][1] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                                                 rsrc, (int)select_or_oob(ok ? h[u].m1 : 0ull, a1, oobv), 0, 0));
+    }
+  };
+  auto fma = [&](int g, const float4_t(&v)[U][CH]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float2 q = cf[min(g * U + u, cnt - 1)];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        acc[0][c] += q.x * v[u][c];
+        acc[1][c] += q.y * v[u][c];
+      }
+    }
+  };
+  const int ng = (cnt + U - 1) / U;
+  if constexpr (DB) {
+    float4_t va[U][CH], vb[U][CH];
+    issue(0, va);
+    for (int g = 0; g < ng; g += 2) {
+      issue(min(g + 1, ng - 1), vb);
+      fma(g, va);
+      issue(min(g + 2, ng - 1), va);
+      if (g + 1 < ng) fma(g + 1, vb);
+    }
+  } else {
+    float4_t va[U][CH];
+    for (int g = 0; g < ng; ++g) {
+      issue(g, va);
+      fma(g, va);
+    }
+  }
+  const int Fp = F + 1;
+  float* __restrict__ out = rows_out + job.out_row * (int64_t)(K + 1) * Fp + (int64_t)K * Fp + 1;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (r == 1 && job.node_b < 0) break;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int co = col0 + (lane + 64 * c) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (co + e < F) out[(int64_t)r * (K + 1) * Fp + co + e] = acc[r][c][e];
+    }
+  }
+}
+
 template <int K>
 s3grl_status launch_packed_k(s3grl_context* ctx, const s3grl_plan* p, const GatherView& v,
                              const s3grl_features* f, float* rows) {
   hipStream_t stream = ctx->stream;
   const unsigned gx = (unsigned)((v.njobs + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (const char* proto = getenv("S3GRL_GATHER_PROTO")) {   // timing-only experiment: see gather_last_proto_kernel
+    const uint32_t db = (uint32_t)((f->pk_chunks + 1) * 16);
+#define S3GRL_PROTO(UU, DBB, WW)                                                                               \
+  hipLaunchKernelGGL((gather_last_proto_kernel<K, UU, DBB, WW>), dim3((unsigned)v.njobs, (unsigned)f->tiles),   \
+                     dim3(64), 0, stream, v.jobs, (int)v.njobs, p->c_ids, p->c_coef, v.job_order,              \
+                     static_cast<const PackedHdr*>(f->pk_hdr), static_cast<const float4_t*>(f->pk_data), db,   \
+                     f->N, (int)f->F, rows)
+    switch (atoi(proto)) {
+      case 1: S3GRL_PROTO(4, false, 8); break;   // one buffer of four rows, eight waves per SIMD
+      case 2: S3GRL_PROTO(2, true, 8); break;    // two buffers of two rows, eight waves
+      case 3: S3GRL_PROTO(4, true, 5); break;    // two buffers of four rows, five waves
+      case 4: S3GRL_PROTO(4, false, 4); break;   // control: one buffer at the real kernel's four waves
+      default: S3GRL_PROTO(2, false, 8); break;
+    }
+#undef S3GRL_PROTO
+    S3GRL_HIP_TRY(hipGetLastError());
+    return S3GRL_OK;
+  }
   static const bool masked = !getenv("S3GRL_GATHER_UNMASKED");   // comparison hook: the unconditional loads
   const uint32_t data_bytes = (uint32_t)((f->pk_chunks + 1) * 16);
   // experiment hook: dynamic LDS per workgroup caps the resident waves (timing only)
