@@ -373,6 +373,13 @@ s3grl_status launch_translate_links(s3grl_context* ctx, const s3grl_graph* g, co
 // plan on a big graph works on its links (locality; outputs stay in the caller's order)
 s3grl_status launch_link_order(s3grl_context* ctx, const int64_t* links, int64_t L, int64_t N,
                                const int32_t* indptr, int32_t* perm);
+// (u64 key, i32 value) radix sort, instantiated in relabel.hip only (see there)
+s3grl_status sort_pairs_u64_i32_bytes(s3grl_context* ctx, size_t n, size_t* bytes);
+s3grl_status sort_pairs_u64_i32(s3grl_context* ctx, void* tmp, size_t bytes, uint64_t* keys_in, uint64_t* keys_out,
+                                int32_t* vals_in, int32_t* vals_out, size_t n);
+// segsort.hip
+s3grl_status segmented_sort_i32(s3grl_context* ctx, void* tmp, size_t* bytes, const int32_t* keys_in, int32_t* keys_out,
+                                size_t n, unsigned segments, const int64_t* seg);
 // balls.hip
 s3grl_status ensure_ball_cache(s3grl_context* ctx, s3grl_graph* g, int hops, bool* usable);
 void release_ball_cache(s3grl_graph* g);

@@ -20,7 +20,6 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_segmented_radix_sort.hpp>
 
 #include "s3grl_internal.hpp"
 #include "s3grl_device.hpp"
@@ -337,6 +336,23 @@ s3grl_status launch_link_order(s3grl_context* ctx, const int64_t* links, int64_t
   return S3GRL_OK;   // (tmp is released on return: stream-ordered reuse)
 }
 
+// (u64 key, i32 value) radix sort for the other translation units: rocPRIM's kernels are templates, and a
+// second unit instantiating the same sort makes the host-side launch stubs of this one resolve to WHICHEVER
+// unit's code object the linker kept — s3grl_graph_create then loaded the SoP unit's 2 MB to sort its node keys
+s3grl_status sort_pairs_u64_i32_bytes(s3grl_context* ctx, size_t n, size_t* bytes) {
+  *bytes = 0;
+  S3GRL_HIP_TRY(rocprim::radix_sort_pairs(nullptr, *bytes, static_cast<uint64_t*>(nullptr), static_cast<uint64_t*>(nullptr),
+                                          static_cast<int32_t*>(nullptr), static_cast<int32_t*>(nullptr), n, 0, 64,
+                                          ctx->stream));
+  return S3GRL_OK;
+}
+
+s3grl_status sort_pairs_u64_i32(s3grl_context* ctx, void* tmp, size_t bytes, uint64_t* keys_in, uint64_t* keys_out,
+                                int32_t* vals_in, int32_t* vals_out, size_t n) {
+  S3GRL_HIP_TRY(rocprim::radix_sort_pairs(tmp, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 64, ctx->stream));
+  return S3GRL_OK;
+}
+
 s3grl_status launch_translate_links(s3grl_context* ctx, const s3grl_graph* g, const int64_t* links, int64_t L,
                                     int64_t* out) {
   if (L == 0) return S3GRL_OK;
@@ -372,12 +388,10 @@ s3grl_status launch_sort_hops(s3grl_context* ctx, const s3grl_plan* p, int32_t* 
                      p->node_off, p->lvl, p->L, so);
   S3GRL_HIP_TRY(hipGetLastError());
   size_t bytes = 0;
-  S3GRL_HIP_TRY(rocprim::segmented_radix_sort_keys(nullptr, bytes, nodes, static_cast<int32_t*>(sorted), (size_t)n,
-                                                   (unsigned)nseg, so, so + 1, 0, 32, ctx->stream));
+  S3GRL_TRY(segmented_sort_i32(ctx, nullptr, &bytes, nodes, static_cast<int32_t*>(sorted), (size_t)n, (unsigned)nseg, so));
   S3GRL_TRY(ctx->arena.alloc(std::max<size_t>(bytes, 16), &rt));
   tmp.ptrs.push_back(rt);
-  S3GRL_HIP_TRY(rocprim::segmented_radix_sort_keys(rt, bytes, nodes, static_cast<int32_t*>(sorted), (size_t)n,
-                                                   (unsigned)nseg, so, so + 1, 0, 32, ctx->stream));
+  S3GRL_TRY(segmented_sort_i32(ctx, rt, &bytes, nodes, static_cast<int32_t*>(sorted), (size_t)n, (unsigned)nseg, so));
   S3GRL_HIP_TRY(hipMemcpyAsync(nodes, sorted, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
   S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));   // tmp is released on return
   return S3GRL_OK;

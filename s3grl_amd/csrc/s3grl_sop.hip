@@ -18,7 +18,6 @@
 
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "s3grl_internal.hpp"
 #include "s3grl_device.hpp"
@@ -605,7 +604,7 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
     S3GRL_TRY(alloc((size_t)L * 8, &q)); kb = (uint64_t*)q;
     S3GRL_TRY(alloc((size_t)L * 4, &q)); va = (int32_t*)q;
     S3GRL_TRY(alloc((size_t)L * 4, &q)); vb = (int32_t*)q;
-    S3GRL_HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, ka, kb, va, vb, (size_t)L, 0, 64, ctx->stream));
+    S3GRL_TRY(sort_pairs_u64_i32_bytes(ctx, (size_t)L, &sort_bytes));
     S3GRL_TRY(alloc(std::max<size_t>(sort_bytes, 16), &sort_tmp));
     order = vb;
     sort_ka = ka, sort_kb = kb, sort_va = va;
@@ -631,8 +630,7 @@ s3grl_status s3grl_sop_run(s3grl_context* ctx, const s3grl_sop* s, const int64_t
     hipLaunchKernelGGL(sop_order_keys_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream, links,
                        L, sort_ka, sort_va);
     S3GRL_HIP_TRY(hipGetLastError());
-    S3GRL_HIP_TRY(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, sort_ka, sort_kb, sort_va, order, (size_t)L, 0, 64,
-                                            ctx->stream));
+    S3GRL_TRY(sort_pairs_u64_i32(ctx, sort_tmp, sort_bytes, sort_ka, sort_kb, sort_va, order, (size_t)L));
   }
   // capacity of every link's ball: the sizing BFS of the PoS path, or a degree bound for radius <= 1
   if (RB <= 1) {
