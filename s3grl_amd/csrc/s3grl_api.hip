@@ -738,8 +738,14 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   int32_t* stash = nullptr;
   int slot = 4096;
   if (const char* e = getenv("S3GRL_STASH_SLOT")) slot = std::max(0, atoi(e));   // test hook; 0 = off
-  while (slot > 256 && (int64_t)L * slot * 4 > ((int64_t)6 << 30)) slot >>= 1;
-  if (!onehop && slot > 0 && (int64_t)L * slot * 4 <= ((int64_t)6 << 30))
+  // Which flavour of the link kernel a link takes must not depend on the rest of the list (a link gives the same
+  // bits in a sharded and an unsharded run), and the induced-CSR flavour needs the list in the stash: plans that
+  // may use it keep the full slot up to 32 GiB of stash (2 M links) instead of shrinking it from 6 GiB on
+  const bool csr_candidate = !onehop && !walks && !sampling && !g->directed && g->r_indptr && !getenv("S3GRL_NO_RELABEL") &&
+                             csr_mode_for(g, cfg->num_hops, K, true, true);
+  const int64_t stash_cap = csr_candidate ? ((int64_t)32 << 30) : ((int64_t)6 << 30);
+  while (slot > 256 && (int64_t)L * slot * 4 > stash_cap) slot >>= 1;
+  if (!onehop && slot > 0 && (int64_t)L * slot * 4 <= stash_cap)
     S3GRL_TRY(arena_alloc(ctx, (size_t)L * slot, &stash, tr));
   // Plain plans walk the graph in its degree order (s3grl_relabel.hip): links translated on the way
   // in, everything the plan hands out translated back by the link kernels.  Sampled and random-walk

@@ -573,14 +573,36 @@ __global__ __launch_bounds__(256) void gather_traffic_kernel(
 // headline's rows) with nothing pipelined by hand, the wavefronts covering each other's latency.  This
 // kernel runs that phase over the WHOLE list of every job and writes the last operator's rows only.
 // DB: two buffers of U rows (the loads of group g + 1 in flight under the multiply-adds of group g).
-template <int K, int U, bool DB, int WAVES>
+// HALVES = 2: a wavefront takes HALF of the tile (64 of its 128 chunks: one mask word, one load per row, half
+// the accumulators) — twice the wavefronts, each walking the whole list.  PIN: the two halves run on disjoint
+// sets of XCDs (workgroup id mod 8 < 4: half 0), so that an XCD's L2 only ever sees half of the packed operand.
+// HDRWIN: the headers are read from a window of 256 rows (every scalar load a cache hit; the chunk loads then
+// stay inside those rows' data as well) — what the kernel would cost without misses on its per-row chain.
+// VHDR: the headers of the next 64 rows are fetched by ONE vector gather (lane u: row u's mask words and offset)
+// and handed to the wavefront with v_readlane, instead of one scalar load per row through the scalar cache.
+// ONELOAD (timing only, wrong sums): ONE wave-load per row — lane l fetches the row's l-th populated chunk (a
+// row has ~42 of 128) — and the multiply-adds use it for both halves: what the kernel would cost if the texture
+// path saw one 1-KiB wave-load per row instead of two (the data would then have to reach its owner lanes
+// through LDS).
+template <int K, int U, bool DB, int WAVES, int HALVES = 1, bool PIN = false, bool HDRWIN = false, bool VHDR = false,
+          bool ONELOAD = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void gather_last_proto_kernel(
     const Job* __restrict__ jobs, int njobs, const int32_t* __restrict__ c_ids, const float* __restrict__ c_coef,
     const int32_t* __restrict__ job_order, const PackedHdr* __restrict__ hdr, const float4_t* __restrict__ data,
     uint32_t data_bytes, int64_t N, int F, float* __restrict__ rows_out) {
-  constexpr int CH = 2;
+  constexpr int CH = 2 / HALVES;
   const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x);
+  int wid = __builtin_amdgcn_readfirstlane(blockIdx.x), half = 0;
+  if constexpr (HALVES == 2) {
+    if constexpr (PIN) {
+      const int sub = wid & 7;
+      half = sub >> 2;
+      wid = (wid >> 3) * 4 + (sub & 3);
+    } else {
+      half = wid & 1;
+      wid >>= 1;
+    }
+  }
   if (wid >= njobs) return;
   const int jid = __builtin_amdgcn_readfirstlane(job_order[wid]);
   const int col0 = blockIdx.y * kTile;
@@ -598,23 +620,61 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
   for (int r = 0; r < 2; ++r)
 #pragma unroll
     for (int c = 0; c < CH; ++c) acc[r][c] = (float4_t)(0.f);
+  // VHDR: headers of rows [hb, hb + 64) in registers, one row per lane (m0, m1 as two dwords each, offset)
+  uint32_t hv[5] = {0, 0, 0, 0, 0};
+  int hb = -64;
+  auto fetch_headers = [&](int base_row) __attribute__((always_inline)) {
+    const int r = min(base_row + lane, cnt - 1);
+    const uint32_t id = uid[r];
+    const uint32_t* __restrict__ hp = reinterpret_cast<const uint32_t*>(th + id);
+    const uint4_t w = *reinterpret_cast<const uint4_t*>(hp);
+    hv[0] = w.x; hv[1] = w.y; hv[2] = w.z; hv[3] = w.w;
+    hv[4] = hp[4];
+    hb = base_row;
+  };
   auto issue = [&](int g, float4_t(&v)[U][CH]) __attribute__((always_inline)) {
     uint32_t id[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) id[u] = uid[min(g * U + u, cnt - 1)];
     PackedHdr h[U];
+    if constexpr (VHDR) {
+      if (g * U >= hb + 64) fetch_headers(g * U);      // (64 % U == 0: a group never straddles two batches)
 #pragma unroll
-    for (int u = 0; u < U; ++u) h[u] = th[id[u]];
+      for (int u = 0; u < U; ++u) {
+        const int ln = g * U + u - hb;
+        h[u].m0 = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hv[0], ln) |
+                  ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hv[1], ln) << 32);
+        h[u].m1 = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hv[2], ln) |
+                  ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hv[3], ln) << 32);
+        h[u].off = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hv[4], ln);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) id[u] = uid[min(g * U + u, cnt - 1)];
+#pragma unroll
+      for (int u = 0; u < U; ++u) h[u] = th[HDRWIN ? (id[u] & 255u) : id[u]];
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const bool ok = g * U + u < cnt;
       const uint32_t base = (uint32_t)h[u].off;
       const uint32_t a0 = (base + (uint32_t)below(h[u].m0)) << 4;
       const uint32_t a1 = (base + (uint32_t)__popcll(h[u].m0) + (uint32_t)below(h[u].m1)) << 4;
-      v[u][0] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(
-                                                 rsrc, (int)select_or_oob(ok ? h[u].m0 : 0ull, a0, oobv), 0, 0));
-      v[u][1] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(
-                                                 rsrc, (int)select_or_oob(ok ? h[u].m1 : 0ull, a1, oobv), 0, 0));
+      if constexpr (HALVES == 2) {
+        const uint64_t m = half ? h[u].m1 : h[u].m0;
+        v[u][0] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   rsrc, (int)select_or_oob(ok ? m : 0ull, half ? a1 : a0, oobv), 0, 0));
+      } else if constexpr (ONELOAD) {
+        const uint32_t nch = (uint32_t)(__popcll(h[u].m0) + __popcll(h[u].m1));
+        const uint32_t ac = (uint32_t)lane < nch && ok ? (base + (uint32_t)lane) << 4 : oobv;
+        v[u][0] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)ac, 0, 0));
+        v[u][CH - 1] = v[u][0];
+        (void)a0;
+        (void)a1;
+      } else {
+        v[u][0] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   rsrc, (int)select_or_oob(ok ? h[u].m0 : 0ull, a0, oobv), 0, 0));
+        v[u][CH - 1] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                                                        rsrc, (int)select_or_oob(ok ? h[u].m1 : 0ull, a1, oobv), 0, 0));
+      }
     }
   };
   auto fma = [&](int g, const float4_t(&v)[U][CH]) __attribute__((always_inline)) {
@@ -652,7 +712,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     if (r == 1 && job.node_b < 0) break;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      const int co = col0 + (lane + 64 * c) * 4;
+      const int co = col0 + (lane + 64 * (HALVES == 2 ? half : c)) * 4;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (co + e < F) out[(int64_t)r * (K + 1) * Fp + co + e] = acc[r][c][e];
@@ -677,6 +737,37 @@ s3grl_status launch_packed_k(s3grl_context* ctx, const s3grl_plan* p, const Gath
       case 2: S3GRL_PROTO(2, true, 8); break;    // two buffers of two rows, eight waves
       case 3: S3GRL_PROTO(4, true, 5); break;    // two buffers of four rows, five waves
       case 4: S3GRL_PROTO(4, false, 4); break;   // control: one buffer at the real kernel's four waves
+      case 5: S3GRL_PROTO(2, false, 8); break;
+#define S3GRL_PROTO_H(UU, DBB, WW, PINN)                                                                        \
+  hipLaunchKernelGGL((gather_last_proto_kernel<K, UU, DBB, WW, 2, PINN>),                                       \
+                     dim3((unsigned)((v.njobs + 3) / 4 * 8), (unsigned)f->tiles), dim3(64), 0, stream, v.jobs,  \
+                     (int)v.njobs, p->c_ids, p->c_coef, v.job_order, static_cast<const PackedHdr*>(f->pk_hdr),  \
+                     static_cast<const float4_t*>(f->pk_data), db, f->N, (int)f->F, rows)
+      case 6: S3GRL_PROTO_H(4, false, 8, true); break;    // half tiles pinned to XCD halves, one buffer, eight waves
+      case 7: S3GRL_PROTO_H(4, false, 8, false); break;   // half tiles, not pinned (control)
+      case 8: S3GRL_PROTO_H(4, true, 8, true); break;     // half tiles pinned, two buffers of four rows
+      case 9: S3GRL_PROTO_H(4, true, 8, false); break;
+#undef S3GRL_PROTO_H
+#define S3GRL_PROTO_X(UU, DBB, WW, WIN, VH)                                                                      \
+  hipLaunchKernelGGL((gather_last_proto_kernel<K, UU, DBB, WW, 1, false, WIN, VH>),                              \
+                     dim3((unsigned)v.njobs, (unsigned)f->tiles), dim3(64), 0, stream, v.jobs, (int)v.njobs,     \
+                     p->c_ids, p->c_coef, v.job_order, static_cast<const PackedHdr*>(f->pk_hdr),                 \
+                     static_cast<const float4_t*>(f->pk_data), db, f->N, (int)f->F, rows)
+      case 10: S3GRL_PROTO_X(4, false, 8, true, false); break;   // headers (and chunks) from a 256-row window
+      case 11: S3GRL_PROTO_X(4, false, 8, false, true); break;   // headers by vector gather + readlane, one buffer
+      case 12: S3GRL_PROTO_X(4, true, 5, false, true); break;    // ... two buffers of four rows at five waves
+      case 13: S3GRL_PROTO_X(2, true, 8, false, true); break;    // ... two buffers of two rows at eight waves
+      case 14: S3GRL_PROTO_X(4, true, 5, true, false); break;    // window control with two buffers
+#undef S3GRL_PROTO_X
+#define S3GRL_PROTO_O(UU, DBB, WW, VH)                                                                           \
+  hipLaunchKernelGGL((gather_last_proto_kernel<K, UU, DBB, WW, 1, false, false, VH, true>),                      \
+                     dim3((unsigned)v.njobs, (unsigned)f->tiles), dim3(64), 0, stream, v.jobs, (int)v.njobs,     \
+                     p->c_ids, p->c_coef, v.job_order, static_cast<const PackedHdr*>(f->pk_hdr),                 \
+                     static_cast<const float4_t*>(f->pk_data), db, f->N, (int)f->F, rows)
+      case 15: S3GRL_PROTO_O(4, false, 8, true); break;    // one compact load per row, vector headers, eight waves
+      case 16: S3GRL_PROTO_O(4, true, 8, true); break;     // ... two buffers of four rows (16 VGPRs each)
+      case 17: S3GRL_PROTO_O(4, false, 8, false); break;   // ... scalar headers
+#undef S3GRL_PROTO_O
       default: S3GRL_PROTO(2, false, 8); break;
     }
 #undef S3GRL_PROTO
