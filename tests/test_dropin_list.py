@@ -272,3 +272,22 @@ def test_coalesce_twin():
     assert out.tolist() == [[0, 1, 2], [3, 0, 1]] and w.tolist() == [7, 4, 4]
     out, w = coalesce(ei, None, 4)
     assert out.tolist() == [[0, 1, 2], [3, 0, 1]] and w is None
+
+
+def test_host_result_memory_and_copy_threads():
+    """The host side of the default result path (tuned_SIGN._to_host): fresh pageable memory on a 2 MiB boundary
+    that asked for huge pages, and the module's own copy threads (exact copies, any length, reusable pool)."""
+    for n in (1, 1000, (1 << 19) + 3, 3 * (1 << 20) + 17):
+        t = ts._huge_empty(n)
+        assert t.shape == (n,) and t.dtype == torch.float32 and t.is_contiguous() and not t.is_pinned()
+        assert t.data_ptr() % (1 << 21) == 0 or n * 4 < (1 << 21)
+        src = torch.arange(n, dtype=torch.float32)
+        ts._parallel_copy(t, src)
+        assert torch.equal(t, src)
+    assert ts._usable_cpus() >= 1
+    # a second copy reuses the pool; views of a result stay valid after the base name is dropped
+    big = ts._huge_empty(1 << 21)
+    ts._parallel_copy(big, torch.ones(1 << 21))
+    view = big[5:9]
+    del big
+    assert view.tolist() == [1.0, 1.0, 1.0, 1.0]
