@@ -7,6 +7,11 @@ namespace s3grl {
 namespace {
 
 typedef float float4_t __attribute__((ext_vector_type(4)));
+// the same with the alignment of a float: output rows start at column 1 of a [K+1][1+F] block, i.e. anywhere
+// modulo 16 bytes.  gfx950 runs with unaligned global access enabled (dword-aligned wide accesses are legal),
+// so a store through this type is ONE global_store_dwordx4 instead of four dword stores with a 16-byte stride
+// between lanes (4x the store instructions of the epilogue, each touching a quarter of every line)
+typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));
 
 // rows are [K+1][1+F] fp32; the +1 label column makes them 4-byte aligned only.  A folded
 // reversed duplicate gets the same values with the two rows swapped.  acc[i][r][c]: operator i+1,
@@ -41,17 +46,25 @@ __device__ __forceinline__ void write_pair_rows_part(const Job& job, int jid, co
           if constexpr (XROW) {
             const float4_t x0 = *reinterpret_cast<const float4_t*>(xr + coff[c]);
             float* o = out + 1 + coff[c];
+            if (nv == 4) {
+              *reinterpret_cast<float4_u*>(o) = x0;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (e < nv) o[e] = x0[e];
+              for (int e = 0; e < 4; ++e)
+                if (e < nv) o[e] = x0[e];
+            }
           }
 #pragma unroll
           for (int i = I0; i < I1; ++i) {
             const float4_t a = acc[i][r][c];
             float* oi = out + (int64_t)(i + 1) * Fp + 1 + coff[c];
+            if (nv == 4) {
+              *reinterpret_cast<float4_u*>(oi) = a;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (e < nv) oi[e] = a[e];
+              for (int e = 0; e < 4; ++e)
+                if (e < nv) oi[e] = a[e];
+            }
           }
         }
       }
