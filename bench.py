@@ -335,7 +335,13 @@ def cpu_baseline(w, link_index, y, budget_s, max_links):
     fn = {"pos": oracle.get_PoS_prepped_ds, "pos_plus": oracle.get_PoS_Plus_prepped_ds}.get(w.mode)
     done, t0 = 0, time.perf_counter()
     chunk = 50
-    if w.mode == "sop":
+    if w.mode == "sop_restricted":
+        t0 = time.perf_counter()
+        P = oracle.global_normalized_powers(w.A, w.sign_k, np.float32)
+        sel = idx[:min(max_links, 400)]
+        oracle.get_SoP_restricted_ds(P, link_index[:, sel], w.num_hops, w.A, w.X, 1, dtype=np.float32)
+        done = len(sel)
+    elif w.mode == "sop":
         t0 = time.perf_counter()
         P = oracle.global_normalized_powers(w.A, w.sign_k, np.float32)
         sel = idx[:max_links]
@@ -690,7 +696,7 @@ def main():
                        "otherwise load them at the first launch of each kernel family, i.e. inside the first graph / "
                        "plan / run).  None of it is part of a step; cold_run is the figure that includes all of it"}
     links = eng.links(link_index)
-    fixed_rows = w.mode in ("pos", "sop")
+    fixed_rows = w.mode in ("pos", "sop", "sop_restricted")
 
     out = None
     traffic_req = None
@@ -1050,17 +1056,17 @@ def main():
                                   "(SURVEY §8d setup term, f64); included in value like the reference's "
                                   "timed region includes its global powers"},
             }
-        if world == 1 and not args.no_api:
+        if world == 1 and not args.no_api and w.mode != "sop_restricted":   # (not a reference flow: no operator API)
             try:
                 line["end_to_end_api"] = end_to_end_api(w, link_index, y)
             except Exception as e:   # the bench line must not die on the optional leg
                 line["end_to_end_api"] = {"error": repr(e)}
-        if world == 1 and not args.no_cold_run and not args.no_api and not ge.under_profiler():
+        if world == 1 and not args.no_cold_run and not args.no_api and not ge.under_profiler() and w.mode != "sop_restricted":
             line["cold_run"] = cold_run(args.workload)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w, link_index, y, args.cpu_seconds, args.cpu_links)
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
-            if w.mode != "sop":
+            if w.mode not in ("sop", "sop_restricted"):
                 line["cpu_baseline_native"] = cpu_baseline_native(w, link_index, y, args.cpu_native_links)
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -58,7 +58,12 @@ typedef enum s3grl_status {
 typedef enum s3grl_mode {
   S3GRL_MODE_POS = 0,      /* get_PoS_prepped_ds       : rows {src,dst} */
   S3GRL_MODE_POS_PLUS = 1, /* get_PoS_Plus_prepped_ds  : rows {src,dst} + N(src) ∩ N(dst) */
-  S3GRL_MODE_SOP = 2       /* get_SoP_prepped_ds       : global operators, rows {src,dst} */
+  S3GRL_MODE_SOP = 2,      /* get_SoP_prepped_ds       : global operators, rows {src,dst} */
+  S3GRL_MODE_SOP_RESTRICTED = 3 /* NOT a reference flow (its SoP ignores num_hops, tuned_SIGN.py:49-134): the SoP rows
+                              with every operator row restricted to the num_hops-ball of {src,dst} — the optional
+                              twin BASELINE config 3 ("2-hop subgraphs") and SURVEY §8(d) name, reported separately.
+                              x_i[s] = [Â^i[s,s] | Σ_{w in ball, w != d} Â^i[s,w] X[w]] with the GLOBAL Â; through
+                              s3grl_plan_create / s3grl_run like PoS; needs sign_k - 1 <= num_hops */
 } s3grl_mode;
 
 typedef enum s3grl_strategy {

@@ -22,6 +22,7 @@ from .s3grl_oracle import (  # noqa: F401
     get_PoS_Plus_prepped_ds,
     global_normalized_powers,
     get_SoP_prepped_ds,
+    get_SoP_restricted_ds,
     hybrid_combine,
     centre_pool,
     collate_rows,

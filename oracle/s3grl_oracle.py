@@ -354,6 +354,41 @@ def get_SoP_prepped_ds(powers_of_A, link_index, A, x, y, *, dtype=np.float32):
     return out
 
 
+def get_SoP_restricted_ds(powers_of_A, link_index, num_hops, A, x, y, *, dtype=np.float32):
+    """NOT a reference flow — the optional twin SURVEY §8(d) names for BASELINE config 3 ("2-hop subgraphs"): the
+    SoP rows of `get_SoP_prepped_ds` (tuned_SIGN.py:49-134) with every operator row additionally restricted to the
+    `num_hops`-ball of {src, dst} on the unmasked graph (the node set `k_hop_subgraph` extracts, utils.py:53-74):
+        x_i[s] = [ Â^i[s,s] | Σ_{w in ball, w != d} Â^i[s,w] X[w] ].
+    Plain per-link loop over the global powers."""
+    links = np.asarray(_links(link_index), dtype=np.int64).reshape(-1, 2)
+    A = ssp.csr_matrix(A)
+    X = np.asarray(x, dtype=dtype)
+    P = [ssp.csr_matrix(p).astype(dtype) for p in powers_of_A]
+    out = []
+    ones = np.ones((2, 1), dtype=dtype)
+    for s_, d_ in links:
+        ball = {int(s_), int(d_)}
+        fringe = set(ball)
+        for _ in range(int(num_hops)):
+            fringe = neighbors(fringe, A) - ball
+            if not fringe:
+                break
+            ball |= fringe
+        keep = np.zeros(A.shape[0], dtype=bool)
+        keep[list(ball)] = True
+        d = {"x": np.hstack([ones, X[[s_, d_]]]), "y": y, "rows_global": np.array([s_, d_], dtype=np.int64)}
+        for i, Pi in enumerate(P, start=1):
+            rows = []
+            for a, b in ((s_, d_), (d_, s_)):
+                r = Pi[a]
+                w = np.asarray(r.todense(), dtype=dtype).ravel() * keep
+                w[b] = 0
+                rows.append(np.concatenate([[Pi[a, a]], w @ X]))
+            d[f"x{i}"] = np.asarray(rows, dtype=dtype)
+        out.append(d)
+    return out
+
+
 def hybrid_combine(pos_list, sop_list, sign_k):
     """Reference utils.py:472-480: PoS keys kept, SoP x2..xK appended as x{K+1}..x{2K-1}."""
     out = []

@@ -22,7 +22,7 @@ ERR_NO_DEVICE = 6
 ERR_GRAPH_TOO_LARGE = 7
 ERR_SELF_LINK = 8
 
-MODE_POS, MODE_POS_PLUS, MODE_SOP = 0, 1, 2
+MODE_POS, MODE_POS_PLUS, MODE_SOP, MODE_SOP_RESTRICTED = 0, 1, 2, 3
 STRATEGY = {"intersection": 0, "union": 1}
 
 # every symbol include/s3grl.h declares; tests check the library exports all of them

@@ -579,9 +579,17 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
     set_last_error("sign_k must be in 1..8 and num_hops in 0..30");
     return S3GRL_ERR_INVALID_ARGUMENT;
   }
-  if (cfg->mode != S3GRL_MODE_POS && cfg->mode != S3GRL_MODE_POS_PLUS) {
-    set_last_error("s3grl_plan_create handles PoS / PoS Plus; use s3grl_sop_* for SoP");
+  if (cfg->mode != S3GRL_MODE_POS && cfg->mode != S3GRL_MODE_POS_PLUS && cfg->mode != S3GRL_MODE_SOP_RESTRICTED) {
+    set_last_error("s3grl_plan_create handles PoS / PoS Plus / the num_hops-restricted SoP; use s3grl_sop_* for SoP");
     return S3GRL_ERR_INVALID_ARGUMENT;
+  }
+  const bool sop2 = cfg->mode == S3GRL_MODE_SOP_RESTRICTED;
+  if (sop2 && (g->directed || sets || cfg->rw_m > 0 || cfg->max_nodes_per_hop > 0 ||
+               (cfg->ratio_per_hop > 0.0 && cfg->ratio_per_hop < 1.0) || cfg->num_hops < 1 ||
+               cfg->sign_k - 1 > cfg->num_hops)) {
+    set_last_error("the num_hops-restricted SoP needs an undirected graph, plain k-hop balls and sign_k - 1 <= num_hops "
+                   "(the operators' rows must stay inside the ball until the last step)");
+    return S3GRL_ERR_NOT_IMPLEMENTED;
   }
   if ((cfg->directed != 0) != g->directed) {
     set_last_error(g->directed ? "the graph was created with s3grl_graph_create_directed: s3grl_cfg.directed must be 1"
@@ -734,14 +742,14 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   S3GRL_TRY(arena_alloc(ctx, (size_t)L * kMaxLevels, &plan->lvl, own));
   // one-hop plans on big graphs: sizes by intersecting the two sorted rows (no bitmaps, no limit on
   // num_nodes, no node-list hand-over: link_full_kernel merges the rows again)
-  const bool onehop = cfg->num_hops == 1 && !walks && !sampling && onehop_mode_for(g) && g->fwd_indptr;
+  const bool onehop = cfg->num_hops == 1 && !walks && !sampling && onehop_mode_for(g) && g->fwd_indptr && !sop2;
   int32_t* stash = nullptr;
   int slot = 4096;
   if (const char* e = getenv("S3GRL_STASH_SLOT")) slot = std::max(0, atoi(e));   // test hook; 0 = off
   // Which flavour of the link kernel a link takes must not depend on the rest of the list (a link gives the same
   // bits in a sharded and an unsharded run), and the induced-CSR flavour needs the list in the stash: plans that
   // may use it keep the full slot up to 32 GiB of stash (2 M links) instead of shrinking it from 6 GiB on
-  const bool csr_candidate = !onehop && !walks && !sampling && !g->directed && g->r_indptr && !getenv("S3GRL_NO_RELABEL") &&
+  const bool csr_candidate = !sop2 && !onehop && !walks && !sampling && !g->directed && g->r_indptr && !getenv("S3GRL_NO_RELABEL") &&
                              csr_mode_for(g, cfg->num_hops, K, true, true);
   const int64_t stash_cap = csr_candidate ? ((int64_t)32 << 30) : ((int64_t)6 << 30);
   while (slot > 256 && (int64_t)L * slot * 4 > stash_cap) slot >>= 1;
@@ -819,7 +827,7 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   // Plans whose every operator reaches the whole subgraph, on graphs of the bitmap flavour with cached
   // balls: the links run on their induced LDS CSR (s3grl_csr.hip); its classes are cut by the exact entry
   // count, which a sizing kernel of its own produces once the node offsets are known
-  const bool csr_plan = !(cfg->flags & S3GRL_FLAG_COUNT_ONLY) && stash != nullptr && balls &&
+  const bool csr_plan = !sop2 && !(cfg->flags & S3GRL_FLAG_COUNT_ONLY) && stash != nullptr && balls &&
                         csr_mode_for(g, cfg->num_hops, K, balls, relabel && !walks && !sampling && !onehop);
   // PoS has no common-neighbour rows: the LDS classes are known without a round trip
   if (!plus && !csr_plan)
@@ -949,7 +957,7 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
                          plan->c_coef, plan->jobs, plan->job_z, plan->job_lim, plan->row_nodes, plan->lvl, st,
                          st + kStatRow, st + 2 * kStatRow, smp, stash, slot, e_cap, max_n,
                          relabel ? g->old_of_new : nullptr, relabel ? g->new_of_old : nullptr, split_t, seg_shift,
-                         x_cap, csr_cnt, csr_e));
+                         x_cap, csr_cnt, csr_e, sop2 ? 1 : 0));
   if (split_t > 0) {   // pieces per job and their total (read with the statistics below)
     int32_t* pcnt;
     S3GRL_TRY(arena_alloc(ctx, (size_t)njobs, &pcnt, tr));

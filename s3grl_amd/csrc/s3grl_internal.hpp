@@ -560,7 +560,7 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           int slot = 0, const int32_t* e_cap = nullptr, int64_t max_nodes = 0,
                           const int32_t* old_of_new = nullptr, const int32_t* new_of_old = nullptr,
                           int split_t = 0, int seg_shift = 0, const int64_t* x_cap = nullptr,
-                          const uint16_t* csr_cnt = nullptr, const int32_t* csr_e = nullptr);
+                          const uint16_t* csr_cnt = nullptr, const int32_t* csr_e = nullptr, int sop2 = 0);
 // pieces of the split jobs: piece_off [njobs + 1] (device) and *total (device scalar) first, the
 // piece arrays once the host knows the total
 s3grl_status launch_split_count(s3grl_context* ctx, const Job* jobs, int64_t njobs, int seg_shift,

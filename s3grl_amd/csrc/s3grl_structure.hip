@@ -848,8 +848,11 @@ __global__ __launch_bounds__(T, S3GRL_LINK_MINW(T)) void link_kernel(
     char* __restrict__ scratch, int64_t scratch_stride, int bm_ext_words, unsigned long long* __restrict__ dbg,
     HopSampling smp, const int32_t* __restrict__ stash, int slot,
     const int32_t* __restrict__ old_of_new, const int32_t* __restrict__ new_of_old, int lo_id,
-    int split_t, int seg_shift, const DirGraph dg) {
+    int split_t, int seg_shift, const DirGraph dg, int sop2) {
   static_assert(!DIRECTED || (!HS && !DM), "directed plans run on the bitmap flavour");
+  // sop2 (S3GRL_MODE_SOP_RESTRICTED): the rows of the GLOBAL operator restricted to the subgraph — D^-1/2 from
+  // the global degrees, the target link NOT removed, the partner's column zeroed in the features and the
+  // label column = the diagonal entry (reference tuned_SIGN.py:71-78,102-113 on the ball instead of all of V)
   extern __shared__ uint32_t smem[];
   // rows walked by the operator passes (pull), by the degree count and by the common-neighbour test
   const int32_t* __restrict__ w_indptr = DIRECTED ? dg.in_indptr : indptr;
@@ -925,6 +928,11 @@ __global__ __launch_bounds__(T, S3GRL_LINK_MINW(T)) void link_kernel(
   float2* nxs = cur + p_alloc;
 
   const int src = (int)links[2 * (int64_t)l], dst = (int)links[2 * (int64_t)l + 1];
+  const int msrc = sop2 ? -2 : src, mdst = sop2 ? -3 : dst;   // the endpoints as far as the MASKING is concerned
+  auto gdinv = [&](int v) -> float {                          // sop2: D^-1/2 of the global degree
+    const int d = indptr[v + 1] - indptr[v];
+    return d > 0 ? 1.0f / sqrtf((float)d) : 0.0f;
+  };
 
   // ---- BFS on the unmasked graph (reference utils.py:53-74) --------------------------------
   int nlev;
@@ -1048,7 +1056,13 @@ __global__ __launch_bounds__(T, S3GRL_LINK_MINW(T)) void link_kernel(
   int edges_local = 0;
   int edges_exact = -1;   // set when a pass of pair 0 walked every row of S
   int dinv_rows = DIRECTED ? n : lvl_end[min(max_row_hop, nlev - 1)];
-  if (!DIRECTED && !walks_on(ws) && !sampling_on(smp) && hops > max_row_hop) {
+  if (sop2) {
+    for (int t = tid; t < dinv_rows; t += T) {
+      const int v = list[t];
+      dinvP[p_index_of_row(t, v)] = gdinv(v);
+      edges_local += indptr[v + 1] - indptr[v];
+    }
+  } else if (!DIRECTED && !walks_on(ws) && !sampling_on(smp) && hops > max_row_hop) {
     // A plain BFS to `hops` holds every neighbour of a node that sits below hop `hops`: the
     // subgraph degree of such a row is its global degree, minus the masked target link at src and
     // dst (utils.py:79-80).  No walk.
@@ -1066,7 +1080,7 @@ __global__ __launch_bounds__(T, S3GRL_LINK_MINW(T)) void link_kernel(
         [&](RowAcc& a, int v, int u, bool valid) {
           // the target link is masked (utils.py:79-80): one compare per neighbour against the
           // row's partner (-1 for every row but src and dst; hoisted out of the neighbour loop)
-          const int mp = v == src ? dst : (v == dst ? src : -1);
+          const int mp = v == msrc ? dst : (v == mdst ? src : -1);
           a.n += (valid && in_s(u) && u != mp) ? 1 : 0;
         },
         [&](RowAcc& a, int t, int v) {
@@ -1097,7 +1111,7 @@ __global__ __launch_bounds__(T, S3GRL_LINK_MINW(T)) void link_kernel(
   // measured a loss: USAir's 1-hop subgraphs are nearly as dense as their global rows (+20 % on
   // the link kernel), and on PubMed K=5 the matrix of a 300-500-node subgraph pushes the link
   // into a bigger LDS class (+10 %); the collab-scale config gains 12 %.
-  const bool use_bm = HS && !DM && !GS && K >= 2 && p == n && p_alloc == n_alloc && n <= kBmMaxNodes;
+  const bool use_bm = HS && !DM && !GS && K >= 2 && p == n && p_alloc == n_alloc && n <= kBmMaxNodes && !sop2;
   uint32_t* bm = reinterpret_cast<uint32_t*>(nxs + p_alloc);              // [n][WB]
   uint16_t* pos_of_rank = reinterpret_cast<uint16_t*>(bm + (use_bm ? n * WB : 0));   // bitmap flavour
   uint16_t* rank_of_pos = pos_of_rank + n;
@@ -1268,7 +1282,7 @@ __global__ __launch_bounds__(T, S3GRL_LINK_MINW(T)) void link_kernel(
               on = member && (wp & bit);
               col = r;
             }
-            const int mp = v == src ? dst : (v == dst ? src : -1);
+            const int mp = v == msrc ? dst : (v == mdst ? src : -1);
             member = member && u != mp;
             on = on && u != mp;
             if (build_bm && member) {
@@ -1283,7 +1297,7 @@ __global__ __launch_bounds__(T, S3GRL_LINK_MINW(T)) void link_kernel(
             const int w = p_index_of_row(t, v);
             float dw;
             if (t >= dinv_rows) {   // first pass to reach this row: its degree comes from this walk
-              dw = a.n > 0 ? 1.0f / sqrtf((float)a.n) : 0.0f;
+              dw = sop2 ? gdinv(v) : (a.n > 0 ? 1.0f / sqrtf((float)a.n) : 0.0f);
               dinvP[w] = dw;
               edges_local += a.n;
             } else {
@@ -1291,7 +1305,8 @@ __global__ __launch_bounds__(T, S3GRL_LINK_MINW(T)) void link_kernel(
             }
             const float rx = dw * a.x, ry = dw * a.y;
             s_out[w] = make_float2(dw * rx, dw * ry);
-            coef[cidx(i, t)] = make_float2(rx, ry);
+            // (sop2: the partner's column is zeroed in the product with X — tuned_SIGN.py:73-76)
+            coef[cidx(i, t)] = make_float2((sop2 && v == dst) ? 0.f : rx, (sop2 && v == src) ? 0.f : ry);
             // label column of operator i+1: Σ_w r[w] z_w = r[src] + r[dst]  (tuned_SIGN.py:177-185)
             if (v == src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
             if (v == dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
@@ -1338,7 +1353,7 @@ __global__ __launch_bounds__(T, S3GRL_LINK_MINW(T)) void link_kernel(
               member = valid && (wv & bit);
               on = member && (wp & bit);
             }
-            const int mp = v == src ? dst : (v == dst ? src : -1);
+            const int mp = v == msrc ? dst : (v == mdst ? src : -1);
             const bool masked = u == mp;
             member = member && !masked;
             on = on && !masked;
@@ -1351,9 +1366,9 @@ __global__ __launch_bounds__(T, S3GRL_LINK_MINW(T)) void link_kernel(
             if (t < support) {
               // (directed: a.n counted predecessors; D^-1/2 is the out-degree's, known for all of S)
               const float dw = DIRECTED ? dinvP[p_index_of_row(t, v)]
-                                        : (a.n > 0 ? 1.0f / sqrtf((float)a.n) : 0.0f);
+                                        : (sop2 ? gdinv(v) : (a.n > 0 ? 1.0f / sqrtf((float)a.n) : 0.0f));
               const float rx = dw * a.x, ry = dw * a.y;
-              coef[cidx(i, t)] = make_float2(rx, ry);
+              coef[cidx(i, t)] = make_float2((sop2 && v == dst) ? 0.f : rx, (sop2 && v == src) ? 0.f : ry);
               if (v == src) { zbuf[(0 * K + i) * 2] = rx; zbuf[(0 * K + i) * 2 + 1] = ry; }
               if (v == dst) { zbuf[(1 * K + i) * 2] = rx; zbuf[(1 * K + i) * 2 + 1] = ry; }
             }
@@ -1364,7 +1379,9 @@ __global__ __launch_bounds__(T, S3GRL_LINK_MINW(T)) void link_kernel(
     S3GRL_STAMP(4)
     if (tid < 2 * K) {
       const int i = tid >> 1, r = tid & 1;
-      job_z[(jid * K + i) * 2 + r] = zbuf[(0 * K + i) * 2 + r] + zbuf[(1 * K + i) * 2 + r];
+      // label column of operator i+1: r[src] + r[dst]; sop2: the diagonal entry — r_a[src] for row a, r_b[dst] for b
+      job_z[(jid * K + i) * 2 + r] = sop2 ? zbuf[(r * K + i) * 2 + r]
+                                          : zbuf[(0 * K + i) * 2 + r] + zbuf[(1 * K + i) * 2 + r];
     }
     // operator i+1 reaches the list prefix within i+1 hops of the row (the limits of the passes
     // above): the gather skips its multiply-adds beyond that
@@ -2019,6 +2036,7 @@ struct LinkArgs {
   int hub_slice_grid;
   const uint16_t* csr_cnt;                  // induced-CSR flavour (s3grl_csr.hip): members per list entry,
   const int32_t* csr_e;                     // ... and per link
+  int sop2;                                 // S3GRL_MODE_SOP_RESTRICTED: global normalisation, nothing masked (link_kernel)
 };
 
 // One-hop full-reach classes (link_full_kernel).  Small classes run one wavefront per link (no
@@ -2074,7 +2092,7 @@ s3grl_status launch_link_class_g(s3grl_context* ctx, const LinkArgs& a, int64_t 
                      reinterpret_cast<unsigned long long*>(a.tot_support),
                      reinterpret_cast<unsigned long long*>(a.tot_vol), a.scratch, a.scratch_stride,
                      GS ? a.bm_ext_words : 0, a.dbg, a.smp, a.stash, a.slot, a.old_of_new, a.new_of_old, a.lo_id, a.split_t, a.seg_shift,
-                     a.dg);
+                     a.dg, a.sop2);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -2279,7 +2297,7 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
                           HopSampling smp, const int32_t* stash, int slot, const int32_t* e_cap,
                           int64_t max_nodes, const int32_t* old_of_new, const int32_t* new_of_old,
                           int split_t, int seg_shift, const int64_t* x_cap, const uint16_t* csr_cnt,
-                          const int32_t* csr_e) {
+                          const int32_t* csr_e, int sop2) {
   if (L == 0) return S3GRL_OK;
   // links too large for LDS keep their lists in HBM scratch: one 256-byte aligned slice each
   Transient scratch_owner{ctx, {}};
@@ -2310,7 +2328,7 @@ s3grl_status launch_links(s3grl_context* ctx, const s3grl_graph* g, const int64_
              smp, stash, slot, e_cap, nullptr, 0, 0, 0, old_of_new, new_of_old,
              (old_of_new && !getenv("S3GRL_NO_LEAF_WALK")) ? g->deg_le2_from : -1, split_t, seg_shift,
              DirGraph{g->out_indptr, g->out_indices, g->in_indptr, g->in_indices}, bm_ext_words, gs_chunk, 0,
-             x_cap, nullptr, 0, 0, csr_cnt, csr_e};
+             x_cap, nullptr, 0, 0, csr_cnt, csr_e, sop2};
   if (class_count_host[kHubBase + kHubClasses] > 0) {   // list of found edges (uint32) + columns (2 x uint16) per slice
     const int64_t xmax = ((int64_t)class_count_host[29] + 63) / 64 * 64;
     a.hub_slice_words = 2 * xmax;

@@ -432,7 +432,7 @@ class Engine:
              directed=False, full_stats=False, fold_reversed=True, rw=None, ratio_per_hop=1.0,
              max_nodes_per_hop=None, seed=0, count_only=False, node_sets=None):
         cfg = N.Cfg()
-        cfg.mode = {"pos": N.MODE_POS, "pos_plus": N.MODE_POS_PLUS}[mode]
+        cfg.mode = {"pos": N.MODE_POS, "pos_plus": N.MODE_POS_PLUS, "sop_restricted": N.MODE_SOP_RESTRICTED}[mode]
         cfg.num_hops = int(num_hops)
         cfg.sign_k = int(sign_k)
         if strategy not in N.STRATEGY:
@@ -474,7 +474,10 @@ class Engine:
     def precompute(self, graph, x, links, *, mode="pos", num_hops=1, sign_k=3,
                    strategy="intersection", directed=False, out=None, rw=None, ratio_per_hop=1.0,
                    max_nodes_per_hop=None, seed=0, node_sets=None, multiplicity=None):
-        """links: int64 [L,2] device tensor (see `links()`); x: fp32 [N,F] device tensor."""
+        """links: int64 [L,2] device tensor (see `links()`); x: fp32 [N,F] device tensor.
+        mode: "pos", "pos_plus", "sop", "hybrid" (the reference's flows) or "sop_restricted" — NOT a reference
+        flow: the SoP rows with every operator row restricted to the `num_hops`-ball of {src, dst} (BASELINE
+        config 3's "2-hop subgraphs", SURVEY §8d's optional twin; needs sign_k - 1 <= num_hops)."""
         if x is None:
             N.check(N.ERR_NO_FEATURES, "precompute")
         if mode == "hybrid":
@@ -487,6 +490,8 @@ class Engine:
             sop = self.precompute(graph, x, links, mode="sop", sign_k=sign_k, multiplicity=multiplicity)
             rows = torch.cat([pos.rows, sop.rows[:, 2:, :]], dim=1)
             return Precomputed(rows, pos.row_ptr, pos.row_nodes, dict(pos.stats))
+        if mode == "sop_restricted" and multiplicity is not None:
+            raise NotImplementedError("the num_hops-restricted SoP takes a coalesced graph (no multiplicities)")
         if mode == "sop":
             sop = Sop(self, graph, x, sign_k, multiplicity)
             try:

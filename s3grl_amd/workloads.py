@@ -260,6 +260,11 @@ def make(name):
         sp = edge_split(n, e, seed=2)
         return Workload(name, sp, init_degree_features(sparse_uniform_features(n, 500, 50, 2), sp.A),
                         "sop", 2, 3)
+    if name == "pubmed_sop_k3_2hop":   # config 3's optional twin: SoP rows restricted to the 2-hop ball —
+        n, e = load_topology("pubmed")   # NOT the reference's semantics (its SoP ignores num_hops), reported separately
+        sp = edge_split(n, e, seed=2)
+        return Workload(name, sp, init_degree_features(sparse_uniform_features(n, 500, 50, 2), sp.A),
+                        "sop_restricted", 2, 3)
     if name == "cora_posplus_k3":    # config 2
         n, e = load_topology("cora")
         rng = np.random.default_rng(1)

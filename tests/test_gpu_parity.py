@@ -1738,3 +1738,45 @@ def test_sop_on_half_a_million_nodes(eng, K):
     report_errors(f"half_million_nodes_sop[K={K}]", err, err)
     assert err < TOL
     f.close(), G.close()
+
+
+@pytest.mark.parametrize("name,hops,K", [("usair", 2, 3), ("usair", 1, 2), ("cora", 2, 3), ("cora", 3, 3), ("rand300", 2, 2),
+                                          ("star_iso", 2, 3), ("triangle", 1, 2)])
+def test_sop_restricted_to_the_k_hop_ball(eng, name, hops, K):
+    """`mode="sop_restricted"` — NOT a reference flow: the optional twin SURVEY §8(d) names for BASELINE config 3
+    ("2-hop subgraphs"): the SoP rows (tuned_SIGN.py:49-134) with every operator row restricted to the num_hops-ball
+    of {src, dst}.  Against the oracle's twin; operators 1..num_hops equal the unrestricted SoP rows (their
+    support lies inside the ball anyway); reversed duplicates come out as their primaries' rows swapped."""
+    g = load_extract(name)
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = np.random.default_rng(4).standard_normal((n, 9))
+    links = np.concatenate([g["links"], g["links"][:5, ::-1]])
+    G = eng.graph(A)
+    f = eng.features(X)
+    res = eng.precompute(G, f, eng.links(links.T), mode="sop_restricted", num_hops=hops, sign_k=K)
+    P = oracle.global_normalized_powers(A, K, np.float64)
+    ref, ptr, _ = oracle.collate_rows(oracle.get_SoP_restricted_ds(P, links.T, hops, A, X, 1, dtype=np.float64), K)
+    assert np.array_equal(res.row_ptr.cpu().numpy(), ptr)
+    got = res.rows.cpu().numpy()
+    assert rel_err(got, ref) < TOL
+    full = eng.precompute(G, f, eng.links(links.T), mode="sop", sign_k=K).rows.cpu().numpy()
+    for i in range(0, min(hops, K) + 1):
+        assert rel_err(got[:, i], full[:, i]) < TOL
+    L, m = len(links), min(5, len(g["links"]))
+    v = got.reshape(L, 2, K + 1, -1)
+    assert np.array_equal(v[L - m:, 0], v[:m, 1]) and np.array_equal(v[L - m:, 1], v[:m, 0])
+    f.close(), G.close()
+
+
+def test_sop_restricted_errors(eng):
+    g = load_extract("usair")
+    A = csr_from_undirected(int(g["num_nodes"]), g["edges"])
+    G = eng.graph(A)
+    f = eng.features(np.ones((int(g["num_nodes"]), 3)))
+    L = eng.links(g["links"].T)
+    with pytest.raises(NotImplementedError):       # sign_k - 1 > num_hops: the rows would leave the ball earlier
+        eng.precompute(G, f, L, mode="sop_restricted", num_hops=1, sign_k=3)
+    with pytest.raises(NotImplementedError):
+        eng.precompute(G, f, L, mode="sop_restricted", num_hops=2, sign_k=3, ratio_per_hop=0.5)
+    f.close(), G.close()

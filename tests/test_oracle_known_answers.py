@@ -149,3 +149,26 @@ def test_sop_operator_counts_duplicate_edges():
     np.testing.assert_allclose(P[1].toarray()[0], [4 / 6, 0, 2 / np.sqrt(18)])
     Q = oracle.global_normalized_powers(A, 1, np.float64)
     np.testing.assert_allclose(Q[0].toarray()[0, 1], 1 / np.sqrt(2))
+
+
+def test_restricted_sop_twin_equals_sop_inside_the_ball():
+    """The optional twin of SURVEY §8(d) (SoP rows restricted to the num_hops-ball): operator i has its support
+    within i hops, so operators 1..num_hops are the unrestricted ones; with the ball = the whole component all are."""
+    import oracle
+    from conftest import csr_from_undirected, load_extract
+
+    g = load_extract("usair")
+    n = int(g["num_nodes"])
+    A = csr_from_undirected(n, g["edges"])
+    X = np.random.default_rng(4).standard_normal((n, 5))
+    links = g["links"][:8].T
+    P = oracle.global_normalized_powers(A, 3, np.float64)
+    full = oracle.get_SoP_prepped_ds(P, links, A, X, 1, dtype=np.float64)
+    two = oracle.get_SoP_restricted_ds(P, links, 2, A, X, 1, dtype=np.float64)
+    big = oracle.get_SoP_restricted_ds(P, links, 30, A, X, 1, dtype=np.float64)
+    for a, b, c in zip(full, two, big):
+        for i in (1, 2):
+            np.testing.assert_allclose(b[f"x{i}"], a[f"x{i}"], rtol=0, atol=1e-14)
+        assert np.abs(b["x3"] - a["x3"]).max() > 1e-6          # USAir: three hops leave the two-hop ball
+        for i in (1, 2, 3):
+            np.testing.assert_allclose(c[f"x{i}"], a[f"x{i}"], rtol=0, atol=1e-14)

@@ -28,7 +28,7 @@ def stats(tag, wl, kernel):
 
 def main(tag):
     wls = ["pubmed_pos_k3", "pubmed_pos_k3_dense", "pubmed_sop_k3", "pubmed_pos_k5", "collab_pos_k3", "cora_posplus_k3",
-           "cora_posplus_k3_real", "usair_pos_k2"]
+           "cora_posplus_k3_real", "usair_pos_k2", "pubmed_sop_k3_2hop"]
     print("| workload | link pairs/s | ms/step | structure | link kernels | dominant kernel | ms (bench / rocprof avg) | bound | frac | L2 hit |")
     print("|---|---|---|---|---|---|---|---|---|---|")
     for wl in wls:

@@ -34,7 +34,7 @@ done
 fi
 if [ "$PART" != a ]; then
 cd $R
-for wl in pubmed_pos_k3_dense pubmed_pos_k5 collab_pos_k3 cora_posplus_k3 cora_posplus_k3_real usair_pos_k2; do
+for wl in pubmed_pos_k3_dense pubmed_pos_k5 collab_pos_k3 cora_posplus_k3 cora_posplus_k3_real usair_pos_k2 pubmed_sop_k3_2hop; do
   timeout -k 10 300 python3 bench.py --workload $wl --collect-pmc > $O/bench_$wl.json 2> $O/bench_$wl.err || rc=1
 done
 fi
