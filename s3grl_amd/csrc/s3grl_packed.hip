@@ -725,7 +725,9 @@ s3grl_status launch_packed_k(s3grl_context* ctx, const s3grl_plan* p, const Gath
                              const s3grl_features* f, float* rows) {
   hipStream_t stream = ctx->stream;
   const unsigned gx = (unsigned)((v.njobs + kWavesPerBlock - 1) / kWavesPerBlock);
-  if (const char* proto = getenv("S3GRL_GATHER_PROTO")) {   // timing-only experiment: see gather_last_proto_kernel
+  // timing-only experiment (see gather_last_proto_kernel); instantiated for the headline's sign_k = 3 only
+  if (const char* proto = K == 3 ? getenv("S3GRL_GATHER_PROTO") : nullptr) {
+   if constexpr (K == 3) {
     const uint32_t db = (uint32_t)((f->pk_chunks + 1) * 16);
 #define S3GRL_PROTO(UU, DBB, WW)                                                                               \
   hipLaunchKernelGGL((gather_last_proto_kernel<K, UU, DBB, WW>), dim3((unsigned)v.njobs, (unsigned)f->tiles),   \
@@ -773,6 +775,7 @@ s3grl_status launch_packed_k(s3grl_context* ctx, const s3grl_plan* p, const Gath
 #undef S3GRL_PROTO
     S3GRL_HIP_TRY(hipGetLastError());
     return S3GRL_OK;
+   }
   }
   static const bool masked = !getenv("S3GRL_GATHER_UNMASKED");   // comparison hook: the unconditional loads
   const uint32_t data_bytes = (uint32_t)((f->pk_chunks + 1) * 16);
