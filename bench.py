@@ -922,7 +922,7 @@ def main():
             path_bytes, gather_all, gather_bytes = algorithmic_bytes(stats, F, K)
             launches = max(tm["gather_launches"], 1.0)
             gather_ms = tm["gather_ms"] / launches
-            kname = "gather_packed_kernel" if x.is_packed else ("gather_half_kernel" if F <= 128 else "gather_kernel")
+            kname = "gather_packed_kernel" if x.is_packed else ("gather_narrow_kernel" if F <= 128 else "gather_kernel")
             traffic, traffic_source, l2_hit = None, None, None
             if args.collect_pmc and world == 1:
                 # (the child runs ONE step: the sum over the family's dispatches is the launch of a step)

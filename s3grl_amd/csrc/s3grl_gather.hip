@@ -21,8 +21,14 @@
 namespace s3grl {
 namespace {
 
-constexpr int kWavesPerBlock = 4;   // fabric-bound: 1 wave per workgroup measured the same (24.1 vs 23.5 ms)
+#ifndef S3GRL_GATHER_WPB
+#define S3GRL_GATHER_WPB 4
+#endif
+constexpr int kWavesPerBlock = S3GRL_GATHER_WPB;   // fabric-bound: 1 wave per workgroup measured the same (24.1 vs 23.5 ms)
 constexpr int kUnroll = 8;  // rows of X in flight per wavefront (8: 23.1 ms, 4: 23.6 ms on PubMed)
+#ifndef S3GRL_GATHER_NARROW_UNROLL
+#define S3GRL_GATHER_NARROW_UNROLL 8
+#endif
 
 template <int K, int CH>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_kernel(
@@ -104,21 +110,26 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_kernel(
   write_pair_rows<K, CH>(job, jid, acc, coff, cok, job_z, X, ldx, F, rows, blockIdx.y == 0);
 }
 
-// F <= 128 (node2vec / ogbl-style features): a row of X is at most 512 bytes, i.e. 32 lanes x 16 B —
-// with one row per wave-load half of the wavefront would idle in every load and every multiply-add
-// (the collab-scale config: 128 features).  Here the two halves of the wavefront take ALTERNATE list
-// entries (even entries lanes 0..31, odd entries lanes 32..63): one load instruction fetches two rows,
-// ids and coefficients still arrive through the scalar cache and are picked per half with one
-// v_cndmask each.  The halves' partial sums are added at the end (lane l + lane l+32): a fixed order.
+// F <= 128 (node2vec / ogbl-style features: the collab-scale config has 128): a row of X is at most 512 bytes.
+// A lane owns TWO columns (8 bytes), so that one wave-load fetches one whole row with every lane at work, the
+// row's address is scalar arithmetic (the id comes through the scalar cache: base in SGPRs + a constant lane
+// offset, no vector instruction) and its coefficients are scalar operands of the multiply-adds: K·2 packed
+// multiply-adds per row and nothing else on the vector unit.
+// (Until round 4 the two HALVES of the wavefront took alternate list entries with four columns per lane; picking
+// each half's id and coefficients from the scalar pair cost three vector instructions per pick and the 64-bit
+// row address six, two of them quarter-rate — 344 vector instructions per 16 rows, 96 of them multiply-adds, the
+// vector unit 77 % busy: the kernel was bound by its own address arithmetic.  7.1 -> see DESIGN.md Part II.)
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef float float2_u __attribute__((ext_vector_type(2), aligned(4)));   // (see float4_u in s3grl_gather_common.hpp)
+
 template <int K>
-__global__ __launch_bounds__(kWavesPerBlock * 64) void gather_half_kernel(
+__global__ __launch_bounds__(kWavesPerBlock * 64) void gather_narrow_kernel(
     const Job* __restrict__ jobs, int njobs, const int32_t* __restrict__ c_ids,
     const float* __restrict__ c_coef, const float* __restrict__ job_z, const float* __restrict__ X,
     int64_t ldx, int F, float* __restrict__ rows_out, float* __restrict__ prows,
     const int32_t* __restrict__ job_order) {
-  constexpr int U = 8;   // pairs of list entries per trip: 16 rows of X in flight per wavefront
+  constexpr int U = S3GRL_GATHER_NARROW_UNROLL;   // rows of X in flight per wavefront
   const int lane = threadIdx.x & 63;
-  const bool odd = lane >= 32;
   const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
   if (wid >= njobs) return;
   const int jid = job_order ? __builtin_amdgcn_readfirstlane(job_order[wid]) : wid;
@@ -128,60 +139,100 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_half_kernel(
   const int cnt = __builtin_amdgcn_readfirstlane(job.support);
   const int32_t* __restrict__ ids = c_ids + job.ids_off;
   const float2* __restrict__ cf = reinterpret_cast<const float2*>(c_coef) + job.coef_off;
-  int coff[1] = {(lane & 31) * 4};
-  const bool col_ok = coff[0] < F;
-  float4_t acc[K][2][1];
+  const int coff = lane * 2;
+  const bool col_ok = coff < F;   // (rows of X are padded to a multiple of 4 floats: both columns are readable)
+  // every load unconditional: a lane beyond F reads the row's first columns and never writes its sums
+  const uint32_t voff = (uint32_t)(col_ok ? coff : 0) * 4u;
+  float2_t acc[K][2];
 #pragma unroll
   for (int i = 0; i < K; ++i) {
-    acc[i][0][0] = (float4_t)(0.f);
-    acc[i][1][0] = (float4_t)(0.f);
+    acc[i][0] = (float2_t)(0.f);
+    acc[i][1] = (float2_t)(0.f);
   }
-  int j = 0;
-  for (; j + 2 * U <= cnt; j += 2 * U) {
+  const uint32_t row_bytes = (uint32_t)ldx * 4u;   // (launch_k: ldx * 4 < 2^32)
+  auto row_of = [&](int id) -> float2_t {
+    // scalar: unsigned 32 x 32 -> 64 bits (the signed 64-bit product cost ten scalar instructions per row)
+    const char* base = reinterpret_cast<const char*>(X) + (uint64_t)(uint32_t)id * row_bytes;
+    return *reinterpret_cast<const float2_t*>(base + voff);
+  };
+  // One scalar round trip per group instead of two: the ids of group g + 1 are fetched together with the
+  // coefficients of group g, so that a group's row loads go out at the top of its step with nothing to wait for
+  // (measured on config 5 — the kernel waits 74 % of its wave cycles: ids, then rows + coefficients, per group).
+  // (Two row buffers with the loads of group g + 1 under the multiply-adds of g: 6.4 against 6.2 ms; 12 or 16
+  // rows per group spill the scalar registers that hold a group's coefficients: 6.7 / 6.9 ms.)
+  // (The partial last group as one masked group instead of a row at a time, and operator 0's rows fetched up
+  // front: 6.3 against 6.2 ms — not kept.)
+  const int nrow = job.node_b >= 0 ? 2 : 1;
+  const int ng = cnt / U;   // full groups: contiguous, unclamped scalar loads (wide s_load)
+  if (ng > 0) {
     int id[U];
-    float4_t v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int a = ids[j + 2 * u], b = ids[j + 2 * u + 1];   // scalar loads
-      id[u] = odd ? b : a;
+    for (int u = 0; u < U; ++u) id[u] = ids[u];
+    for (int g = 0; g < ng; ++g) {
+      float2_t v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = row_of(id[u]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int jn = min(g + 1, ng - 1) * U;   // (the last group fetches its own ids again)
+#pragma unroll
+      for (int u = 0; u < U; ++u) id[u] = ids[jn + u];
+      float2 q[K][U];
+#pragma unroll
+      for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int u = 0; u < U; ++u) q[i][u] = cf[(int64_t)i * cnt + g * U + u];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < K; ++i) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          acc[i][0] += q[i][u].x * v[u];
+          acc[i][1] += q[i][u].y * v[u];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      v[u] = col_ok ? *reinterpret_cast<const float4_t*>(X + (int64_t)id[u] * ldx + coff[0]) : (float4_t)(0.f);
+  }
+  for (int j = ng * U; j < cnt; ++j) {
+    const float2_t v = row_of(ids[j]);
 #pragma unroll
     for (int i = 0; i < K; ++i) {
+      const float2 q = cf[(int64_t)i * cnt + j];
+      acc[i][0] += q.x * v;
+      acc[i][1] += q.y * v;
+    }
+  }
+  // rows are [K+1][1+F] fp32 (see write_pair_rows_part): operator 0 = X[node], operators 1..K, the label column
+  const int Fp = F + 1;
+  const int64_t rstride = (int64_t)(K + 1) * Fp;
+  const int ncopy = job.mirror_row >= 0 ? 2 : 1;
+  const int nv = min(2, F - coff);
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const float2 qa = cf[(int64_t)i * cnt + j + 2 * u], qb = cf[(int64_t)i * cnt + j + 2 * u + 1];
-        const float qx = odd ? qb.x : qa.x, qy = odd ? qb.y : qa.y;
-        acc[i][0][0] += qx * v[u];
-        acc[i][1][0] += qy * v[u];
+  for (int r = 0; r < 2; ++r) {
+    if (r >= nrow) break;
+    const float2_t x0 = row_of(r == 0 ? job.node_a : job.node_b);
+    for (int m = 0; m < ncopy; ++m) {
+      const int64_t orow = m == 0 ? job.out_row + r : job.mirror_row + (job.mirror_swap ? 1 - r : r);
+      float* __restrict__ out = rows + orow * rstride;
+      if (col_ok) {
+        float* o = out + 1 + coff;
+        if (nv == 2) {
+          *reinterpret_cast<float2_u*>(o) = x0;
+#pragma unroll
+          for (int i = 0; i < K; ++i) *reinterpret_cast<float2_u*>(o + (int64_t)(i + 1) * Fp) = acc[i][r];
+        } else {
+          o[0] = x0[0];
+#pragma unroll
+          for (int i = 0; i < K; ++i) o[(int64_t)(i + 1) * Fp] = acc[i][r][0];
+        }
+      }
+      if (lane <= K) {
+        const float z = lane == 0 ? (float)(r == 0 ? job.z_a : job.z_b)
+                                  : job_z[((int64_t)jid * K + (lane - 1)) * 2 + r];
+        out[(int64_t)lane * Fp] = z;
       }
     }
   }
-  for (; j < cnt; j += 2) {   // at most 2U - 1 entries; the odd half may run past the end
-    const bool has_b = j + 1 < cnt;
-    const int a = ids[j], b = ids[has_b ? j + 1 : j];
-    const int id = odd ? b : a;
-    const bool live = col_ok && (!odd || has_b);
-    const float4_t v = live ? *reinterpret_cast<const float4_t*>(X + (int64_t)id * ldx + coff[0]) : (float4_t)(0.f);
-#pragma unroll
-    for (int i = 0; i < K; ++i) {
-      const float2 qa = cf[(int64_t)i * cnt + j], qb = cf[(int64_t)i * cnt + (has_b ? j + 1 : j)];
-      const float qx = odd ? qb.x : qa.x, qy = odd ? qb.y : qa.y;
-      acc[i][0][0] += qx * v;
-      acc[i][1][0] += qy * v;
-    }
-  }
-  // even + odd entries; afterwards both halves hold the sums, the lower half writes them
-#pragma unroll
-  for (int i = 0; i < K; ++i)
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[i][r][0][e] += __shfl_xor(acc[i][r][0][e], 32);
-  const bool cok[1] = {col_ok && !odd};
-  write_pair_rows<K, 1>(job, jid, acc, coff, cok, job_z, X, ldx, F, rows, true);
 }
 
 template <int K>
@@ -191,8 +242,8 @@ s3grl_status launch_k(s3grl_context* ctx, const Job* jobs, int64_t njobs, const 
   hipStream_t stream = ctx->stream;
   const unsigned gx = (unsigned)((njobs + kWavesPerBlock - 1) / kWavesPerBlock);
   static const bool no_half = getenv("S3GRL_GATHER_NO_HALF") != nullptr;   // comparison hook
-  if (F <= 128 && !no_half) {
-    hipLaunchKernelGGL((gather_half_kernel<K>), dim3(gx, 1), dim3(kWavesPerBlock * 64), 0, stream,
+  if (F <= 128 && !no_half && ldx < ((int64_t)1 << 30)) {
+    hipLaunchKernelGGL((gather_narrow_kernel<K>), dim3(gx, 1), dim3(kWavesPerBlock * 64), 0, stream,
                        jobs, (int)njobs, c_ids, c_coef, job_z, X, ldx, (int)F, rows, prows, job_order);
   } else if (F <= 256) {
     hipLaunchKernelGGL((gather_kernel<K, 1>), dim3(gx, 1), dim3(kWavesPerBlock * 64), 0, stream,

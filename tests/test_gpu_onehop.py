@@ -287,7 +287,8 @@ def test_cached_hub_neighbourhoods_equal_the_per_link_road(eng, monkeypatch, mod
     assert sa == sb and torch.equal(pa, pb) and torch.equal(na, nb_)
     assert all(torch.equal(x, y) for x, y in zip(ea, eb))
     assert not torch.equal(ra, rb)                        # (another summation order: the cache WAS used)
-    assert rel_err(rb.cpu().numpy(), ra.cpu().numpy()) < 3e-6
+    # (fp32 round-off of two summation orders; the narrow gather sums a list front to back)
+    assert rel_err(rb.cpu().numpy(), ra.cpu().numpy()) < 5e-6
     from oracle import c_oracle
 
     ref, ptr, _, _ = c_oracle.pos_rows(links.T, 1, A, X, 3, plus=mode == "pos_plus")
