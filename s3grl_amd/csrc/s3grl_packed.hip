@@ -198,13 +198,19 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) S3GRL_GATHER_OCC void gather_p
 #pragma unroll
       for (int c = 0; c < CH; ++c) acc[i][r][c] = (float4_t)(0.f);
 
+  // a header through the scalar cache: the row id as a 32-bit byte offset on the uniform base (s_load with an
+  // offset register: one shift per row instead of a 64-bit shift and add; build_packed_rows keeps N * 32 < 2^32)
+  auto hdr_of = [&](uint32_t id) __attribute__((always_inline)) -> PackedHdr {
+    static_assert(sizeof(PackedHdr) == 32, "the shift below");
+    return *reinterpret_cast<const PackedHdr*>(reinterpret_cast<const char*>(th) + (id << 5));
+  };
   auto load_hdrs = [&](int g, PackedHdr(&h)[U]) __attribute__((always_inline)) {   // scalar: ids (one wide load), then headers
     uint32_t id[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) id[u] = uid[g * U + u];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < U; ++u) h[u] = th[id[u]];
+    for (int u = 0; u < U; ++u) h[u] = hdr_of(id[u]);
     __builtin_amdgcn_sched_barrier(0);
   };
   // the same in two halves for the steady-state loops: the ids of a group are fetched one step
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) S3GRL_GATHER_OCC void gather_p
   };
   auto hdrs_from = [&](const uint32_t(&id)[U], PackedHdr(&h)[U]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) h[u] = th[id[u]];
+    for (int u = 0; u < U; ++u) h[u] = hdr_of(id[u]);
     __builtin_amdgcn_sched_barrier(0);
   };
   // phase B's form: the ids pass through an opaque statement — without it the header addresses
@@ -229,21 +235,23 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) S3GRL_GATHER_OCC void gather_p
     asm volatile("" : "+s"(idv[0]), "+s"(idv[1]), "+s"(idv[2]), "+s"(idv[3]));
     static_assert(U == 4, "the opaque statement above lists four ids");
 #pragma unroll
-    for (int u = 0; u < U; ++u) h[u] = th[idv[u]];
+    for (int u = 0; u < U; ++u) h[u] = hdr_of(idv[u]);
     __builtin_amdgcn_sched_barrier(0);
   };
   // (valid = false: a group beyond the end of the list — every lane reads as zero)
   auto issue = [&](const PackedHdr(&h)[U], float4_t(&v)[U][CH], bool valid = true) __attribute__((always_inline)) {   // 2U unconditional loads
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t base = (uint32_t)h[u].off;
+      // MASKED: a group beyond the end gets a base whose every chunk address is out of range (one scalar select
+      // per row instead of one per mask word)
+      const uint32_t base = MASKED ? (valid ? (uint32_t)h[u].off : (kOobOffset >> 4)) : (uint32_t)h[u].off;
       const uint32_t a0 = (base + (uint32_t)below(h[u].m0)) << 4;
       const uint32_t a1 = (base + (uint32_t)__popcll(h[u].m0) + (uint32_t)below(h[u].m1)) << 4;
       if constexpr (MASKED) {
         v[u][0] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(
-                                                   rsrc, (int)select_or_oob(valid ? h[u].m0 : 0ull, a0, oobv), 0, 0));
+                                                   rsrc, (int)select_or_oob(h[u].m0, a0, oobv), 0, 0));
         v[u][1] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(
-                                                   rsrc, (int)select_or_oob(valid ? h[u].m1 : 0ull, a1, oobv), 0, 0));
+                                                   rsrc, (int)select_or_oob(h[u].m1, a1, oobv), 0, 0));
       } else {
         v[u][0] = *reinterpret_cast<const float4_t*>(bytes + select_by_mask(valid ? h[u].m0 : 0ull, a0));
         v[u][1] = *reinterpret_cast<const float4_t*>(bytes + select_by_mask(valid ? h[u].m1 : 0ull, a1));
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) S3GRL_GATHER_OCC void gather_p
   auto tail_rows = [&](auto first, auto last, int j0) __attribute__((always_inline)) {   // at most U-1 rows, operators first+1 .. last
     constexpr int I0 = decltype(first)::value, I1 = decltype(last)::value;
     for (int j = j0; j < cnt; ++j) {
-      const PackedHdr h = th[uid[j]];
+      const PackedHdr h = hdr_of(uid[j]);
       const uint32_t base = (uint32_t)h.off;
       const uint32_t a0 = (base + (uint32_t)below(h.m0)) << 4;
       const uint32_t a1 = (base + (uint32_t)__popcll(h.m0) + (uint32_t)below(h.m1)) << 4;
@@ -837,6 +845,7 @@ s3grl_status build_packed_rows(s3grl_context* ctx, s3grl_features* f, double max
   f->pk_chunks = chunks;
   if ((double)chunks > max_density * slots) return S3GRL_OK;
   if ((chunks + 1) * 16 >= ((int64_t)1 << 31)) return S3GRL_OK;   // 32-bit byte offsets, and room for the out-of-range one
+  if (N >= ((int64_t)1 << 27)) return S3GRL_OK;                   // 32-bit byte offsets into a tile's headers
   void* hdr = nullptr;
   void* data = nullptr;
   S3GRL_TRY(ctx->arena.alloc((size_t)items * sizeof(PackedHdr), &hdr));

@@ -14,10 +14,10 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" \
            "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" \
            "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY" \
-           "SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM SQ_INSTS_FLAT" \
-           "FETCH_SIZE WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
-           "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum" \
-           "TCP_TA_TCP_STATE_READ_sum TCP_GATE_EN1_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"; do
+           "SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM SQ_INSTS_FLAT"; do
+  # (a sixth pass with FETCH_SIZE WRITE_SIZE aborted inside rocprofv3 on collab_pos_k3 and hung the call:
+  # the byte counters come from bench.py's own passes, tools/pmc_passes.py)
+  echo "pass $((i+1)): $set"
   i=$((i+1))
   S3GRL_SERIAL_CLASSES=1 rocprofv3 --pmc $set -d "$out/p$i" -o p --output-format csv -- \
     python3 bench.py --workload $wl --steps 1 --warmup 0 --no-cpu-baseline --no-api --no-pmc --no-cold-run \
