@@ -832,7 +832,7 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   // PoS has no common-neighbour rows: the LDS classes are known without a round trip
   if (!plus && !csr_plan)
     S3GRL_TRY(launch_classify(ctx, g, 1, K, plan->n_nodes, p_nodes, lvl_max, L, class_count, class_list,
-                              !sampling && !g->directed, e_cap, stash ? slot : 0, perm, x_cap));
+                              !sampling && !g->directed, e_cap, stash ? slot : 0, perm, x_cap, nullptr, true));
   S3GRL_HIP_TRY(hipMemcpyAsync(hs, ds, 56 * 8, hipMemcpyDeviceToHost, ctx->stream));   // scalars + class counts
   S3GRL_HIP_TRY(hipMemcpyAsync(ctx->h_stats + 3 * kStatRow, st + 3 * kStatRow, 2 * kStatRow * sizeof(int64_t),
                                hipMemcpyDeviceToHost, ctx->stream));
@@ -863,7 +863,8 @@ static s3grl_status plan_create_impl(s3grl_context* ctx, const s3grl_graph* g, c
   }
   if (plus || csr_plan) {
     S3GRL_TRY(launch_classify(ctx, g, plus ? cn_cap : 1, K, plan->n_nodes, p_nodes, lvl_max, L, class_count,
-                              class_list, !sampling && !g->directed, e_cap, stash ? slot : 0, perm, x_cap, csr_e));
+                              class_list, !sampling && !g->directed, e_cap, stash ? slot : 0, perm, x_cap, csr_e,
+                              !plus));
     S3GRL_HIP_TRY(hipMemcpyAsync(hs + 32, ds + 32, 24 * 8, hipMemcpyDeviceToHost, ctx->stream));
     S3GRL_HIP_TRY(hipStreamSynchronize(ctx->stream));
   }

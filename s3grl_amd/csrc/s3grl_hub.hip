@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 
@@ -883,6 +884,243 @@ s3grl_status launch_hub_class(s3grl_context* ctx, const HubLinkArgs& a, int K, i
     case 6: return launch_hub_k<6>(a, cls, class_list, count, stream);
     case 7: return launch_hub_k<7>(a, cls, class_list, count, stream);
     case 8: return launch_hub_k<8>(a, cls, class_list, count, stream);
+    default: return S3GRL_ERR_INVALID_ARGUMENT;
+  }
+}
+
+// ---- links of at most 32 / 64 nodes: half a wavefront / a wavefront each, one lane per node ---------------------
+namespace {
+
+// lanes of a group (W = 32: a half, `hb` = 0 / 32; W = 64: the wavefront, hb = 0) exchange through full-width
+// shuffles with absolute lane numbers
+__device__ __forceinline__ int hshfl(int v, int idx, int hb) { return __shfl(v, hb + idx); }
+__device__ __forceinline__ float hshflf(float v, int idx, int hb) { return __shfl(v, hb + idx); }
+template <int W>
+__device__ __forceinline__ unsigned long long hballot(bool p, int hb) {
+  const unsigned long long b = __ballot(p);
+  return W == 32 ? (unsigned long long)(uint32_t)(b >> hb) : b;
+}
+// LDS written by some lanes of this wavefront, read by others (a wavefront's LDS instructions complete in
+// order; the fence keeps the compiler from moving them)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// first index in [0, len) whose value (lane idx of `vals`, ascending) is >= x; every lane runs all the steps
+template <int W>
+__device__ __forceinline__ int hlower_bound(int vals, int len, int x, int hb) {
+  int lo = 0, hi = len;
+#pragma unroll
+  for (int st = 0; st < (W == 32 ? 6 : 7); ++st) {
+    const int mid = (lo + hi) >> 1;
+    const int y = hshfl(vals, min(mid, W - 1), hb);
+    const bool go = lo < hi;
+    const bool lt = y < x;
+    lo = go && lt ? mid + 1 : lo;
+    hi = go && !lt ? mid : hi;
+  }
+  return lo;
+}
+
+constexpr int kTinyThreads = 256;
+
+template <int K, int W>
+__global__ __launch_bounds__(kTinyThreads) void link_tiny_kernel(const TinyLinkArgs a,
+                                                                 const int32_t* __restrict__ class_list, int count) {
+  constexpr int kTinyLinksPerBlock = kTinyThreads / W;
+  using Mask = typename std::conditional<W == 32, uint32_t, unsigned long long>::type;
+  __shared__ int32_t s_list[kTinyLinksPerBlock][W];
+  __shared__ Mask s_adj[kTinyLinksPerBlock][W];
+  __shared__ float2 s_state[kTinyLinksPerBlock][W];
+  const int sub = threadIdx.x / W, t = threadIdx.x & (W - 1), hb = W == 32 ? (threadIdx.x & 32) : 0;
+  const int item = blockIdx.x * kTinyLinksPerBlock + sub;
+  if (item >= count) return;   // (no workgroup barrier below: a half may leave)
+  const int32_t* __restrict__ indptr = a.indptr;
+  const int32_t* __restrict__ indices = a.indices;
+  auto ext = [&](int v) -> int { return a.old_of_new ? a.old_of_new[v] : v; };
+  const int l = class_list[item];
+  const int64_t noff = a.node_off[l];
+  const int n = (int)(a.node_off[l + 1] - noff);
+  const int mirror = a.mirror_of ? a.mirror_of[l] : -1;
+  const int src = (int)a.links[2 * (int64_t)l], dst = (int)a.links[2 * (int64_t)l + 1];
+  const int bs = indptr[src], bd = indptr[dst];
+  const int cs = indptr[src + 1] - bs, cd = indptr[dst + 1] - bd;   // <= W each: n <= W
+  int32_t* list = s_list[sub];
+  Mask* adjw = s_adj[sub];
+  float2* state = s_state[sub];
+  constexpr int kNone = 0x7fffffff;
+
+  // ---- S in canonical order (link_full_kernel's): {min, max}, then N(src) ∪ N(dst) \ {src, dst} ascending ----
+  const int xs = t < cs ? indices[bs + t] : kNone;
+  const int xd = t < cd ? indices[bd + t] : kNone;
+  adjw[t] = 0;
+  const bool mem_s = t < cs && xs != src && xs != dst, mem_d = t < cd && xd != src && xd != dst;
+  const int lb_d = hlower_bound<W>(xd, cd, xs, hb);   // members of row dst below xs (excluded entries counted)
+  const int lb_s = hlower_bound<W>(xs, cs, xd, hb);
+  // (every shuffle outside of divergent control flow: a lane that is switched off hands out nothing)
+  const int at_d = hshfl(xd, min(lb_d, W - 1), hb), at_s = hshfl(xs, min(lb_s, W - 1), hb);
+  const bool dup_s = mem_s && lb_d < cd && at_d == xs;
+  const bool dup_d = mem_d && lb_s < cs && at_s == xd;
+  const bool s_has_s = hballot<W>(t < cs && xs == src, hb) != 0ull, s_has_d = hballot<W>(t < cs && xs == dst, hb) != 0ull;
+  const bool d_has_s = hballot<W>(t < cd && xd == src, hb) != 0ull, d_has_d = hballot<W>(t < cd && xd == dst, hb) != 0ull;
+  const unsigned long long below = (1ull << t) - 1ull;
+  const int cdup_s = __popcll(hballot<W>(dup_s, hb) & below), cdup_d = __popcll(hballot<W>(dup_d, hb) & below);
+  if (mem_s) {   // common members are emitted from row src
+    const int own = t - ((s_has_s && src < xs) ? 1 : 0) - ((s_has_d && dst < xs) ? 1 : 0);
+    const int oth = lb_d - ((d_has_s && src < xs) ? 1 : 0) - ((d_has_d && dst < xs) ? 1 : 0);
+    const int pos = 2 + own + oth - cdup_s;
+    if (pos < n) list[pos] = xs;
+  }
+  if (mem_d && !dup_d) {
+    const int own = t - ((d_has_s && src < xd) ? 1 : 0) - ((d_has_d && dst < xd) ? 1 : 0);
+    const int oth = lb_s - ((s_has_s && src < xd) ? 1 : 0) - ((s_has_d && dst < xd) ? 1 : 0);
+    const int pos = 2 + own + oth - cdup_d;
+    if (pos < n) list[pos] = xd;
+  }
+  if (t == 0) {
+    list[0] = min(src, dst);
+    list[1] = max(src, dst);
+  }
+  wave_lds_sync();
+  const bool live = t < n;
+  const int v = live ? list[t] : kNone;   // this lane's node; lanes 2 .. n-1 ascending
+  if (live) a.c_ids[noff + t] = ext(v);
+  int vol = live ? indptr[v + 1] - indptr[v] : 0;
+
+  // ---- masked induced adjacency through the oriented rows (reference utils.py:76-80), one mask per lane ----
+  const int fb = live ? a.fwd_indptr[v] : 0;
+  const int flen = live ? a.fwd_indptr[v + 1] - fb : 0;
+  int incl = flen;
+#pragma unroll
+  for (int o = 1; o < W; o <<= 1) {
+    const int up = __shfl_up(incl, o);
+    if (t >= o) incl += up;
+  }
+  const int excl = incl - flen;
+  const int walk_total = hshfl(incl, W - 1, hb);
+  const int vsorted = t >= 2 ? v : -1;   // lanes 0, 1 hold the endpoints (any order): searched apart
+  const int v0 = hshfl(v, 0, hb), v1 = hshfl(v, 1, hb);
+  for (int e0 = 0; e0 < walk_total; e0 += W) {
+    const int e = e0 + t;
+    // the row holding entry e: last r with excl[r] <= e  =  (first r with excl[r] > e) - 1
+    const int first_gt = hlower_bound<W>(excl, n, e + 1, hb);
+    const int row = max(first_gt - 1, 0);
+    const int rstart = hshfl(fb, row, hb), roff = hshfl(excl, row, hb), vi = hshfl(v, row, hb);
+    const bool valid = e < walk_total;
+    const int u = valid ? a.fwd_indices[rstart + (e - roff)] : -1;
+    const int p = hlower_bound<W>(vsorted, n, u, hb);   // (lanes 0, 1 read as -1: below every id)
+    const int at_p = hshfl(v, min(p, W - 1), hb);
+    int j = -1;
+    if (u == v0) j = 0;
+    else if (u == v1) j = 1;
+    else if (p >= 2 && p < n && at_p == u) j = p;
+    const bool target = (vi == src && u == dst) || (vi == dst && u == src);
+    if (valid && j >= 0 && !target) {
+      atomicOr(&adjw[row], (Mask)1 << j);
+      if (row != j) atomicOr(&adjw[j], (Mask)1 << row);
+    }
+  }
+  wave_lds_sync();
+  const Mask adj = live ? adjw[t] : (Mask)0;
+  const int dg = __popcll((unsigned long long)adj);
+  const float dinv = dg > 0 ? 1.0f / sqrtf((float)dg) : 0.0f;
+  int edges = dg;
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) {
+    edges += __shfl_xor(edges, o);
+    vol += __shfl_xor(vol, o);
+  }
+
+  // ---- the row pair (src, dst): K pulls, a row summed in ascending local id ------------------------------------
+  const int pos_src = src < dst ? 0 : 1, pos_dst = 1 - pos_src;
+  const int64_t rp = a.row_ptr[l];
+  const int64_t mrp = mirror >= 0 ? a.row_ptr[mirror] : -1;
+  const int64_t jid = a.job_off[l];
+  const int64_t coff = a.coef_off ? a.coef_off[jid] : noff;
+  float2* __restrict__ coef = reinterpret_cast<float2*>(a.c_coef) + coff * K;   // [K][n] float2
+  float sx = t == pos_src ? dinv : 0.f, sy = t == pos_dst ? dinv : 0.f;
+#pragma unroll 1
+  for (int i = 0; i < K; ++i) {
+    state[t] = make_float2(sx, sy);
+    wave_lds_sync();
+    float ax = 0.f, ay = 0.f;
+    Mask m = adj;
+    while (m) {
+      const int u = __ffsll((unsigned long long)m) - 1;
+      m &= m - 1;
+      const float2 sv = state[u];
+      ax += sv.x;
+      ay += sv.y;
+    }
+    wave_lds_sync();
+    const float rx = dinv * ax, ry = dinv * ay;
+    sx = dinv * rx;
+    sy = dinv * ry;
+    if (live) coef[(int64_t)i * n + t] = make_float2(rx, ry);
+    // label column of operator i+1: r[src] + r[dst]  (tuned_SIGN.py:177-185)
+    const float zx = hshflf(rx, pos_src, hb) + hshflf(rx, pos_dst, hb);
+    const float zy = hshflf(ry, pos_src, hb) + hshflf(ry, pos_dst, hb);
+    if (t == 0) {
+      a.job_z[(jid * K + i) * 2] = zx;
+      a.job_z[(jid * K + i) * 2 + 1] = zy;
+    }
+  }
+  if (t < K) a.job_lim[jid * K + t] = n;
+  if (t < 2) {
+    a.row_nodes[rp + t] = ext(t == 0 ? src : dst);
+    if (mirror >= 0) a.row_nodes[mrp + t] = ext(t == 0 ? dst : src);
+  }
+  if (t < kMaxLevels) a.lvl[(int64_t)l * kMaxLevels + t] = t == 0 ? 2 : n;
+  if (t == 0) {
+    Job j;
+    j.coef_off = coff * K;
+    j.ids_off = noff;
+    j.out_row = rp;
+    j.link = l;
+    j.support = n;
+    j.node_a = ext(src);
+    j.node_b = ext(dst);
+    j.z_a = 1;
+    j.z_b = 1;
+    j.mirror_row = mirror >= 0 ? mrp : -1;
+    j.mirror_swap = 1;
+    j.split = 0;
+    a.jobs[jid] = j;
+    const unsigned long long mult = mirror >= 0 ? 2ull : 1ull;
+    atomicAdd(stat_slot(a.tot_support), (unsigned long long)n * mult);
+    atomicAdd(stat_slot(a.tot_edges), (unsigned long long)edges * mult);
+    atomicAdd(stat_slot(a.tot_vol), (unsigned long long)vol * mult);
+  }
+}
+
+template <int K>
+s3grl_status launch_tiny_k(const TinyLinkArgs& a, int width, const int32_t* class_list, int count, hipStream_t stream) {
+  const int per = kTinyThreads / width;
+  const unsigned grid = (unsigned)((count + per - 1) / per);
+  if (width == 32)
+    hipLaunchKernelGGL((link_tiny_kernel<K, 32>), dim3(grid), dim3(kTinyThreads), 0, stream, a, class_list, count);
+  else
+    hipLaunchKernelGGL((link_tiny_kernel<K, 64>), dim3(grid), dim3(kTinyThreads), 0, stream, a, class_list, count);
+  S3GRL_HIP_TRY(hipGetLastError());
+  return S3GRL_OK;
+}
+
+}  // namespace
+
+s3grl_status launch_tiny_class(s3grl_context* ctx, const TinyLinkArgs& a, int K, int width, const int32_t* class_list,
+                               int count, hipStream_t stream) {
+  (void)ctx;
+  if (count <= 0) return S3GRL_OK;
+  switch (K) {
+    case 1: return launch_tiny_k<1>(a, width, class_list, count, stream);
+    case 2: return launch_tiny_k<2>(a, width, class_list, count, stream);
+    case 3: return launch_tiny_k<3>(a, width, class_list, count, stream);
+    case 4: return launch_tiny_k<4>(a, width, class_list, count, stream);
+    case 5: return launch_tiny_k<5>(a, width, class_list, count, stream);
+    case 6: return launch_tiny_k<6>(a, width, class_list, count, stream);
+    case 7: return launch_tiny_k<7>(a, width, class_list, count, stream);
+    case 8: return launch_tiny_k<8>(a, width, class_list, count, stream);
     default: return S3GRL_ERR_INVALID_ARGUMENT;
   }
 }

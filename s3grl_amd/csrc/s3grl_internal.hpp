@@ -431,6 +431,30 @@ s3grl_status launch_hub_class(s3grl_context* ctx, const HubLinkArgs& a, int K, i
                               int count, hipStream_t stream);
 s3grl_status launch_sort_hops(s3grl_context* ctx, const s3grl_plan* p, int32_t* nodes);
 
+// hub.hip, link_tiny_kernel — one-hop PoS links of at most kTinyNodes nodes (two rows per link: no common-
+// neighbour rows), half a wavefront or a wavefront per link: one lane per node, the masked induced adjacency as
+// one 32- / 64-bit mask per lane, no hash, no CSR, no block scans, no barriers.  link_full_kernel spends ~2 000 wave
+// instructions on such a link with a third of its lanes at work (config 5: 763 000 of them, the vector unit
+// 93 % busy).  Class list kTinyList of classify_kernel.
+constexpr int kTinyNodes = 64;   // (up to 32: half a wavefront per link, class list kTinyList; up to 64: a wavefront, kTinyList + 1)
+struct TinyLinkArgs {
+  const int32_t *indptr, *indices, *fwd_indptr, *fwd_indices;
+  const int64_t* links;
+  const int64_t *node_off, *row_ptr, *job_off, *coef_off;
+  const int32_t* mirror_of;
+  int32_t* c_ids;
+  float* c_coef;
+  Job* jobs;
+  float* job_z;
+  int32_t* job_lim;
+  int64_t* row_nodes;
+  int32_t* lvl;
+  unsigned long long *tot_edges, *tot_support, *tot_vol;
+  const int32_t* old_of_new;
+};
+s3grl_status launch_tiny_class(s3grl_context* ctx, const TinyLinkArgs& a, int K, int width, const int32_t* class_list,
+                               int count, hipStream_t stream);
+
 // csr.hip — links whose every operator reaches the whole subgraph (sign_k - 1 >= num_hops: p == n), on
 // graphs of the bitmap flavour with cached balls: the masked induced adjacency is built ONCE per link as a
 // CSR of 16-bit list positions in LDS (member counts per row by a sizing kernel of their own, so that the
@@ -537,7 +561,7 @@ s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_ca
                              const int32_t* lvl_max, int64_t L, int32_t* class_count,
                              int32_t* class_list, bool allow_hash = true, const int32_t* e_cap = nullptr,
                              int stash_slot = 0, const int32_t* perm = nullptr, const int64_t* x_cap = nullptr,
-                             const int32_t* csr_e = nullptr);
+                             const int32_t* csr_e = nullptr, bool tiny_ok = false);
 // one-hop plans on big graphs (s3grl_onehop.inl): degree-oriented rows of the graph, and the
 // sizing pass that needs no bitmaps
 bool sparse_mode_for(const s3grl_graph* g);

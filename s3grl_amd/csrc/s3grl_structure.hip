@@ -696,7 +696,8 @@ constexpr int kFullBig = kFullBase + kNumClasses;
 // kHubBase.. = one-hop links with a cached hub neighbourhood, link_hub_kernel (s3grl_hub.hip) by LDS need
 constexpr int kHubBase = kFullBig + 1;
 constexpr int kNumLists = kHubBase + kHubClasses + 1;   // (+ the class with its found edges in HBM slices)
-static_assert(kNumLists <= 29, "class_count[29..31] carry maxima");
+constexpr int kTinyList = kNumLists;   // one-hop PoS links of at most kTinyNodes nodes: link_tiny_kernel (s3grl_hub.hip)
+static_assert(kTinyList + 1 < 29, "class_count[29..31] carry maxima");
 // kCsrBase.. (s3grl_internal.hpp) = full-reach links on their induced LDS CSR, link_csr_kernel (s3grl_csr.hip)
 constexpr int kNumListsAll = kCsrBase + kCsrClasses;
 
@@ -708,7 +709,7 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
                                 int32_t* __restrict__ class_count, int32_t* __restrict__ class_list,
                                 const int32_t* __restrict__ perm, const int64_t* __restrict__ x_cap,
                                 ClassBounds hbound, const int32_t* __restrict__ csr_e, CsrBounds cbound, int W,
-                                int csr_pct) {
+                                int csr_pct, int tiny_max_n) {
   const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   // (perm: the class lists come out in the plan's processing order, up to the order of the atomics)
   const int64_t l = li < L ? (perm ? (int64_t)perm[li] : li) : L;
@@ -743,6 +744,10 @@ __global__ void classify_kernel(const int32_t* __restrict__ n_nodes,
       c = kHubBase + kHubClasses;
       atomicMax(&class_count[29], (int)xb);   // sizes the HBM slices of that class
     }
+  }
+  if (!sparse && e_cap && n > 0 && p == n && n <= tiny_max_n) {   // (tiny_max_n = 0: plans with common-neighbour rows)
+    sparse = true;
+    c = kTinyList + (n > 32 ? 1 : 0);
   }
   if (!sparse && e_cap && n > 0 && p == n && n <= 65535) {
     const int ec = e_cap[l];
@@ -1963,8 +1968,12 @@ s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_ca
                              const int32_t* n_nodes, const int32_t* p_nodes,
                              const int32_t* lvl_max, int64_t L, int32_t* class_count,
                              int32_t* class_list, bool allow_hash, const int32_t* e_cap, int stash_slot,
-                             const int32_t* perm, const int64_t* x_cap, const int32_t* csr_e) {
+                             const int32_t* perm, const int64_t* x_cap, const int32_t* csr_e, bool tiny_ok) {
   if (L == 0) return S3GRL_OK;
+  // link_tiny_kernel takes the smallest one-hop links of plans without common-neighbour rows (never a list that
+  // a test hook would split: S3GRL_SPLIT_SEG_SHIFT below 6)
+  const char* segs = getenv("S3GRL_SPLIT_SEG_SHIFT");
+  const int tiny_max_n = (tiny_ok && !getenv("S3GRL_NO_TINY") && !(segs && atoi(segs) < 6)) ? kTinyNodes : 0;
   ClassBounds cb = class_bounds(g->num_nodes, cn_cap, K);
   const bool dm = allow_hash && stash_slot > 0 && dm_mode_for(g);
   if (cb.b[kNumClasses - 1] < 0 || getenv("S3GRL_FORCE_EXT_BITMAPS")) {
@@ -1986,7 +1995,7 @@ s3grl_status launch_classify(s3grl_context* ctx, const s3grl_graph* g, int cn_ca
                      getenv("S3GRL_FORCE_BM_HBM") ? 0 : (1 << 30),   // test hook: bit matrices in HBM
                      dm ? std::min(stash_slot + 2, 65535) : 0, dm ? dm_class_mask_for(g, cn_cap, K) : 0,
                      class_count, class_list, perm, x_cap, hb, csr_e, csrb, words_for(g->num_nodes),
-                     getenv("S3GRL_CSR_LDS_PCT") ? std::max(100, atoi(getenv("S3GRL_CSR_LDS_PCT"))) : 100);
+                     getenv("S3GRL_CSR_LDS_PCT") ? std::max(100, atoi(getenv("S3GRL_CSR_LDS_PCT"))) : 100, tiny_max_n);
   S3GRL_HIP_TRY(hipGetLastError());
   return S3GRL_OK;
 }
@@ -2137,9 +2146,9 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
   static const int only = getenv("S3GRL_ONLY_CLASS") ? atoi(getenv("S3GRL_ONLY_CLASS")) : -1;
   int32_t class_count_host[kNumListsAll];
   for (int c = 0; c < kNumListsAll; ++c)
-    class_count_host[c] = (only < 0 || c == only || (c >= kNumLists && c < kCsrBase)) ? class_count_in[c] : 0;
+    class_count_host[c] = (only < 0 || c == only || (c > kTinyList + 1 && c < kCsrBase)) ? class_count_in[c] : 0;
   int launches = 0;
-  for (int c = 0; c < kNumLists; ++c) launches += class_count_host[c] > 0 && c != kNumClasses + 1;
+  for (int c = 0; c <= kTinyList + 1; ++c) launches += class_count_host[c] > 0 && c != kNumClasses + 1;
   for (int c = kCsrBase; c < kNumListsAll; ++c) launches += class_count_host[c] > 0;
   const bool fork = !serial && launches > 1;
   if (fork) {
@@ -2199,6 +2208,16 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
                   a.hub_slices, a.hub_slice_words, a.hub_slice_grid};
     S3GRL_TRY(launch_hub_class(ctx, h, K, c - kHubBase, a.class_list + (int64_t)c * L, class_count_host[c],
                                next_stream()));
+  }
+  for (int w = 0; w < 2; ++w) {   // the smallest one-hop links, half a wavefront / a wavefront each (s3grl_hub.hip)
+    if (class_count_host[kTinyList + w] == 0) continue;
+    TinyLinkArgs t{a.g->indptr, a.g->indices, a.g->fwd_indptr, a.g->fwd_indices, a.links, a.node_off, a.row_ptr,
+                   a.job_off, a.coef_off, a.mirror_of, a.c_ids, a.c_coef, a.jobs, a.job_z, a.job_lim, a.row_nodes,
+                   a.lvl, reinterpret_cast<unsigned long long*>(a.tot_edges),
+                   reinterpret_cast<unsigned long long*>(a.tot_support),
+                   reinterpret_cast<unsigned long long*>(a.tot_vol), a.old_of_new};
+    S3GRL_TRY(launch_tiny_class(ctx, t, K, w == 0 ? 32 : 64, a.class_list + (int64_t)(kTinyList + w) * L,
+                                class_count_host[kTinyList + w], next_stream()));
   }
   for (int c = kFullBig - 1; c >= kFullBase; --c) {
     const int count = class_count_host[c];
