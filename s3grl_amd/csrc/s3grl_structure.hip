@@ -2151,9 +2151,28 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
   for (int c = 0; c <= kTinyList + 1; ++c) launches += class_count_host[c] > 0 && c != kNumClasses + 1;
   for (int c = kCsrBase; c < kNumListsAll; ++c) launches += class_count_host[c] > 0;
   const bool fork = !serial && launches > 1;
+  // the side streams rejoin the context's stream on EVERY way out: a launch that fails half-way must not leave
+  // kernels of this plan running beside whatever the caller queues next (its buffers go back to the arena)
+  struct SideJoin {
+    s3grl_context* ctx;
+    bool armed = false;
+    hipError_t join() {
+      hipError_t first = hipSuccess;
+      if (armed)
+        for (int i = 0; i < s3grl_context::kSide; ++i) {
+          hipError_t e = hipEventRecord(ctx->side_ev[i], ctx->side[i]);
+          if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->side_ev[i], 0);
+          if (e != hipSuccess && first == hipSuccess) first = e;
+        }
+      armed = false;
+      return first;
+    }
+    ~SideJoin() { (void)join(); }
+  } side_join{ctx};
   if (fork) {
     S3GRL_TRY(side_streams(ctx));
     S3GRL_HIP_TRY(hipEventRecord(ctx->side_ev[s3grl_context::kSide], ctx->stream));
+    side_join.armed = true;
     for (int i = 0; i < s3grl_context::kSide; ++i)
       S3GRL_HIP_TRY(hipStreamWaitEvent(ctx->side[i], ctx->side_ev[s3grl_context::kSide], 0));
   }
@@ -2270,11 +2289,7 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
     else if (t <= 512) S3GRL_TRY((launch_link_class<512, K>(ctx, a, L, c, count, next_stream())));
     else S3GRL_TRY((launch_link_class<1024, K>(ctx, a, L, c, count, next_stream())));
   }
-  if (fork)
-    for (int i = 0; i < s3grl_context::kSide; ++i) {
-      S3GRL_HIP_TRY(hipEventRecord(ctx->side_ev[i], ctx->side[i]));
-      S3GRL_HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->side_ev[i], 0));
-    }
+  S3GRL_HIP_TRY(side_join.join());
   return S3GRL_OK;
 }
 
