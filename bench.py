@@ -163,7 +163,9 @@ def link_kernel_roofline(args, w, link_index, stats, phase_ms, K, F, collect):
     ms = phase_ms["propagate"]
     onehop = stats.get("oriented_entries", 0) > 0
     hub_links = stats.get("hub_links", 0)
-    kname = ("link_full_kernel + link_hub_kernel" if hub_links else "link_full_kernel") if onehop else "link_kernel"
+    # (the families whose counters add up to the phase; collect_pmc keeps those that ran)
+    kname = (("link_full_kernel + link_hub_kernel + link_tiny_kernel" if hub_links
+              else "link_full_kernel + link_tiny_kernel") if onehop else "link_kernel")
     n_ext, vol, sup, pairs = stats["extracted_nodes"], stats["total_volume"], stats["total_support"], stats["num_row_pairs"]
     folded = stats.get("folded_links", 0)
     L = link_index.shape[1]
@@ -206,7 +208,8 @@ def link_kernel_roofline(args, w, link_index, stats, phase_ms, K, F, collect):
         "traffic": traffic, "traffic_source": traffic_source, "l2_hit_rate": l2_hit, "pmc": pmc,
         "limiter": ("LDS issue of the K pulls (cached hub rows + found edges, a few entries per row) and of the "
                     "neighbour tests of the walked rows (link_hub_kernel); dependent-load latency of the per-link "
-                    "chain rows -> rank merge -> hash -> oriented-row probes -> CSR -> K pulls (link_full_kernel): "
+                    "chain rows -> rank merge -> hash -> oriented-row probes -> CSR -> K pulls (link_full_kernel; "
+                    "links of at most 64 nodes: one lane per node, no barrier, link_tiny_kernel): "
                     "the classes' serial times add up to the phase, HBM (this fraction) is not the bound") if onehop else
                    "VALU issue of the row walk (76-86 % busy at under half of its lanes), DESIGN §2.1",
         "phase_ms": phase_ms,

@@ -245,12 +245,13 @@ s3grl_status s3grl_plan_export_subgraphs(const s3grl_plan* p, int64_t* node_ptr,
  * measured — what a multi-GPU caller balances its shards by (a count-only plan is enough).  The
  * model follows the kernels and was fitted on MI355X: multi-hop plans  pairs * n + 400  (gather and
  * row walks grow with the subgraph and with the row pairs of PoS Plus, ~400 nodes' worth of fixed
- * work per link); one-hop plans on big graphs  e_bound + 150 + (pairs - 1) * n  with e_bound the
+ * work per link); one-hop plans on big graphs  e_bound + 220 + (pairs - 1) * n  with e_bound the
  * bound of the induced entries the sizing pass derives from the degree-oriented rows (a hub-rich
  * positive costs several times a random negative of the collab-scale workload; node counts alone
  * say 1.5x) — except for the links served from a cached hub neighbourhood (plan statistics: hub_links),
- * whose oriented rows are not probed:  12.8 * n + 1420 + (pairs - 1) * n  (both fitted with
- * tools/cost_fit_onehop.py: the two kinds of links timed apart, two size buckets each).  A reversed duplicate (d,s) that the plan folds into its primary (s,d) costs 250: its two
+ * whose oriented rows are not probed:  12.1 * n + 1380 + (pairs - 1) * n  (both fitted with
+ * tools/cost_fit_onehop.py: the two kinds of links timed apart, two size buckets each; round 4, after
+ * link_tiny_kernel and gather_narrow_kernel: profiles/r04_cost_fit_onehop.txt).  A reversed duplicate (d,s) that the plan folds into its primary (s,d) costs 250: its two
  * output rows and bookkeeping (least squares over the shards of 2-, 4- and 8-way splits of PubMed:
  * 410 / 290 at sign_k = 3, 310 / 260 at sign_k = 5) — so the cost of a pair is what ONE rank pays for it when both directions are kept
  * together (s3grl_amd.parallel.shard_assignment); with S3GRL_FLAG_NO_FOLD every link is priced in full. */

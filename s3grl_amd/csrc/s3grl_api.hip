@@ -164,7 +164,7 @@ __global__ void max_i32_kernel(const int32_t* __restrict__ in, int64_t n, int64_
   if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<long long*>(out), (long long)m);
 }
 
-constexpr float kHubCostSlope = 12.8f;   // cost of a link at a cached hub per node of its subgraph (S3GRL_HUB_COST_SLOPE: fitting hook)
+constexpr float kHubCostSlope = 12.1f;   // cost of a link at a cached hub per node of its subgraph (S3GRL_HUB_COST_SLOPE: fitting hook)
 
 __global__ void link_cost_kernel(const int32_t* __restrict__ n_nodes, const int32_t* __restrict__ e_cap,
                                  const int64_t* __restrict__ x_cap, const int64_t* __restrict__ row_ptr, int64_t L,
@@ -183,8 +183,8 @@ __global__ void link_cost_kernel(const int32_t* __restrict__ n_nodes, const int3
   const float pairs = (float)((row_ptr[l + 1] - row_ptr[l] + 1) / 2);
   // one-hop plans on big graphs: a link served from a cached hub neighbourhood (link_hub_kernel) costs
   // its pulls and its gather, both ~ n; the others the probes of their oriented rows
-  if (x_cap && x_cap[l] >= 0) cost[l] = hub_slope * (float)n + 1420.f + (pairs - 1.f) * (float)n;
-  else cost[l] = e_cap ? (float)e_cap[l] + 150.f + (pairs - 1.f) * (float)n
+  if (x_cap && x_cap[l] >= 0) cost[l] = hub_slope * (float)n + 1380.f + (pairs - 1.f) * (float)n;
+  else cost[l] = e_cap ? (float)e_cap[l] + 220.f + (pairs - 1.f) * (float)n
                        : pairs * (float)n + 400.f;
 }
 

@@ -26,7 +26,7 @@ K, F = w.sign_k, w.X.shape[1]
 n = eng.subgraph_sizes(g, eng.links(li), num_hops=1).cpu().numpy().astype(np.float64)
 cost = eng.link_costs(g, eng.links(li), num_hops=1, mode="pos", fold_reversed=False).cpu().numpy().astype(np.float64)
 hub = cost >= 999.0 * n
-ecap = np.where(hub, 0.0, cost - 150.0)
+ecap = np.where(hub, 0.0, cost - 220.0)
 print(f"{hub.sum()} hub links (mean n {n[hub].mean():.0f}), {(~hub).sum()} others (mean n {n[~hub].mean():.1f}, mean e_bound {ecap[~hub].mean():.1f})")
 
 

@@ -18,7 +18,7 @@ from collections import defaultdict
 from pathlib import Path
 
 REPO = Path(__file__).resolve().parent.parent
-FAMILIES = ["gather_packed_kernel", "gather_sparse_kernel", "gather_narrow_kernel", "gather_kernel", "link_full_kernel", "link_hub_kernel", "link_csr_kernel", "link_kernel",
+FAMILIES = ["gather_packed_kernel", "gather_sparse_kernel", "gather_narrow_kernel", "gather_kernel", "link_full_kernel", "link_hub_kernel", "link_tiny_kernel", "link_csr_kernel", "link_kernel",
             "csr_count_kernel", "count_balls_kernel", "count1_kernel", "count_kernel", "combine_kernel", "sop_rows_kernel", "sop_scalar_kernel",
             "spmm_norm_kernel"]
 
