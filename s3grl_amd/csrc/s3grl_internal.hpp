@@ -186,7 +186,10 @@ struct HubCache {
 constexpr int kHubMinDegree = 128;
 constexpr int kHubClasses = 4;           // LDS classes of link_hub_kernel: 128 / 256 / 512 / 1024 threads; one more
                                          // (index kHubClasses) keeps its list of found edges in HBM slices
-constexpr int64_t kHubVolMax = 65536;    // Σ degree over the other endpoint's neighbourhood: beyond, the old path
+// Σ degree over the other endpoint's neighbourhood: beyond, the old path (it sizes the HBM slices of the class whose
+// found edges do not fit LDS).  65 536 until round 4: the 561 hub - hub links of config 5 beyond it cost 2.2 ms on
+// link_full_kernel's big class and the general kernel, one after the other; here 0.4 ms of the phase less.
+constexpr int64_t kHubVolMax = 262144;
 
 // BFS balls of every node of the degree-ordered graph as N-bit bitmaps (s3grl_balls.hip): level d - 1 of
 // `bits` holds ball_d(x) = the nodes within d hops of x, x included, for all x — built on first use, level by

@@ -287,8 +287,9 @@ def test_cached_hub_neighbourhoods_equal_the_per_link_road(eng, monkeypatch, mod
     assert sa == sb and torch.equal(pa, pb) and torch.equal(na, nb_)
     assert all(torch.equal(x, y) for x, y in zip(ea, eb))
     assert not torch.equal(ra, rb)                        # (another summation order: the cache WAS used)
-    # (fp32 round-off of two summation orders; the narrow gather sums a list front to back)
-    assert rel_err(rb.cpu().numpy(), ra.cpu().numpy()) < 5e-6
+    # (fp32 round-off of two summation orders; the narrow gather sums a list front to back, and the hub - hub
+    # links of this list — thousands of nodes — take the cached road too since the volume cap was raised)
+    assert rel_err(rb.cpu().numpy(), ra.cpu().numpy()) < 8e-6
     from oracle import c_oracle
 
     ref, ptr, _, _ = c_oracle.pos_rows(links.T, 1, A, X, 3, plus=mode == "pos_plus")
