@@ -40,8 +40,14 @@ namespace {
 // row up to kHubTinyRow entries, four lanes up to kHubLongRow, a whole wavefront beyond (at most
 // kHubLongCap rows per link — the first in row order — further ones stay with their four lanes).  (Row
 // counts per tier travel through one block scan packed 16 + 16 bits: a link here has a few thousand rows.)
-constexpr int kHubTinyRow = 4;
-constexpr int kHubLongRow = 48;
+#ifndef S3GRL_HUB_TINY_ROW
+#define S3GRL_HUB_TINY_ROW 4
+#endif
+#ifndef S3GRL_HUB_LONG_ROW
+#define S3GRL_HUB_LONG_ROW 48
+#endif
+constexpr int kHubTinyRow = S3GRL_HUB_TINY_ROW;   // (build-time tuning hooks, like S3GRL_HUB_G)
+constexpr int kHubLongRow = S3GRL_HUB_LONG_ROW;
 constexpr int kHubLongCap = 128;
 constexpr int kHubShWords = 72;   // 40 of scan / counter words, 32 of row 0's partial sums
 #ifndef S3GRL_HUB_G
