@@ -10,11 +10,16 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rocprofv3 --list-avail > "$out/avail.txt" 2>&1 || true
 i=0
-for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" \
+if [ -n "$SQ_PROBE_SETS" ]; then   # own counter sets, separated by ';'  (e.g. "TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum")
+  IFS=';' read -ra sets <<< "$SQ_PROBE_SETS"
+else
+  sets=("SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" \
            "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" \
            "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY" \
-           "SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM SQ_INSTS_FLAT"; do
+           "SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM SQ_INSTS_FLAT")
+fi
+for set in "${sets[@]}"; do
   # (a sixth pass with FETCH_SIZE WRITE_SIZE aborted inside rocprofv3 on collab_pos_k3 and hung the call:
   # the byte counters come from bench.py's own passes, tools/pmc_passes.py)
   echo "pass $((i+1)): $set"
