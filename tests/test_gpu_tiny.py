@@ -138,3 +138,47 @@ def test_tiny_links_with_self_loops_and_both_widths(eng, monkeypatch):
     assert rel_err(res.rows.cpu().numpy(), ref) < TOL
     monkeypatch.delenv("S3GRL_FORCE_ONEHOP", raising=False)
     f.close(), G.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+@pytest.mark.parametrize("K", [2, 4, 8])
+def test_tiny_links_fuzz_vs_c(eng, monkeypatch, seed, K):
+    """Random sparse graphs of mixed shape (isolated nodes, leaves, a few denser nodes, self-loops), links between
+    adjacent and non-adjacent nodes, endpoints without neighbours, reversed duplicates: node lists and row nodes
+    exactly, rows within the tolerance, every sign_k instantiation of the kernel that the other tests leave out."""
+    from oracle import c_oracle
+    from s3grl_amd import workloads
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.choice([200, 1500, 6000]))
+    m = int(n * rng.choice([0.6, 1.5, 4.0]))
+    e = rng.integers(0, n, size=(m, 2))
+    if seed % 2:   # a few denser nodes
+        hubs = rng.choice(n, 5, replace=False)
+        e = np.concatenate([e, np.stack([rng.choice(hubs, 40 * 5), rng.integers(0, n, 40 * 5)], 1)])
+    e = np.unique(np.sort(e, axis=1), axis=0)
+    loops = e[e[:, 0] == e[:, 1]][:, 0]
+    e = e[e[:, 0] != e[:, 1]]
+    A = workloads.csr_from_undirected(n, e)
+    if len(loops):
+        A = (A + sp.diags((np.bincount(loops, minlength=n) > 0).astype(A.dtype))).tocsr()
+        A.sort_indices()
+    pos = e[rng.choice(len(e), min(len(e), 400), replace=False)]
+    neg = rng.integers(0, n, size=(400, 2))
+    links = np.concatenate([pos, neg, pos[:20, ::-1]])
+    links = links[links[:, 0] != links[:, 1]]
+    X = rng.standard_normal((n, int(rng.choice([5, 64, 128])))).astype(np.float32)
+    monkeypatch.setenv("S3GRL_FORCE_ONEHOP", "1")
+    G = eng.graph(A)
+    f = eng.features(X)
+    L = eng.links(links.T)
+    counts = _class_counts(eng, monkeypatch, G, L, K)
+    assert counts[26] + counts[27] > 0
+    res = eng.precompute(G, f, L, mode="pos", num_hops=1, sign_k=K)
+    ref, ptr, nodes, _ = c_oracle.pos_rows(links.T, 1, A, X, K, plus=False)
+    assert np.array_equal(res.row_nodes.cpu().numpy(), nodes)
+    assert np.array_equal(res.row_ptr.cpu().numpy(), ptr)
+    assert rel_err(res.rows.cpu().numpy(), ref) < TOL
+    monkeypatch.delenv("S3GRL_FORCE_ONEHOP", raising=False)
+    f.close(), G.close()
