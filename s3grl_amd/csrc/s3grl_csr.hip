@@ -34,7 +34,10 @@
 namespace s3grl {
 namespace {
 
-constexpr int kCsrCountT = 128;
+#ifndef S3GRL_CSR_COUNT_T
+#define S3GRL_CSR_COUNT_T 128   // threads per link of the sizing walk (build-time tuning hook)
+#endif
+constexpr int kCsrCountT = S3GRL_CSR_COUNT_T;
 #ifndef S3GRL_CSR_COUNT_UN
 #define S3GRL_CSR_COUNT_UN 4   // row groups in flight per lane group of the sizing walk (build-time tuning hook)
 #endif
