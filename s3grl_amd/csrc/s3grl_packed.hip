@@ -592,8 +592,10 @@ __global__ __launch_bounds__(256) void gather_traffic_kernel(
 // row has ~42 of 128) — and the multiply-adds use it for both halves: what the kernel would cost if the texture
 // path saw one 1-KiB wave-load per row instead of two (the data would then have to reach its owner lanes
 // through LDS).
+// EXECM (timing only): the chunk loads under an EXEC mask (inline assembly; the lanes of empty slots are switched
+// off instead of being sent out of range) — does the texture addresser charge per ACTIVE lane?
 template <int K, int U, bool DB, int WAVES, int HALVES = 1, bool PIN = false, bool HDRWIN = false, bool VHDR = false,
-          bool ONELOAD = false>
+          bool ONELOAD = false, bool EXECM = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void gather_last_proto_kernel(
     const Job* __restrict__ jobs, int njobs, const int32_t* __restrict__ c_ids, const float* __restrict__ c_coef,
     const int32_t* __restrict__ job_order, const PackedHdr* __restrict__ hdr, const float4_t* __restrict__ data,
@@ -677,6 +679,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         v[u][CH - 1] = v[u][0];
         (void)a0;
         (void)a1;
+      } else if constexpr (EXECM) {
+        const uint64_t mm0 = ok ? h[u].m0 : 0ull, mm1 = ok ? h[u].m1 : 0ull;
+        v[u][0] = (float4_t)(0.f);
+        v[u][CH - 1] = (float4_t)(0.f);
+        asm volatile("s_mov_b64 exec, %2\n\tbuffer_load_dwordx4 %0, %4, %6, 0 offen\n\t"
+                     "s_mov_b64 exec, %3\n\tbuffer_load_dwordx4 %1, %5, %6, 0 offen\n\ts_mov_b64 exec, -1"
+                     : "+v"(v[u][0]), "+v"(v[u][CH - 1])
+                     : "s"(mm0), "s"(mm1), "v"(a0), "v"(a1), "s"(rsrc)
+                     : "memory");
       } else {
         v[u][0] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(
                                                    rsrc, (int)select_or_oob(ok ? h[u].m0 : 0ull, a0, oobv), 0, 0));
@@ -685,7 +696,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
       }
     }
   };
-  auto fma = [&](int g, const float4_t(&v)[U][CH]) __attribute__((always_inline)) {
+  auto fma = [&](int g, float4_t(&v)[U][CH]) __attribute__((always_inline)) {
+    if constexpr (EXECM) {   // the compiler does not see those loads: wait for all of them, the values tied to the wait
+#pragma unroll
+      for (int u = 0; u < U; ++u) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[u][0]), "+v"(v[u][CH - 1]));
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const float2 q = cf[min(g * U + u, cnt - 1)];
@@ -778,6 +793,18 @@ s3grl_status launch_packed_k(s3grl_context* ctx, const s3grl_plan* p, const Gath
       case 16: S3GRL_PROTO_O(4, true, 8, true); break;     // ... two buffers of four rows (16 VGPRs each)
       case 17: S3GRL_PROTO_O(4, false, 8, false); break;   // ... scalar headers
 #undef S3GRL_PROTO_O
+      case 21:   // chunk loads under an EXEC mask, scalar headers, one buffer of four rows, eight waves
+        hipLaunchKernelGGL((gather_last_proto_kernel<K, 4, false, 8, 1, false, false, false, false, true>),
+                           dim3((unsigned)v.njobs, (unsigned)f->tiles), dim3(64), 0, stream, v.jobs, (int)v.njobs,
+                           p->c_ids, p->c_coef, v.job_order, static_cast<const PackedHdr*>(f->pk_hdr),
+                           static_cast<const float4_t*>(f->pk_data), db, f->N, (int)f->F, rows);
+        break;
+      case 22:   // ... vector headers
+        hipLaunchKernelGGL((gather_last_proto_kernel<K, 4, false, 8, 1, false, false, true, false, true>),
+                           dim3((unsigned)v.njobs, (unsigned)f->tiles), dim3(64), 0, stream, v.jobs, (int)v.njobs,
+                           p->c_ids, p->c_coef, v.job_order, static_cast<const PackedHdr*>(f->pk_hdr),
+                           static_cast<const float4_t*>(f->pk_data), db, f->N, (int)f->F, rows);
+        break;
       default: S3GRL_PROTO(2, false, 8); break;
     }
 #undef S3GRL_PROTO

@@ -24,7 +24,7 @@ for set in "${sets[@]}"; do
   # the byte counters come from bench.py's own passes, tools/pmc_passes.py)
   echo "pass $((i+1)): $set"
   i=$((i+1))
-  S3GRL_SERIAL_CLASSES=1 rocprofv3 --pmc $set -d "$out/p$i" -o p --output-format csv -- \
+  S3GRL_SERIAL_CLASSES=1 timeout -k 10 150 rocprofv3 --pmc $set -d "$out/p$i" -o p --output-format csv -- \
     python3 bench.py --workload $wl --steps 1 --warmup 0 --no-cpu-baseline --no-api --no-pmc --no-cold-run \
     > "$out/p$i.json" 2> "$out/p$i.err" || echo "pass $i failed"
 done
