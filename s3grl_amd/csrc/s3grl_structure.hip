@@ -2245,7 +2245,9 @@ s3grl_status launch_links_k(s3grl_context* ctx, const LinkArgs& a, int64_t L,
     // leaves one or two workgroups per CU get 1024 / 512 threads (their probing trips are chains
     // of dependent loads: more rows per trip, more loads in flight)
     const int fc = c - kFullBase;
-    int t = fc <= 1 ? 64 : (fc <= 3 ? 256 : (fc == 4 ? 512 : 1024));
+    // (class 2 at 128 threads since the links of at most 64 nodes left for link_tiny_kernel: 16.55 -> 16.3 ms on
+    // config 5; 64: 16.75, 256: 16.55, 512: 18.2)
+    int t = fc <= 1 ? 64 : (fc == 2 ? 128 : (fc == 3 ? 256 : (fc == 4 ? 512 : 1024)));
     {
       char name[32];   // tuning hook
       snprintf(name, sizeof(name), "S3GRL_TF_CLASS%d", fc);
