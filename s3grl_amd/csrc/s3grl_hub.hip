@@ -929,7 +929,10 @@ __device__ __forceinline__ int hlower_bound(int vals, int len, int x, int hb) {
   return lo;
 }
 
-constexpr int kTinyThreads = 256;
+#ifndef S3GRL_TINY_THREADS
+#define S3GRL_TINY_THREADS 256   // threads per workgroup of link_tiny_kernel (build-time tuning hook)
+#endif
+constexpr int kTinyThreads = S3GRL_TINY_THREADS;
 
 template <int K, int W>
 __global__ __launch_bounds__(kTinyThreads) void link_tiny_kernel(const TinyLinkArgs a,
