@@ -152,9 +152,16 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_narrow_kernel(
   }
   const uint32_t row_bytes = (uint32_t)ldx * 4u;   // (launch_k: ldx * 4 < 2^32)
   auto row_of = [&](int id) -> float2_t {
-    // scalar: unsigned 32 x 32 -> 64 bits (the signed 64-bit product cost ten scalar instructions per row)
-    const char* base = reinterpret_cast<const char*>(X) + (uint64_t)(uint32_t)id * row_bytes;
-    return *reinterpret_cast<const float2_t*>(base + voff);
+    // the row's base on the SCALAR unit (unsigned 32 x 32 -> 64 bits; the signed 64-bit product cost ten scalar
+    // instructions per row) and kept there: left to itself the compiler folds product and lane offset into ONE
+    // quarter-rate v_mad_u64_u32 per row — a third of the loop's vector time.  With the product opaque the load
+    // takes the scalar base + 32-bit lane offset form: no vector instruction per row.
+    uint64_t prod = (uint64_t)(uint32_t)id * row_bytes;
+    asm volatile("" : "+s"(prod));
+    const char* base = reinterpret_cast<const char*>(X) + prod;
+    uint32_t vo = voff;            // (opaque as well: hoisted, X + voff becomes a 64-bit vector add per row again)
+    asm volatile("" : "+v"(vo));
+    return *reinterpret_cast<const float2_t*>(base + vo);
   };
   // One scalar round trip per group instead of two: the ids of group g + 1 are fetched together with the
   // coefficients of group g, so that a group's row loads go out at the top of its step with nothing to wait for
