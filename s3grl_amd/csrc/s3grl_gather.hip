@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gather_narrow_kernel(
     int64_t ldx, int F, float* __restrict__ rows_out, float* __restrict__ prows,
     const int32_t* __restrict__ job_order) {
   // rows of X in flight per wavefront: as many as leave a group's 2·K·U coefficient scalars (and 2U ids) in SGPRs
-  constexpr int U = K <= 3 ? S3GRL_GATHER_NARROW_UNROLL : (K <= 6 ? S3GRL_GATHER_NARROW_UNROLL / 2 : 3);
+  constexpr int U = K <= 3 ? S3GRL_GATHER_NARROW_UNROLL : (K == 4 ? 6 : (K == 5 ? 5 : (K == 6 ? 4 : 3)));
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
   if (wid >= njobs) return;
